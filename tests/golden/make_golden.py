@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE implementation.
+
+Runs ONLY in the build container, where /root/reference is mounted: it imports the reference's
+PyTorch streaming modules (onnx_model/dpdfnet.py, onnx_model/dpdfnet_48khz_hr.py) and host code
+(package/src/dpdfnet/{audio,stream}.py), loads OUR portable seeded synthetic weights into them
+(the reference ships no checkpoints and no network goldens) and records
+inputs + expected outputs as small .npz files.  Nothing of the reference itself is stored:
+fixtures are data only (waveforms, spectra, state vectors, per-stage activations).
+
+    python tests/golden/make_golden.py            # regenerates every fixture
+
+The fixtures pin (a) the CPU oracle (tests/test_oracle_golden.py, no GPU) and (b) through the
+oracle and directly, the HIP path (tests/test_gpu_parity.py, -m gpu).
+"""
+from __future__ import annotations
+
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parents[2]
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+SEED = 20260417
+PROBE_FRAMES = (0, 1, 2, 5, 50)
+
+
+def synth_clip(n: int, sr: int, seed: int) -> np.ndarray:
+    """SURVEY.md section 8(d) synthetic input: 0.05 N(0,1) + AM sinusoid, clipped to [-1,1]."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n, dtype=np.float64) / sr
+    f0 = rng.uniform(100.0, 1000.0)
+    x = 0.05 * rng.standard_normal(n) + 0.1 * np.sin(2 * np.pi * f0 * t) * (1.0 + np.sin(2 * np.pi * 3.0 * t))
+    return np.clip(x, -1.0, 1.0).astype(np.float32)
+
+
+def _stub_modules():
+    for name in ("soundfile", "librosa", "onnxruntime"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    ort = sys.modules["onnxruntime"]
+    if not hasattr(ort, "InferenceSession"):
+        ort.InferenceSession = object
+        ort.SessionOptions = object
+        ort.GraphOptimizationLevel = types.SimpleNamespace(ORT_ENABLE_ALL=0)
+
+
+def build_reference_model(sr: int, nb: int, blob: np.ndarray, entries):
+    import torch
+    from dpdfnet_amd.weights import unpack_to_streaming_state_dict
+
+    if sr == 16000:
+        from onnx_model.dpdfnet import DPDFNet as Net
+    else:
+        from onnx_model.dpdfnet_48khz_hr import DPDFNet48HR as Net
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = Net(dprnn_num_blocks=nb).eval()
+    sd = {k: torch.from_numpy(v) for k, v in unpack_to_streaming_state_dict(entries, blob).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    allowed = ("erb_fb", "erb_inv_fb", "mask.erb_inv_fb", "stft.w", "istft.w_inv", "istft_norm.w_inv",
+               "enc.lsnr_fc.0.weight", "enc.lsnr_fc.0.bias")
+    bad = [k for k in missing if k not in allowed and "num_batches_tracked" not in k]
+    assert not bad, f"manifest does not cover reference tensors: {bad}"
+    return model
+
+
+def run_reference_frames(model, spec_unnorm: np.ndarray, probe_frames=PROBE_FRAMES, state=None):
+    """spec_unnorm [T,F,2] (librosa-style unnormalised STFT) -> dict of goldens.  Applies the export
+    wrapper's x wnorm / / wnorm (reference onnx_model/export_dpdfnet_to_onnx.py:14-25)."""
+    import torch
+
+    acts = {}
+
+    def grab(name, pick=lambda o: o):
+        def hook(_m, _i, o):
+            acts[name] = pick(o).detach().cpu().numpy().copy()
+        return hook
+
+    first = lambda o: o[0]
+    hooks = [
+        model.erb_norm.register_forward_hook(grab("feat_erb", first)),      # [1,1,E]
+        model.spec_norm.register_forward_hook(grab("feat_spec_ri", first)),  # [1,1,D,2]
+        model.enc.erb_conv0.register_forward_hook(grab("e0")),
+        model.enc.erb_conv1.register_forward_hook(grab("e1")),
+        model.enc.erb_conv2.register_forward_hook(grab("e2")),
+        model.enc.erb_conv3.register_forward_hook(grab("e3")),
+        model.enc.df_conv0.register_forward_hook(grab("c0")),
+        model.enc.df_conv1.register_forward_hook(grab("c1")),
+        model.enc.emb_gru.register_forward_hook(grab("emb", first)),
+        model.erb_dec.register_forward_hook(grab("m", first)),
+        model.df_dec.register_forward_hook(grab("coefs_fk", first)),        # [1,1,D,10]
+    ]
+    if hasattr(model.enc.dprnn_erb, "blocks"):
+        hooks.append(model.enc.dprnn_erb.register_forward_hook(grab("e3_dprnn", first)))
+        hooks.append(model.enc.dprnn_df.register_forward_hook(grab("c1_dprnn", first)))
+
+    wnorm = np.float32(model.wnorm)
+    inv_wnorm = np.float32(1.0 / float(model.wnorm))
+    T = spec_unnorm.shape[0]
+    st = model.initial_state(dtype=torch.float32) if state is None else torch.from_numpy(state.copy())
+    init_state = st.numpy().copy()
+    out = np.zeros_like(spec_unnorm)
+    probes = {}
+    with torch.no_grad():
+        for t in range(T):
+            x = torch.from_numpy(spec_unnorm[t:t + 1][None]) * torch.tensor(wnorm)
+            y, st = model(x, st)
+            out[t] = (y * torch.tensor(inv_wnorm)).numpy()[0, 0]
+            if t in probe_frames:
+                for k, v in acts.items():
+                    probes[f"f{t}_{k}"] = v.reshape(-1).astype(np.float32)
+    for h in hooks:
+        h.remove()
+    return dict(spec_e=out, state_out=st.numpy().copy(), init_state=init_state, **probes)
+
+
+def make_model_fixture(tag: str, sr: int, nb: int, seconds: float, seed: int, attn_dbs=(0.0, 12.0)):
+    import torch
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import parse_manifest_text, synth_blob
+
+    entries = parse_manifest_text(orc.manifest_text(sr, nb))
+    blob = synth_blob(entries, seed)
+    model = build_reference_model(sr, nb, blob, entries)
+    n = int(seconds * sr)
+    wav = synth_clip(n, sr, seed + 1)
+    win = model.stft.win_len
+
+    # reference analysis: onnx_model/dpdfnet.py:854-860 (pad win, torch.stft center/reflect), but
+    # kept UNNORMALISED as package/src/dpdfnet/audio.py:104-117 hands it to session.run
+    with torch.no_grad():
+        audio_pad = torch.nn.functional.pad(torch.from_numpy(wav)[None], (0, win))
+        spec_c = model.stft(audio_pad).transpose(1, 2)[0]           # [T,F] complex64
+    spec = torch.view_as_real(spec_c).numpy().astype(np.float32)     # [T,F,2]
+    g = run_reference_frames(model, spec)
+
+    # reference synthesis: torch.istft == librosa.istft semantics (dpdfnet.py:862-873, audio.py:120-136)
+    def synth(spec_e: np.ndarray) -> np.ndarray:
+        with torch.no_grad():
+            c = torch.view_as_complex(torch.from_numpy(np.ascontiguousarray(spec_e)))[None]  # [1,T,F]
+            audio = model.istft(c.transpose(1, 2))
+            audio = torch.nn.functional.pad(audio[:, win * 2:], (0, win * 2))
+        a = audio[0].numpy()
+        out = np.zeros(n, dtype=np.float32)
+        m = min(n, a.shape[0])
+        out[:m] = a[:m]                                              # fit_length audio.py:30-38
+        return out
+
+    fix = dict(
+        wav=wav, spec_head=spec[:8].copy(), spec_tail=spec[-4:].copy(),
+        enhanced=synth(g["spec_e"]),
+        spec_e_head=g["spec_e"][:64].copy(), state_out=g["state_out"], init_state=g["init_state"],
+    )
+    fix.update({k: v for k, v in g.items() if k.startswith("f")})
+    # attenuation limit: the reference's own apply_attn_limit (package/src/dpdfnet/audio.py:41-76)
+    from dpdfnet.audio import apply_attn_limit
+    for db in attn_dbs:
+        se = apply_attn_limit(spec[None], g["spec_e"][None], db)[0]
+        fix[f"enhanced_attn{int(db)}"] = synth(se)
+    meta = dict(tag=tag, sample_rate=sr, nb=nb, seed=seed, n=n, T=int(spec.shape[0]),
+                state_size=int(model.state_size()), n_weights=int(blob.size),
+                probe_frames=list(PROBE_FRAMES))
+    fix["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / f"model_{tag}.npz", **fix)
+    print(f"[golden] model_{tag}.npz  T={spec.shape[0]} S={model.state_size()} "
+          f"rms_in={np.sqrt(np.mean(wav**2)):.4f} rms_out={np.sqrt(np.mean(fix['enhanced']**2)):.4f} "
+          f"m~[{g['f50_m'].min():.3f},{g['f50_m'].max():.3f}] coefs_rms={np.sqrt(np.mean(g['f50_coefs_fk']**2)):.3f}")
+    return model, entries, blob
+
+
+def make_constants_fixture():
+    """Config-derived constants the reference computes: vorbis window, ERB band widths, norm inits,
+    48 kHz empirical init tables (onnx_model/init_norms.py), state sizes, manifest shapes."""
+    import io, contextlib
+    import torch
+    from model.utils import vorbis_window, erb_filter_banks, get_wnorm
+    from onnx_model.layers import ErbNorm, SpecNorm, MagNorm48, SpecNorm48
+    from dpdfnet.audio import vorbis_window as pkg_window
+
+    fb = erb_filter_banks(nfft=320, low_freq=0, fs=16000, n_filters=32, min_nb_freqs=1)
+    out = dict(
+        window_320=vorbis_window(320).numpy(), window_960=vorbis_window(960).numpy(),
+        pkg_window_320=pkg_window(320), pkg_window_960=pkg_window(960),
+        erb_widths_16k=fb.sum(axis=1).astype(np.int32),
+        wnorm_16k=np.float32(get_wnorm(320, 160)), wnorm_48k=np.float32(get_wnorm(960, 480)),
+        erb_norm_init_16k=ErbNorm(32, 0.98).initial_state().numpy(),
+        spec_norm_init_16k=SpecNorm(96, 0.98).initial_state().numpy(),
+        erb_norm_init_48k=MagNorm48(481, 0.98).initial_state().numpy(),
+        spec_norm_init_48k=SpecNorm48(96, 0.98).initial_state().numpy(),
+    )
+    sizes = {}
+    from onnx_model.dpdfnet import DPDFNet
+    from onnx_model.dpdfnet_48khz_hr import DPDFNet48HR
+    with contextlib.redirect_stdout(io.StringIO()):
+        for nb in (0, 1, 2, 4, 8):
+            sizes[f"16000_{nb}"] = int(DPDFNet(dprnn_num_blocks=nb).state_size())
+        for nb in (1, 2, 8):
+            sizes[f"48000_{nb}"] = int(DPDFNet48HR(dprnn_num_blocks=nb).state_size())
+    out["state_sizes_json"] = np.frombuffer(json.dumps(sizes).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / "constants.npz", **out)
+    print("[golden] constants.npz", sizes)
+
+
+def make_host_dsp_fixture():
+    """Known answers for the host DSP helpers of the path (package/src/dpdfnet/audio.py)."""
+    from dpdfnet.audio import apply_attn_limit, fit_length, to_mono, pcm16_safe
+    rng = np.random.default_rng(SEED + 77)
+    noisy = rng.standard_normal((1, 9, 5, 2)).astype(np.float32)
+    enh = rng.standard_normal((1, 9, 5, 2)).astype(np.float32)
+    stereo = rng.standard_normal((50, 2)).astype(np.float32)
+    x = rng.uniform(-1.5, 1.5, 64).astype(np.float32)
+    np.savez_compressed(
+        OUT / "host_dsp.npz", noisy=noisy, enh=enh,
+        attn0=apply_attn_limit(noisy, enh, 0.0), attn6=apply_attn_limit(noisy, enh, 6.0),
+        attn_inf=apply_attn_limit(noisy, enh, float("inf")), attn_none=apply_attn_limit(noisy, enh, None),
+        stereo=stereo, mono=to_mono(stereo), x=x, pcm16=pcm16_safe(x),
+        fit_short=fit_length(x, 40), fit_long=fit_length(x, 80),
+    )
+    print("[golden] host_dsp.npz")
+
+
+def make_stream_fixture(model, sr: int, tag: str):
+    """StreamEnhancer goldens: the reference's stream.py driven by (a) a passthrough session and
+    (b) the real frame function, for several chunk sizes (package/src/dpdfnet/stream.py:74-200)."""
+    import torch
+    import dpdfnet.stream as ref_stream
+    from dpdfnet.models import ModelInfo, ResolvedModel
+
+    win = 320 if sr == 16000 else 960
+    F = win // 2 + 1
+
+    class _In:
+        def __init__(self, name, shape): self.name, self.shape = name, shape
+
+    class _Session:
+        def __init__(self, fn): self.fn = fn
+        def get_inputs(self): return [_In("spec", [1, 1, F, 2]), _In("state_in", [model.state_size()])]
+        def get_outputs(self): return [_In("spec_e", None), _In("state_out", None)]
+        def run(self, _names, feeds): return self.fn(feeds["spec"], feeds["state_in"])
+
+    wnorm = torch.tensor(np.float32(model.wnorm)); inv = torch.tensor(np.float32(1.0 / float(model.wnorm)))
+
+    def real_fn(spec, state):
+        with torch.no_grad():
+            y, st = model(torch.from_numpy(np.ascontiguousarray(spec)) * wnorm, torch.from_numpy(state.copy()))
+        return [(y * inv).numpy()[None] if y.dim() == 3 else (y * inv).numpy(), st.numpy()]
+
+    def pass_fn(spec, state):
+        return [spec.copy(), state.copy()]
+
+    def make(fn):
+        init = model.initial_state(dtype=torch.float32).numpy()
+        rt = ref_stream.RuntimeModel(session=_Session(fn), init_state=init, in_spec_name="spec",
+                                     in_state_name="state_in", out_spec_name="spec_e", out_state_name="state_out")
+        ref_stream.resolve_model = lambda **kw: ResolvedModel(
+            info=ModelInfo(name="x", sample_rate=sr, frame_ms=20.0, description="", onnx_filename="x.onnx"),
+            onnx_path=Path("/dev/null"))
+        ref_stream.build_runtime_model = lambda _p: rt
+        ref_stream.infer_win_len = lambda _s, _sr: win
+        return ref_stream.StreamEnhancer(model="x")
+
+    n = int(0.35 * sr) + 37
+    wav = synth_clip(n, sr, SEED + 5)
+    out = dict(wav=wav)
+    for kind, fn in (("pass", pass_fn), ("real", real_fn)):
+        for chunk in (7, win // 2, 171, 512, n):
+            se = make(fn)
+            pieces = [se.process(wav[i:i + chunk]) for i in range(0, n, chunk)]
+            pieces.append(se.flush())
+            out[f"{kind}_chunk{chunk}"] = np.concatenate(pieces).astype(np.float32)
+            out[f"{kind}_chunk{chunk}_nflush"] = np.int32(len(pieces[-1]))
+    np.savez_compressed(OUT / f"stream_{tag}.npz", **out)
+    print(f"[golden] stream_{tag}.npz", {k: v.shape for k, v in out.items() if not k.endswith('nflush')})
+
+
+def main():
+    assert REF.is_dir(), "reference checkout not mounted; goldens can only be regenerated in the build container"
+    _stub_modules()
+    sys.path.insert(0, str(REF))
+    sys.path.insert(0, str(REF / "package" / "src"))
+    import torch
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+
+    make_constants_fixture()
+    make_host_dsp_fixture()
+    make_model_fixture("16k_nb0", 16000, 0, 0.6, SEED + 100)
+    make_model_fixture("16k_nb1", 16000, 1, 1.0, SEED + 101)
+    m2, _, _ = make_model_fixture("16k_nb2", 16000, 2, 1.0, SEED + 102)
+    make_stream_fixture(m2, 16000, "16k_nb2")
+    make_model_fixture("16k_nb4", 16000, 4, 2.0, SEED + 104)
+    m48, _, _ = make_model_fixture("48k_nb1", 48000, 1, 0.6, SEED + 148)
+    make_stream_fixture(m48, 48000, "48k_nb1")
+
+
+if __name__ == "__main__":
+    main()
