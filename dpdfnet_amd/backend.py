@@ -1,0 +1,293 @@
+"""ctypes binding of libdpdfnet_hip.so -- the thin C-ABI layer between the Python host code and the
+hand-written gfx950 kernels (include/dpdfnet_hip.h).
+
+This module is the counterpart of the reference's runtime seam
+(reference package/src/dpdfnet/onnx_backend.py:11-107: ``RuntimeModel``, ``build_runtime_model``,
+``infer_win_len``, ``load_initial_state_from_metadata``).  There is deliberately NO CPU fallback:
+if the shared library or a GPU is missing, loading/creating fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import threading
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+
+from . import weights as _weights
+
+_PKG_DIR = Path(__file__).resolve().parent
+_LIB_NAME = "libdpdfnet_hip.so"
+_lib: Optional[ctypes.CDLL] = None
+_lib_lock = threading.Lock()
+
+DPDF_HOST_PTRS = 0
+DPDF_DEVICE_PTRS = 1
+
+
+class DpdfCfg(ctypes.Structure):
+    _fields_ = [("sample_rate", ctypes.c_int), ("nb", ctypes.c_int)]
+
+
+class DpdfDims(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("sr", "nb", "win", "hop", "F", "E", "Ec", "D", "C", "H", "O", "s1", "s2", "s3",
+                 "F1", "F2", "F3", "Fd", "emb", "is48")] + [("wnorm", ctypes.c_float), ("state_size", ctypes.c_int)]
+
+
+EXPORTED_SYMBOLS = (
+    "dpdf_abi_version", "dpdf_last_error", "dpdf_device_count", "dpdf_weight_count", "dpdf_manifest_text",
+    "dpdf_query_dims", "dpdf_create", "dpdf_destroy", "dpdf_set_norm_init", "dpdf_state_size",
+    "dpdf_initial_state", "dpdf_win_len", "dpdf_hop", "dpdf_freq_bins", "dpdf_sample_rate",
+    "dpdf_run_frames", "dpdf_enhance_batch", "dpdf_num_frames", "dpdf_streams_create",
+    "dpdf_streams_destroy", "dpdf_streams_reset", "dpdf_streams_prime", "dpdf_streams_process",
+    "dpdf_streams_get_state", "dpdf_sync", "dpdf_profile_enable", "dpdf_profile_report",
+    "dpdf_set_chunk_frames", "dpdf_debug_fetch",
+)
+
+
+def lib_path() -> Path:
+    return _PKG_DIR / _LIB_NAME
+
+
+def load_library() -> ctypes.CDLL:
+    """Load the HIP extension.  Raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        p = lib_path()
+        if not p.is_file():
+            raise RuntimeError(
+                f"MI355X HIP extension not built: {p} is missing. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)."
+            )
+        try:
+            L = ctypes.CDLL(str(p))
+        except OSError as exc:
+            raise RuntimeError(f"Failed to load the MI355X HIP extension {p}: {exc}") from exc
+        fp = ctypes.POINTER(ctypes.c_float)
+        vp = ctypes.c_void_p
+        cfgp = ctypes.POINTER(DpdfCfg)
+        L.dpdf_abi_version.restype = ctypes.c_int
+        L.dpdf_last_error.restype = ctypes.c_char_p
+        L.dpdf_device_count.restype = ctypes.c_int
+        L.dpdf_weight_count.restype = ctypes.c_size_t
+        L.dpdf_weight_count.argtypes = [cfgp]
+        L.dpdf_manifest_text.restype = ctypes.c_size_t
+        L.dpdf_manifest_text.argtypes = [cfgp, ctypes.c_char_p, ctypes.c_size_t]
+        L.dpdf_query_dims.argtypes = [cfgp, ctypes.POINTER(DpdfDims)]
+        L.dpdf_create.argtypes = [cfgp, fp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(vp)]
+        L.dpdf_destroy.argtypes = [vp]
+        L.dpdf_destroy.restype = None
+        L.dpdf_set_norm_init.argtypes = [vp, fp, ctypes.c_int, fp, ctypes.c_int]
+        for fn in ("dpdf_state_size", "dpdf_win_len", "dpdf_hop", "dpdf_freq_bins", "dpdf_sample_rate", "dpdf_sync"):
+            getattr(L, fn).argtypes = [vp]
+        L.dpdf_initial_state.argtypes = [vp, fp]
+        L.dpdf_run_frames.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int]
+        L.dpdf_enhance_batch.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, ctypes.c_int]
+        L.dpdf_num_frames.argtypes = [vp, ctypes.c_int]
+        L.dpdf_streams_create.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
+        L.dpdf_streams_destroy.argtypes = [vp]
+        L.dpdf_streams_destroy.restype = None
+        L.dpdf_streams_reset.argtypes = [vp, ctypes.c_int]
+        L.dpdf_streams_prime.argtypes = [vp, vp, ctypes.c_int]
+        L.dpdf_streams_process.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int]
+        L.dpdf_streams_get_state.argtypes = [vp, ctypes.c_int, fp]
+        L.dpdf_profile_enable.argtypes = [vp, ctypes.c_int]
+        L.dpdf_profile_report.restype = ctypes.c_size_t
+        L.dpdf_profile_report.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+        L.dpdf_set_chunk_frames.argtypes = [vp, ctypes.c_int]
+        L.dpdf_debug_fetch.restype = ctypes.c_long
+        L.dpdf_debug_fetch.argtypes = [vp, ctypes.c_char_p, fp, ctypes.c_long]
+        _lib = L
+        return L
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _check(rc: int) -> None:
+    """Map C status codes to the reference's exception types."""
+    if rc == 0:
+        return
+    msg = load_library().dpdf_last_error().decode("utf-8", "replace")
+    if rc == -2:
+        raise RuntimeError(msg)
+    raise ValueError(msg)
+
+
+def manifest(sample_rate: int, nb: int) -> List[_weights.ManifestEntry]:
+    L = load_library()
+    cfg = DpdfCfg(int(sample_rate), int(nb))
+    n = L.dpdf_manifest_text(ctypes.byref(cfg), None, 0)
+    if n == 0:
+        raise ValueError(f"Unsupported model config sample_rate={sample_rate} nb={nb}")
+    buf = ctypes.create_string_buffer(n + 1)
+    L.dpdf_manifest_text(ctypes.byref(cfg), buf, n + 1)
+    return _weights.parse_manifest_text(buf.value.decode("utf-8"))
+
+
+def query_dims(sample_rate: int, nb: int) -> DpdfDims:
+    d = DpdfDims()
+    cfg = DpdfCfg(int(sample_rate), int(nb))
+    _check(load_library().dpdf_query_dims(ctypes.byref(cfg), ctypes.byref(d)))
+    return d
+
+
+def device_count() -> int:
+    return int(load_library().dpdf_device_count())
+
+
+class HipModel:
+    """A frame-function handle on one GPU (the analogue of an ORT ``InferenceSession``)."""
+
+    def __init__(self, sample_rate: int, nb: int, blob: np.ndarray, device: int = 0,
+                 erb_norm_init: Optional[np.ndarray] = None, spec_norm_init: Optional[np.ndarray] = None):
+        self._L = load_library()
+        self.cfg = DpdfCfg(int(sample_rate), int(nb))
+        blob = np.ascontiguousarray(blob, dtype=np.float32).reshape(-1)
+        h = ctypes.c_void_p()
+        _check(self._L.dpdf_create(ctypes.byref(self.cfg), _fp(blob), blob.size, int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.sample_rate = int(sample_rate)
+        self.nb = int(nb)
+        self.state_size = int(self._L.dpdf_state_size(h))
+        self.win_len = int(self._L.dpdf_win_len(h))
+        self.hop = int(self._L.dpdf_hop(h))
+        self.freq_bins = int(self._L.dpdf_freq_bins(h))
+        if erb_norm_init is not None or spec_norm_init is not None:
+            e = None if erb_norm_init is None else np.ascontiguousarray(erb_norm_init, dtype=np.float32)
+            s = None if spec_norm_init is None else np.ascontiguousarray(spec_norm_init, dtype=np.float32)
+            _check(self._L.dpdf_set_norm_init(h, None if e is None else _fp(e), 0 if e is None else e.size,
+                                              None if s is None else _fp(s), 0 if s is None else s.size))
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.dpdf_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference RuntimeModel surface ------------------------------------------------------
+    def initial_state(self) -> np.ndarray:
+        st = np.zeros(self.state_size, dtype=np.float32)
+        _check(self._L.dpdf_initial_state(self._h, _fp(st)))
+        return st
+
+    def num_frames(self, n_samples: int) -> int:
+        return int(self._L.dpdf_num_frames(self._h, int(n_samples)))
+
+    def run_frames(self, spec: np.ndarray, state: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """spec [B,T,F,2] (or [T,F,2]), state [B,S] (or [S]) -> (spec_e, state_out)."""
+        spec = np.ascontiguousarray(spec, dtype=np.float32)
+        squeeze = spec.ndim == 3
+        if squeeze:
+            spec = spec[None]
+        if spec.ndim != 4 or spec.shape[2] != self.freq_bins or spec.shape[3] != 2:
+            raise ValueError(f"spec must be [B,T,{self.freq_bins},2], got {spec.shape}")
+        B, T = spec.shape[0], spec.shape[1]
+        st = np.array(state, dtype=np.float32).reshape(B, -1)
+        if st.shape[1] != self.state_size:
+            raise ValueError(f"state must have {self.state_size} values per stream, got {st.shape[1]}")
+        st = np.ascontiguousarray(st)
+        out = np.empty_like(spec)
+        _check(self._L.dpdf_run_frames(self._h, spec.ctypes.data, B, T, st.ctypes.data, out.ctypes.data, DPDF_HOST_PTRS))
+        if squeeze:
+            return out[0], st[0]
+        return out, st
+
+    def enhance_batch(self, wav: np.ndarray, attn_limit_db: Optional[float] = None) -> np.ndarray:
+        """wav [B,N] float32 at the model rate -> enhanced [B,N]."""
+        wav = np.ascontiguousarray(wav, dtype=np.float32)
+        if wav.ndim != 2:
+            raise ValueError(f"wav must be [B,N], got {wav.shape}")
+        out = np.empty_like(wav)
+        db = float("nan") if attn_limit_db is None else float(attn_limit_db)
+        _check(self._L.dpdf_enhance_batch(self._h, wav.ctypes.data, wav.shape[0], wav.shape[1], db, out.ctypes.data, DPDF_HOST_PTRS))
+        return out
+
+    def enhance_batch_device(self, wav_ptr: int, B: int, N: int, out_ptr: int, attn_limit_db: Optional[float] = None) -> None:
+        """Device-pointer form (HBM-resident input/output; asynchronous on the model's stream)."""
+        db = float("nan") if attn_limit_db is None else float(attn_limit_db)
+        _check(self._L.dpdf_enhance_batch(self._h, wav_ptr, int(B), int(N), db, out_ptr, DPDF_DEVICE_PTRS))
+
+    def sync(self) -> None:
+        _check(self._L.dpdf_sync(self._h))
+
+    def set_chunk_frames(self, frames: int) -> None:
+        _check(self._L.dpdf_set_chunk_frames(self._h, int(frames)))
+
+    def debug_fetch(self, name: str) -> np.ndarray:
+        n = self._L.dpdf_debug_fetch(self._h, name.encode(), None, 0)
+        if n < 0:
+            raise ValueError(f"unknown debug tensor {name!r}")
+        buf = np.empty(n, dtype=np.float32)
+        self._L.dpdf_debug_fetch(self._h, name.encode(), _fp(buf), n)
+        return buf
+
+    def profile(self, on: bool) -> None:
+        _check(self._L.dpdf_profile_enable(self._h, 1 if on else 0))
+
+    def profile_report(self) -> Dict[str, Tuple[float, int]]:
+        n = self._L.dpdf_profile_report(self._h, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        self._L.dpdf_profile_report(self._h, buf, n + 1)
+        rep: Dict[str, Tuple[float, int]] = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, calls = line.split(" ")
+            rep[name] = (float(ms), int(calls))
+        return rep
+
+
+class HipStreams:
+    """S device-resident streams (state + analysis/OLA tails in HBM)."""
+
+    def __init__(self, model: HipModel, n_streams: int):
+        self.model = model
+        self.n = int(n_streams)
+        h = ctypes.c_void_p()
+        _check(model._L.dpdf_streams_create(model._h, self.n, ctypes.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h and self.model._h:
+            self.model._L.dpdf_streams_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream: int = -1) -> None:
+        _check(self.model._L.dpdf_streams_reset(self._h, int(stream)))
+
+    def prime(self, pcm: np.ndarray) -> None:
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32).reshape(self.n, self.model.hop)
+        _check(self.model._L.dpdf_streams_prime(self._h, pcm.ctypes.data, DPDF_HOST_PTRS))
+
+    def process(self, pcm: np.ndarray) -> np.ndarray:
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32).reshape(self.n, -1)
+        if pcm.shape[1] % self.model.hop:
+            raise ValueError("streams.process needs a whole number of hops per stream")
+        n_hops = pcm.shape[1] // self.model.hop
+        out = np.empty_like(pcm)
+        _check(self.model._L.dpdf_streams_process(self._h, pcm.ctypes.data, n_hops, out.ctypes.data, DPDF_HOST_PTRS))
+        return out
+
+    def get_state(self, stream: int) -> np.ndarray:
+        st = np.empty(self.model.state_size, dtype=np.float32)
+        _check(self.model._L.dpdf_streams_get_state(self._h, int(stream), _fp(st)))
+        return st

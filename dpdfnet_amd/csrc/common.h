@@ -1,0 +1,35 @@
+// common.h -- shared device helpers for the gfx950 DPDFNet kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16], exact fp32 FMA chain.
+// lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15];
+// D reg i holds D[row = (l>>4)*4 + i][col = l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+    // tanh(x) = sign(x) * (1 - e) / (1 + e),  e = exp(-2|x|)  (no overflow, abs err ~1e-7)
+    float e = fast_exp(-2.0f * fabsf(x));
+    float t = (1.0f - e) * fast_rcp(1.0f + e);
+    return copysignf(t, x);
+}
+
+// K index supplied by lane-quad q (= lane>>4) for MFMA kb (0..3) of 16-wide K chunk c.
+// All A fragments (4 contiguous floats per lane per chunk) and all packed B fragments use it.
+__host__ __device__ inline int kperm(int c, int q, int kb) { return 16 * c + 4 * q + kb; }
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_TANH) return tanh_f(v);
+    if (act == ACT_SIGMOID) return sigmoid_f(v);
+    return v;
+}

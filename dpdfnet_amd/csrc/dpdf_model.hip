@@ -1,0 +1,1120 @@
+// dpdf_model.hip -- C ABI + host orchestration of the MI355X DPDFNet engine.
+//
+// Schedule: "layer at a time over every frame of every clip" instead of the reference's
+// "every layer for one frame" (reference package/src/dpdfnet/api.py:96-104): each layer is ONE
+// kernel over B*Tc frames; recurrences over time (EMA norms, inter-band GRUs, the 256-wide GRU
+// stacks) are scans inside persistent workgroups; FIFO buffers (CyclicBuffer,
+// onnx_model/layers.py:68-107) become time-halo index shifts.  SURVEY.md appendix A.3 gives the
+// time indexing; the reference's offline twin (model/dpdfnet.py) proves the equivalence.
+// The device state between chunks/calls is kept in the reference's own flat layout, so
+// `dpdf_run_frames` is a drop-in for T consecutive session.run calls.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dpdfnet_hip.h"
+#include "common.h"
+#include "gemm_rows.h"
+#include "gru_scan.h"
+#include "misc_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return set_err(DPDF_E_RUNTIME, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* dpdf_last_error(void) { return g_err; }
+extern "C" int dpdf_abi_version(void) { return 1; }
+extern "C" int dpdf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" size_t dpdf_weight_count(const dpdf_cfg* cfg) { return dpdf_manifest(cfg, nullptr, nullptr); }
+extern "C" int dpdf_query_dims(const dpdf_cfg* cfg, dpdf_dims* out) {
+    if (!out || dpdf_get_dims(cfg, out) != 0) return set_err(DPDF_E_INVALID, "unsupported model config");
+    return DPDF_OK;
+}
+namespace {
+struct TxtCtx { char* buf; size_t cap, len; };
+void text_cb(void* ud, const char* name, const int* shape, int ndim, size_t off, size_t cnt) {
+    TxtCtx* t = (TxtCtx*)ud;
+    char line[256];
+    int k = snprintf(line, sizeof(line), "%s %zu %zu ", name, off, cnt);
+    for (int i = 0; i < ndim; ++i) k += snprintf(line + k, sizeof(line) - k, i ? ",%d" : "%d", shape[i]);
+    k += snprintf(line + k, sizeof(line) - k, "\n");
+    if (t->buf && t->len + k < t->cap) memcpy(t->buf + t->len, line, (size_t)k);
+    t->len += (size_t)k;
+}
+}  // namespace
+extern "C" size_t dpdf_manifest_text(const dpdf_cfg* cfg, char* buf, size_t cap) {
+    TxtCtx t{buf, cap, 0};
+    dpdf_manifest(cfg, text_cb, &t);
+    if (buf && t.len < cap) buf[t.len] = 0;
+    return t.len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side weight preparation
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Blob {
+    const float* base;
+    std::map<std::string, size_t> off;
+    const float* get(const std::string& n) const {
+        auto it = off.find(n);
+        if (it == off.end()) { fprintf(stderr, "dpdfnet_hip: missing tensor %s\n", n.c_str()); abort(); }
+        return base + it->second;
+    }
+};
+void blob_cb(void* ud, const char* name, const int*, int, size_t off, size_t) { ((Blob*)ud)->off[name] = off; }
+
+struct Arena {                     // one device allocation for every prepared constant
+    std::vector<float> h;
+    size_t add(const std::vector<float>& v) {
+        size_t o = (h.size() + 63) & ~size_t(63);
+        h.resize(o + v.size());
+        std::copy(v.begin(), v.end(), h.begin() + o);
+        return o;
+    }
+};
+
+// pack W (math orientation out = A . W, W[k][n] given by accessor) into MFMA B-fragment order
+// [chunk][tile][kb][lane] (K padded to 16, N to NT*16)
+template <class Fn>
+std::vector<float> pack_frag(int K, int N, int NT, Fn w) {
+    const int nch = (K + 15) / 16;
+    std::vector<float> out((size_t)nch * NT * 256, 0.f);
+    for (int c = 0; c < nch; ++c)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int kb = 0; kb < 4; ++kb)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int k = kperm(c, lane >> 4, kb), n = nt * 16 + (lane & 15);
+                    if (k < K && n < N) out[(((size_t)c * NT + nt) * 4 + kb) * 64 + lane] = w(k, n);
+                }
+    return out;
+}
+
+struct BnFold { std::vector<float> scale, shift; };
+BnFold fold_bn(const Blob& B, const std::string& p, int ch) {
+    BnFold f; f.scale.resize(ch); f.shift.resize(ch);
+    const float *w = B.get(p + ".weight"), *b = B.get(p + ".bias"), *m = B.get(p + ".running_mean"), *v = B.get(p + ".running_var");
+    for (int c = 0; c < ch; ++c) {
+        f.scale[c] = w[c] / std::sqrt(v[c] + 1e-5f);
+        f.shift[c] = b[c] - m[c] * f.scale[c];
+    }
+    return f;
+}
+
+struct SepConvW { size_t dw, pwfrag, bias; int nsub; };        // arena offsets
+struct PathW { size_t ps, pb; };
+struct GruW64 { size_t wfrag, bias; int ndirs; };
+struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
+struct Gru256W { size_t ih_frag, ih_bias, hh_frag, b_hn; };
+struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b; };
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    float* p = nullptr; size_t n = 0;
+    int ensure(size_t need) {
+        if (need <= n) return DPDF_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void**)&p, need * sizeof(float));
+        if (e != hipSuccess) return set_err(DPDF_E_RUNTIME, "hipMalloc(%zu floats) failed: %s", need, hipGetErrorString(e));
+        n = need;
+        return DPDF_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct Workspace {
+    int Bcap = 0, Tcap = 0;
+    DevBuf xs, feat_erb, feat_spec, e0, e1, e2, e3, xe_a, xe_b, c0, c1, xd_a, xd_b, hcat, hin;
+    DevBuf embin, g256a, g256b, g256c, gi, emb, demb, demb2, d3, d2, d1, m, dfo, coefs, xm;
+    void release() {
+        DevBuf* all[] = {&xs, &feat_erb, &feat_spec, &e0, &e1, &e2, &e3, &xe_a, &xe_b, &c0, &c1, &xd_a, &xd_b, &hcat, &hin,
+                         &embin, &g256a, &g256b, &g256c, &gi, &emb, &demb, &demb2, &d3, &d2, &d1, &m, &dfo, &coefs, &xm};
+        for (DevBuf* b : all) b->release();
+        Bcap = Tcap = 0;
+    }
+};
+
+struct ProfEntry { double ms = 0; long calls = 0; };
+
+struct dpdf_model {
+    dpdf_cfg cfg; dpdf_dims d; dpdf_state_layout L;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    float* consts = nullptr;           // device arena
+    int* iconsts = nullptr;            // band_start[33] | band_of[F]
+    std::vector<float> erb_norm_init, spec_norm_init;
+    float* d_init_state = nullptr;     // [S]
+    int chunk_frames = 0;
+    // prepared weights (arena offsets)
+    size_t conv0_w, conv0_b;
+    SepConvW erb_conv1, erb_conv2, erb_conv3, df_conv1, convt3, convt2, convt1;
+    size_t dfc0_w, dfc0_pwfrag, dfc0_bias;
+    std::vector<DprnnW> dprnn_erb, dprnn_df;
+    GlW enc_erb_fc, df_fc_emb, enc_lin_in, enc_lin_out, ed_lin_in, ed_lin_out, ed_erb_fc, df_lin_in, df_skip, df_out;
+    Gru256W enc_gru, ed_gru0, ed_gru1, df_gru0, df_gru1;
+    PathW conv3p, conv2p, conv1p, conv0p;
+    size_t c0out_w; float c0out_bias;
+    size_t convp_frag, convp_bias;
+    size_t window, stft_frag, istft_frag;
+    int stft_groups, istft_groups, istft_K;
+    Workspace ws;
+    DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state;
+    // profiling
+    bool prof_on = false;
+    std::map<std::string, ProfEntry> prof;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; int dbg_B = 0, dbg_Tc = 0;
+    const float* C(size_t off) const { return consts + off; }
+};
+
+struct dpdf_streams {
+    dpdf_model* m; int S;
+    DevBuf state, in_tail, ola_tail, spec, spec_e, pcm_in, pcm_out;
+    std::vector<int> primed;
+};
+
+namespace {
+
+struct ProfScope {
+    dpdf_model* m; const char* name;
+    ProfScope(dpdf_model* m_, const char* n) : m(m_), name(n) {
+        if (m->prof_on) (void)hipEventRecord(m->ev0, m->stream);
+    }
+    ~ProfScope() {
+        if (m->prof_on) {
+            (void)hipEventRecord(m->ev1, m->stream);
+            (void)hipEventSynchronize(m->ev1);
+            float ms = 0; (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
+            auto& e = m->prof[name]; e.ms += ms; e.calls++;
+        }
+    }
+};
+
+// ----- weight builders ------------------------------------------------------------------------
+SepConvW build_sepconv(Arena& A, const Blob& B, const std::string& p, int nsub) {
+    SepConvW s; s.nsub = nsub < 1 ? 1 : nsub;
+    std::vector<float> dw((size_t)s.nsub * 64 * 3);
+    for (int k = 0; k < s.nsub; ++k) {
+        const float* w = nsub <= 1 ? B.get(p + ".0.weight") : B.get(p + ".0.convs." + std::to_string(k) + ".weight");
+        std::copy(w, w + 192, dw.begin() + (size_t)k * 192);
+    }
+    s.dw = A.add(dw);
+    BnFold f = fold_bn(B, p + ".2", 64);
+    const float* pw = B.get(p + ".1.weight");           // [out][in]
+    s.pwfrag = A.add(pack_frag(64, 64, 4, [&](int k, int n) { return pw[n * 64 + k] * f.scale[n]; }));
+    s.bias = A.add(f.shift);
+    return s;
+}
+PathW build_path(Arena& A, const Blob& B, const std::string& p) {
+    BnFold f = fold_bn(B, p + ".1", 64);
+    const float* sc = B.get(p + ".0.weight");
+    std::vector<float> ps(64), pb(64);
+    for (int c = 0; c < 64; ++c) { ps[c] = sc[c] * f.scale[c]; pb[c] = f.shift[c]; }
+    PathW w; w.ps = A.add(ps); w.pb = A.add(pb);
+    return w;
+}
+// [dir][wave][part][gate][chunk*4+kb][lane] + bias [dir][4][64]
+GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::string, std::string>>& dirs) {
+    GruW64 g; g.ndirs = (int)dirs.size();
+    std::vector<float> frag((size_t)g.ndirs * 4 * 2 * 3 * 16 * 64), bias((size_t)g.ndirs * 256);
+    for (int d = 0; d < g.ndirs; ++d) {
+        const std::string &p = dirs[d].first, &sfx = dirs[d].second;
+        const float* wih = B.get(p + ".weight_ih" + sfx); const float* whh = B.get(p + ".weight_hh" + sfx);
+        const float* bih = B.get(p + ".bias_ih" + sfx);   const float* bhh = B.get(p + ".bias_hh" + sfx);
+        for (int w = 0; w < 4; ++w)
+            for (int part = 0; part < 2; ++part)
+                for (int gate = 0; gate < 3; ++gate)
+                    for (int c = 0; c < 4; ++c)
+                        for (int kb = 0; kb < 4; ++kb)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                int k = kperm(c, lane >> 4, kb);
+                                int j = gate * 64 + 16 * w + (lane & 15);
+                                const float* W = part == 0 ? wih : whh;
+                                frag[(((((size_t)(d * 4 + w) * 2 + part) * 3 + gate) * 16) + c * 4 + kb) * 64 + lane] = W[j * 64 + k];
+                            }
+        for (int j = 0; j < 64; ++j) {
+            bias[d * 256 + j] = bih[j] + bhh[j];
+            bias[d * 256 + 64 + j] = bih[64 + j] + bhh[64 + j];
+            bias[d * 256 + 128 + j] = bih[128 + j];
+            bias[d * 256 + 192 + j] = bhh[128 + j];
+        }
+    }
+    g.wfrag = A.add(frag); g.bias = A.add(bias);
+    return g;
+}
+GlW build_gl(Arena& A, const Blob& B, const std::string& p, int G, int Og, int Ig) {
+    GlW g; g.G = G; g.Og = Og; g.Ig = Ig; g.NT = (Og + 15) / 16;
+    const float* w = B.get(p + ".weight"); const float* b = B.get(p + ".bias");
+    std::vector<float> frag;
+    for (int gi = 0; gi < G; ++gi) {
+        auto f = pack_frag(Ig, Og, g.NT, [&](int k, int n) { return w[((size_t)gi * Og + n) * Ig + k]; });
+        frag.insert(frag.end(), f.begin(), f.end());
+    }
+    g.frag = A.add(frag);
+    g.bias = A.add(std::vector<float>(b, b + (size_t)G * Og));
+    return g;
+}
+Gru256W build_gru256(Arena& A, const Blob& B, const std::string& p) {
+    Gru256W g;
+    const float* wih = B.get(p + ".weight_ih"); const float* whh = B.get(p + ".weight_hh");
+    const float* bih = B.get(p + ".bias_ih");   const float* bhh = B.get(p + ".bias_hh");
+    // input projection: 6 column blocks of 128 (NT = 8)
+    std::vector<float> frag;
+    for (int g6 = 0; g6 < 6; ++g6) {
+        auto f = pack_frag(256, 128, 8, [&](int k, int n) { return wih[(size_t)(g6 * 128 + n) * 256 + k]; });
+        frag.insert(frag.end(), f.begin(), f.end());
+    }
+    g.ih_frag = A.add(frag);
+    std::vector<float> bias(768), bhn(256);
+    for (int j = 0; j < 256; ++j) {
+        bias[j] = bih[j] + bhh[j]; bias[256 + j] = bih[256 + j] + bhh[256 + j]; bias[512 + j] = bih[512 + j];
+        bhn[j] = bhh[512 + j];
+    }
+    g.ih_bias = A.add(bias); g.b_hn = A.add(bhn);
+    // recurrent: [wave 16][gate 3][chunk 16][kb 4][lane 64]
+    std::vector<float> hh((size_t)16 * 3 * 64 * 64);
+    for (int w = 0; w < 16; ++w)
+        for (int gate = 0; gate < 3; ++gate)
+            for (int c = 0; c < 16; ++c)
+                for (int kb = 0; kb < 4; ++kb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        int k = kperm(c, lane >> 4, kb), j = gate * 256 + 16 * w + (lane & 15);
+                        hh[((((size_t)w * 3 + gate) * 16 + c) * 4 + kb) * 64 + lane] = whh[(size_t)j * 256 + k];
+                    }
+    g.hh_frag = A.add(hh);
+    return g;
+}
+std::vector<DprnnW> build_dprnn(Arena& A, const Blob& B, const std::string& p, int nb) {
+    std::vector<DprnnW> v;
+    for (int i = 0; i < nb; ++i) {
+        std::string q = p + ".blocks." + std::to_string(i);
+        DprnnW w;
+        w.intra = build_gru64(A, B, {{q + ".intra_gru", "_l0"}, {q + ".intra_gru", "_l0_reverse"}});
+        w.inter = build_gru64(A, B, {{q + ".inter_gru.grucell", ""}});
+        const float* fi = B.get(q + ".fc_intra.weight");   // [64][128]
+        w.fci_frag = A.add(pack_frag(128, 64, 4, [&](int k, int n) { return fi[n * 128 + k]; }));
+        w.fci_b = A.add(std::vector<float>(B.get(q + ".fc_intra.bias"), B.get(q + ".fc_intra.bias") + 64));
+        w.lni_g = A.add(std::vector<float>(B.get(q + ".ln_intra.weight"), B.get(q + ".ln_intra.weight") + 64));
+        w.lni_b = A.add(std::vector<float>(B.get(q + ".ln_intra.bias"), B.get(q + ".ln_intra.bias") + 64));
+        const float* fe = B.get(q + ".fc_inter.weight");   // [64][64]
+        w.fce_frag = A.add(pack_frag(64, 64, 4, [&](int k, int n) { return fe[n * 64 + k]; }));
+        w.fce_b = A.add(std::vector<float>(B.get(q + ".fc_inter.bias"), B.get(q + ".fc_inter.bias") + 64));
+        w.lne_g = A.add(std::vector<float>(B.get(q + ".ln_inter.weight"), B.get(q + ".ln_inter.weight") + 64));
+        w.lne_b = A.add(std::vector<float>(B.get(q + ".ln_inter.bias"), B.get(q + ".ln_inter.bias") + 64));
+        v.push_back(w);
+    }
+    return v;
+}
+
+// vorbis window (reference package/src/dpdfnet/audio.py:84-88)
+std::vector<float> vorbis(int n) {
+    std::vector<float> w(n);
+    const double h = n / 2.0;
+    for (int i = 0; i < n; ++i) { double s = std::sin(0.5 * M_PI * (i + 0.5) / h); w[i] = (float)std::sin(0.5 * M_PI * s * s); }
+    return w;
+}
+// ERB band edges (reference model/utils.py:265-324), 16 kHz: 32 bands over 161 bins, min width 1
+void erb_bands(int nfft, int fs, std::vector<int>& start, std::vector<int>& band_of) {
+    const int nf = 32, F = nfft / 2 + 1;
+    const double fw = (double)fs / nfft;
+    const double lo = 9.265 * std::log1p(0.0), hi = 9.265 * std::log1p((fs / 2.0) / (24.7 * 9.265));
+    const double step = (hi - lo) / nf;
+    std::vector<int> bins(nf + 1);
+    for (int i = 0; i <= nf; ++i) bins[i] = (int)std::nearbyint(24.7 * 9.265 * (std::exp((lo + i * step) / 9.265) - 1.0) / fw);
+    bins[nf] = F;
+    start.assign(nf + 1, 0); band_of.assign(F, 0);
+    int over = 0;
+    for (int j = 0; j < nf; ++j) {
+        int a = bins[j] + over, b = bins[j + 1];
+        if (b - a < 1) { over = 1 - (b - a); b = std::min(b + over, F); } else over = 0;
+        start[j] = a; start[j + 1] = b;
+        for (int f = a; f < b; ++f) band_of[f] = j;
+    }
+}
+
+int ensure_ws(dpdf_model* m, int B, int Tc) {
+    Workspace& w = m->ws;
+    if (B <= w.Bcap && Tc <= w.Tcap && (size_t)B * Tc <= (size_t)w.Bcap * w.Tcap) {
+        // buffers are sized by products of B and (Tc + halo); reuse only for an exact fit class
+        if (B == w.Bcap && Tc == w.Tcap) return DPDF_OK;
+    }
+    const dpdf_dims& d = m->d;
+    const size_t BT = (size_t)B * Tc;
+    int rc = DPDF_OK;
+#define ENS(buf, n) do { rc = w.buf.ensure(n); if (rc) return rc; } while (0)
+    ENS(xs, (size_t)B * (Tc + 2) * d.F * 2);
+    ENS(feat_erb, (size_t)B * (Tc + 2) * d.E);
+    ENS(feat_spec, (size_t)B * (Tc + 2) * 2 * d.D);
+    ENS(e0, BT * d.Ec * 64); ENS(e1, BT * d.F1 * 64); ENS(e2, BT * d.F2 * 64); ENS(e3, BT * d.F3 * 64);
+    ENS(xe_a, BT * d.F3 * 64); ENS(xe_b, BT * d.F3 * 64);
+    ENS(c0, (size_t)B * (Tc + 4) * d.D * 64); ENS(c1, BT * d.Fd * 64);
+    ENS(xd_a, BT * d.Fd * 64); ENS(xd_b, BT * d.Fd * 64);
+    ENS(hcat, BT * d.Fd * 128); ENS(hin, BT * d.Fd * 64);
+    ENS(embin, BT * 1024); ENS(g256a, BT * 256); ENS(g256b, BT * 256); ENS(g256c, BT * 256);
+    ENS(gi, BT * 768); ENS(emb, BT * 512); ENS(demb, BT * 512);
+    ENS(demb2, BT * (size_t)d.F3 * 64);
+    ENS(d3, BT * d.F2 * 64); ENS(d2, BT * d.F1 * 64); ENS(d1, BT * d.Ec * 64);
+    ENS(m, BT * d.E); ENS(dfo, BT * d.D * 10);
+    ENS(coefs, (size_t)B * (Tc + 2) * d.D * 10); ENS(xm, (size_t)B * (Tc + 4) * d.F * 2);
+#undef ENS
+    w.Bcap = B; w.Tcap = Tc;
+    return DPDF_OK;
+}
+
+template <int NT, int KP>
+void run_gl(dpdf_model* m, const GlW& g, const float* in, size_t lda, float* out, size_t ldo, int M, int act) {
+    PlainA<KP> ap{in, lda, g.Ig, g.Ig};
+    BiasActStore<NT> ep{out, ldo, g.Og, m->C(g.bias), g.Og, g.Og, act};
+    launch_gemm_rows<NT, KP, false>(m->stream, ap, m->C(g.frag), ep, M, g.Ig, g.G);
+}
+void run_gl_auto(dpdf_model* m, const GlW& g, const float* in, size_t lda, float* out, size_t ldo, int M, int act) {
+    if (g.NT == 1 && g.Ig % 32 == 0 && g.Ig != 64) run_gl<1, 32>(m, g, in, lda, out, ldo, M, act);
+    else if (g.NT == 1 && g.Ig == 64) run_gl<1, 64>(m, g, in, lda, out, ldo, M, act);
+    else if (g.NT == 1) run_gl<1, 16>(m, g, in, lda, out, ldo, M, act);
+    else if (g.NT == 2 && g.Ig == 64) run_gl<2, 64>(m, g, in, lda, out, ldo, M, act);
+    else if (g.NT == 2) run_gl<2, 16>(m, g, in, lda, out, ldo, M, act);
+    else if (g.NT == 4) run_gl<4, 16>(m, g, in, lda, out, ldo, M, act);
+    else run_gl<5, 16>(m, g, in, lda, out, ldo, M, act);
+}
+
+// SqueezedGRU_S cell: gi = W_ih x + b (all frames, one GEMM) then the recurrent scan
+void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int Tc) {
+    const int M = B * Tc;
+    {
+        ProfScope ps(m, "gru256_proj");
+        PlainA<64> ap{x, 256, 0, 256};
+        BiasActStore<8> ep{m->ws.gi.p, 768, 128, m->C(g.ih_bias), 128, 128, ACT_NONE};
+        launch_gemm_rows<8, 64, false>(m->stream, ap, m->C(g.ih_frag), ep, M, 256, 6);
+    }
+    {
+        ProfScope ps(m, "gru256_scan");
+        Gru256Args a{m->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
+        hipLaunchKernelGGL(gru256_scan_kernel, dim3((B + 15) / 16), dim3(1024), 0, m->stream, a);
+    }
+}
+
+// DPRNN (reference onnx_model/layers.py:159-196, 278-302): x [B*Tc][Fp][64] -> same, in xa (uses xb as scratch)
+float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, float* xb, int Fp,
+                 float* state, long S, int soff, int B, int Tc) {
+    const int M = B * Tc * Fp;
+    float* x = xa; float* y = xb;
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        const DprnnW& w = blocks[bi];
+        {   // intra-band bi-GRU over frequency, h0 = 0
+            ProfScope ps(m, "dprnn_intra_scan");
+            Gru64Args a{};
+            a.x = x; a.out = m->ws.hcat.p; a.wfrag = m->C(w.intra.wfrag); a.bias = m->C(w.intra.bias); a.hstate = nullptr;
+            a.nrows = B * Tc; a.nsteps = Fp; a.ndirs = 2; a.rdiv = 1;
+            a.x_hi = (long)Fp * 64; a.x_lo = 0; a.x_step = 64;
+            a.o_hi = (long)Fp * 128; a.o_lo = 0; a.o_step = 128; a.o_dir_off = 64;
+            hipLaunchKernelGGL(gru64_scan_kernel, dim3((a.nrows + 15) / 16, 2), dim3(256), 0, m->stream, a);
+        }
+        {   // fc_intra + ln_intra + residual
+            ProfScope ps(m, "dprnn_fc_ln");
+            PlainA<128> ap{m->ws.hcat.p, 128, 0, 128};
+            LnResStore ep{y, x, m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b)};
+            launch_gemm_rows<4, 128, true>(m->stream, ap, m->C(w.fci_frag), ep, M, 128, 1);
+        }
+        std::swap(x, y);
+        {   // inter-band GRUCell over time, one hidden state per band position
+            ProfScope ps(m, "dprnn_inter_scan");
+            Gru64Args a{};
+            a.x = x; a.out = m->ws.hin.p; a.wfrag = m->C(w.inter.wfrag); a.bias = m->C(w.inter.bias);
+            a.hstate = state + soff + (long)bi * Fp * 64;
+            a.nrows = B * Fp; a.nsteps = Tc; a.ndirs = 1; a.rdiv = Fp;
+            a.x_hi = (long)Tc * Fp * 64; a.x_lo = 64; a.x_step = (long)Fp * 64;
+            a.o_hi = a.x_hi; a.o_lo = 64; a.o_step = a.x_step; a.o_dir_off = 0;
+            a.h_hi = S; a.h_lo = 64;
+            hipLaunchKernelGGL(gru64_scan_kernel, dim3((a.nrows + 15) / 16, 1), dim3(256), 0, m->stream, a);
+        }
+        {
+            ProfScope ps(m, "dprnn_fc_ln");
+            PlainA<64> ap{m->ws.hin.p, 64, 0, 64};
+            LnResStore ep{y, x, m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b)};
+            launch_gemm_rows<4, 64, true>(m->stream, ap, m->C(w.fce_frag), ep, M, 64, 1);
+        }
+        std::swap(x, y);
+    }
+    return x;
+}
+
+template <int S>
+void run_dwconv(dpdf_model* m, const SepConvW& w, TView in, TView out, int B, int Tc) {
+    RowMap rm{Tc, out.Fp};
+    DwConvA<S> ap{in, rm, m->C(w.dw)};
+    BiasReluToView ep{out, rm, m->C(w.bias)};
+    launch_gemm_rows<4, 64, true>(m->stream, ap, m->C(w.pwfrag), ep, B * Tc * out.Fp, 64, 1);
+}
+void run_dwconv_s(dpdf_model* m, const SepConvW& w, TView in, TView out, int B, int Tc, int stride) {
+    if (stride == 1) run_dwconv<1>(m, w, in, out, B, Tc);
+    else if (stride == 2) run_dwconv<2>(m, w, in, out, B, Tc);
+    else run_dwconv<3>(m, w, in, out, B, Tc);
+}
+template <int S>
+void run_subpix(dpdf_model* m, const SepConvW& w, const PathW& p, TView e, TView prev, TView out, int B, int Tc) {
+    RowMap rm{Tc, out.Fp};
+    SubpixA<S> ap{e, prev, rm, m->C(p.ps), m->C(p.pb), m->C(w.dw)};
+    BiasReluToView ep{out, rm, m->C(w.bias)};
+    launch_gemm_rows<4, 64, true>(m->stream, ap, m->C(w.pwfrag), ep, B * Tc * out.Fp, 64, 1);
+}
+void run_subpix_s(dpdf_model* m, const SepConvW& w, const PathW& p, TView e, TView prev, TView out, int B, int Tc, int s) {
+    if (s == 1) run_subpix<1>(m, w, p, e, prev, out, B, Tc);
+    else if (s == 2) run_subpix<2>(m, w, p, e, prev, out, B, Tc);
+    else run_subpix<3>(m, w, p, e, prev, out, B, Tc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one chunk of the frame function for B streams x Tc frames.
+//   raw:   unnormalised spec, frame t of clip b at raw + b*raw_clip_stride + t*F*2
+//   state: device [B][S] reference flat layout, updated in place
+//   out:   enhanced spec, frame (out_t0 + t) of clip b at out + b*out_clip_stride + ...
+// ------------------------------------------------------------------------------------------------
+int run_chunk(dpdf_model* m, const float* raw, size_t raw_clip_stride, int B, int Tc, float* state,
+              float* out, size_t out_clip_stride, int out_t0, const float* attn_raw, float alpha) {
+    int rc = ensure_ws(m, B, Tc);
+    if (rc) return rc;
+    const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L;
+    Workspace& w = m->ws;
+    hipStream_t st = m->stream;
+    const long S = d.state_size;
+    const int BT = B * Tc;
+
+    StateIoArgs sio{state, S, w.feat_erb.p, w.feat_spec.p, w.c0.p, w.xs.p, w.coefs.p, w.xm.p,
+                    L.erb_conv0_buf, L.df_conv0_buf, L.df_convp_buf, L.mask_buf, L.df_coefs_buf, L.df_spec_buf,
+                    B, Tc, d.E, d.D, d.F, 0};
+    {
+        ProfScope ps(m, "state_io");
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 6), dim3(256), 0, st, sio);
+    }
+    {
+        ProfScope ps(m, "features");
+        FeatAArgs fa{raw, raw_clip_stride, w.xs.p, w.feat_erb.p, d.is48 ? nullptr : m->iconsts, B, Tc, d.F, d.E, d.is48, d.wnorm};
+        hipLaunchKernelGGL(feat_a_kernel, dim3(BT), dim3(256), 0, st, fa);
+        FeatBArgs fb{w.feat_erb.p, w.xs.p, w.feat_spec.p, state, S, L.erb_norm, L.spec_norm, B, Tc, d.F, d.E, d.D};
+        int nth = ((d.E + d.D + 63) / 64) * 64;
+        hipLaunchKernelGGL(feat_b_kernel, dim3(B), dim3(nth), 0, st, fb);
+    }
+    // ---- encoder, ERB branch (reference onnx_model/dpdfnet.py:206-219) ----
+    TView e0v{w.e0.p, Tc, 0, d.Ec, 64}, e1v{w.e1.p, Tc, 0, d.F1, 64}, e2v{w.e2.p, Tc, 0, d.F2, 64}, e3v{w.e3.p, Tc, 0, d.F3, 64};
+    {
+        ProfScope ps(m, "enc_convs");
+        Conv0ErbArgs ca{w.feat_erb.p, w.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
+        size_t total = (size_t)BT * d.Ec * 16;
+        hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ca);
+        run_dwconv_s(m, m->erb_conv1, e0v, e1v, B, Tc, d.s1);
+        run_dwconv_s(m, m->erb_conv2, e1v, e2v, B, Tc, d.s2);
+        run_dwconv_s(m, m->erb_conv3, e2v, e3v, B, Tc, d.s3);
+    }
+    float* e3d = w.e3.p;
+    if (d.nb > 0) {
+        HIP_TRY(hipMemcpyAsync(w.xe_a.p, w.e3.p, (size_t)BT * d.F3 * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        e3d = run_dprnn(m, m->dprnn_erb, w.xe_a.p, w.xe_b.p, d.F3, state, S, L.dprnn_erb, B, Tc);
+    }
+    // ---- encoder, DF branch (dpdfnet.py:221-234) ----
+    TView c0v{w.c0.p, Tc + 4, 4, d.D, 64}, c1v{w.c1.p, Tc, 0, d.Fd, 64};
+    {
+        ProfScope ps(m, "enc_convs");
+        RowMap rm{Tc, d.D};
+        Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm, m->C(m->dfc0_w)};
+        BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
+        launch_gemm_rows<4, 64, true>(st, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 64, 1);
+        run_dwconv_s(m, m->df_conv1, c0v, c1v, B, Tc, 2);
+    }
+    float* c1d = w.c1.p;
+    if (d.nb > 0) {
+        HIP_TRY(hipMemcpyAsync(w.xd_a.p, w.c1.p, (size_t)BT * d.Fd * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        c1d = run_dprnn(m, m->dprnn_df, w.xd_a.p, w.xd_b.p, d.Fd, state, S, L.dprnn_df, B, Tc);
+    }
+    m->dbg_e3d = e3d; m->dbg_c1d = c1d; m->dbg_B = B; m->dbg_Tc = Tc;
+    // ---- embedding (dpdfnet.py:233-241; 48k hr.py:285-293).  channels-last [f][c] IS the (f,c) flatten ----
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->df_fc_emb, c1d, (size_t)d.Fd * 64, w.embin.p + 512, 1024, BT, ACT_RELU);
+        if (d.is48) run_gl_auto(m, m->enc_erb_fc, e3d, (size_t)d.F3 * 64, w.embin.p, 1024, BT, ACT_RELU);
+        else HIP_TRY(hipMemcpy2DAsync(w.embin.p, 1024 * sizeof(float), e3d, 512 * sizeof(float), 512 * sizeof(float), BT,
+                                      hipMemcpyDeviceToDevice, st));
+        run_gl_auto(m, m->enc_lin_in, w.embin.p, 1024, w.g256a.p, 256, BT, ACT_RELU);
+    }
+    run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc);
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->enc_lin_out, w.g256b.p, 256, w.emb.p, 512, BT, ACT_RELU);
+        run_gl_auto(m, m->ed_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
+    }
+    // ---- ERB decoder (dpdfnet.py:343-368; 48k hr.py:405-432) ----
+    run_gru256(m, m->ed_gru0, w.g256a.p, w.g256b.p, state, S, L.erb_dec_gru, B, Tc);
+    run_gru256(m, m->ed_gru1, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc);
+    float* dembp = w.demb.p;
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->ed_lin_out, w.g256c.p, 256, w.demb.p, 512, BT, ACT_RELU);
+        if (d.is48) { run_gl_auto(m, m->ed_erb_fc, w.demb.p, 512, w.demb2.p, (size_t)d.F3 * 64, BT, ACT_RELU); dembp = w.demb2.p; }
+    }
+    {
+        ProfScope ps(m, "dec_convs");
+        TView dembv{dembp, Tc, 0, d.F3, 64};
+        TView d3v{w.d3.p, Tc, 0, d.F2, 64}, d2v{w.d2.p, Tc, 0, d.F1, 64}, d1v{w.d1.p, Tc, 0, d.Ec, 64};
+        run_subpix_s(m, m->convt3, m->conv3p, e3v, dembv, d3v, B, Tc, d.s3);
+        run_subpix_s(m, m->convt2, m->conv2p, e2v, d3v, d2v, B, Tc, d.s2);
+        run_subpix_s(m, m->convt1, m->conv1p, e1v, d2v, d1v, B, Tc, d.s1);
+        MaskOutArgs ma{w.e0.p, w.d1.p, w.m.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias,
+                       BT * d.Ec, d.Ec, d.E, d.is48};
+        hipLaunchKernelGGL(mask_out_kernel, dim3((BT * d.Ec + 3) / 4), dim3(256), 0, st, ma);
+    }
+    // ---- DF decoder (dpdfnet.py:486-519) ----
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->df_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
+    }
+    run_gru256(m, m->df_gru0, w.g256a.p, w.g256b.p, state, S, L.df_dec_gru, B, Tc);
+    run_gru256(m, m->df_gru1, w.g256b.p, w.g256c.p, state, S, L.df_dec_gru + 256, B, Tc);
+    {
+        ProfScope ps(m, "grouped_linear");
+        // c = df_gru(emb) + df_skip(emb): accumulate the skip into g256c via a second pass
+        run_gl_auto(m, m->df_skip, w.emb.p, 512, w.g256a.p, 256, BT, ACT_NONE);
+    }
+    {
+        ProfScope ps(m, "df_coefs");
+        size_t n = (size_t)BT * 256;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(axpy_kernel), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, w.g256c.p, w.g256a.p, n);
+        run_gl_auto(m, m->df_out, w.g256c.p, 256, w.dfo.p, (size_t)d.D * 10, BT, ACT_TANH);
+        RowMap rm{Tc, d.D};
+        ConvpA ap{c0v, rm};
+        ConvpEpi ep{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
+        launch_gemm_rows<1, 64, false>(st, ap, m->C(m->convp_frag), ep, BT * d.D, 320, 1);
+    }
+    // ---- mask + deep filter (layers.py:414-445, multiframe.py:200-232) ----
+    {
+        ProfScope ps(m, "mask_df");
+        MaskApplyArgs mk{w.xs.p, w.m.p, w.xm.p, d.is48 ? nullptr : m->iconsts + 33, B, Tc, d.F, d.E};
+        size_t total = (size_t)BT * d.F;
+        hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mk);
+        DfApplyArgs da{w.xm.p, w.coefs.p, out, out_clip_stride, out_t0, attn_raw, alpha, (float)(1.0 - (double)alpha),
+                       B, Tc, d.F, d.D, (float)(1.0 / (double)d.wnorm)};
+        hipLaunchKernelGGL(df_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, da);
+    }
+    {
+        ProfScope ps(m, "state_io");
+        sio.do_export = 1;
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 6), dim3(256), 0, st, sio);
+    }
+    HIP_TRY(hipGetLastError());
+    return DPDF_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_floats, int device, dpdf_model** out) {
+    if (!cfg || !weights || !out) return set_err(DPDF_E_INVALID, "null argument");
+    dpdf_dims d;
+    if (dpdf_get_dims(cfg, &d) != 0) return set_err(DPDF_E_INVALID, "unsupported model config (sample_rate=%d nb=%d)", cfg->sample_rate, cfg->nb);
+    const size_t need = dpdf_manifest(cfg, nullptr, nullptr);
+    if (need != n_floats) return set_err(DPDF_E_INVALID, "weight blob has %zu floats, model needs %zu", n_floats, need);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(DPDF_E_RUNTIME, "no HIP device available: the MI355X engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return set_err(DPDF_E_INVALID, "device %d out of range (have %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    dpdf_model* m = new dpdf_model();
+    m->cfg = *cfg; m->d = d; m->device = device;
+    dpdf_get_state_layout(&d, &m->L);
+    Blob B; B.base = weights;
+    dpdf_manifest(cfg, blob_cb, &B);
+    Arena A;
+
+    // ---- encoder convs ----
+    {
+        BnFold f = fold_bn(B, "enc.erb_conv0.2", 64);
+        const float* w = B.get("enc.erb_conv0.1.weight");
+        std::vector<float> wf(64 * 9);
+        for (int c = 0; c < 64; ++c) for (int k = 0; k < 9; ++k) wf[c * 9 + k] = w[c * 9 + k] * f.scale[c];
+        m->conv0_w = A.add(wf); m->conv0_b = A.add(f.shift);
+    }
+    m->erb_conv1 = build_sepconv(A, B, "enc.erb_conv1", 1);
+    m->erb_conv2 = build_sepconv(A, B, "enc.erb_conv2", 1);
+    m->erb_conv3 = build_sepconv(A, B, "enc.erb_conv3", 1);
+    {
+        std::vector<float> w(64 * 9);
+        const float *w0 = B.get("enc.df_conv0.1.convs.0.weight"), *w1 = B.get("enc.df_conv0.1.convs.1.weight");
+        std::copy(w0, w0 + 32 * 9, w.begin()); std::copy(w1, w1 + 32 * 9, w.begin() + 32 * 9);
+        m->dfc0_w = A.add(w);
+        BnFold f = fold_bn(B, "enc.df_conv0.3", 64);
+        const float* pw = B.get("enc.df_conv0.2.weight");
+        m->dfc0_pwfrag = A.add(pack_frag(64, 64, 4, [&](int k, int n) { return pw[n * 64 + k] * f.scale[n]; }));
+        m->dfc0_bias = A.add(f.shift);
+    }
+    m->df_conv1 = build_sepconv(A, B, "enc.df_conv1", 1);
+    m->dprnn_erb = build_dprnn(A, B, "enc.dprnn_erb", d.nb);
+    m->dprnn_df = build_dprnn(A, B, "enc.dprnn_df", d.nb);
+    if (d.is48) m->enc_erb_fc = build_gl(A, B, "enc.erb_fc_emb.0", 32, d.emb / 32, d.C * d.F3 / 32);
+    m->df_fc_emb = build_gl(A, B, "enc.df_fc_emb.0", 32, d.emb / 32, d.C * d.Fd / 32);
+    m->enc_lin_in = build_gl(A, B, "enc.emb_gru.linear_in.0", 16, d.H / 16, 2 * d.emb / 16);
+    m->enc_gru = build_gru256(A, B, "enc.emb_gru.gru.0.grucell");
+    m->enc_lin_out = build_gl(A, B, "enc.emb_gru.linear_out.0", 16, d.emb / 16, d.H / 16);
+    m->ed_lin_in = build_gl(A, B, "erb_dec.emb_gru.linear_in.0", 16, d.H / 16, d.emb / 16);
+    m->ed_gru0 = build_gru256(A, B, "erb_dec.emb_gru.gru.0.grucell");
+    m->ed_gru1 = build_gru256(A, B, "erb_dec.emb_gru.gru.1.grucell");
+    m->ed_lin_out = build_gl(A, B, "erb_dec.emb_gru.linear_out.0", 16, d.emb / 16, d.H / 16);
+    if (d.is48) m->ed_erb_fc = build_gl(A, B, "erb_dec.erb_fc_emb.0", 32, d.C * d.F3 / 32, d.emb / 32);
+    m->conv3p = build_path(A, B, "erb_dec.conv3p"); m->convt3 = build_sepconv(A, B, "erb_dec.convt3", d.s3 > 1 ? d.s3 : 1);
+    m->conv2p = build_path(A, B, "erb_dec.conv2p"); m->convt2 = build_sepconv(A, B, "erb_dec.convt2", d.s2);
+    m->conv1p = build_path(A, B, "erb_dec.conv1p"); m->convt1 = build_sepconv(A, B, "erb_dec.convt1", d.s1);
+    m->conv0p = build_path(A, B, "erb_dec.conv0p");
+    {
+        BnFold f = fold_bn(B, "erb_dec.conv0_out.1", 1);
+        const float* w = B.get("erb_dec.conv0_out.0.weight");   // [1][64][1][3]
+        std::vector<float> wf(64 * 3);
+        for (int i = 0; i < 192; ++i) wf[i] = w[i] * f.scale[0];
+        m->c0out_w = A.add(wf); m->c0out_bias = f.shift[0];
+    }
+    {   // df_convp: grouped(2) 32->5 k(5,1) . pointwise 10->10 . BN  folded into one [320 x 10] matrix
+        BnFold f = fold_bn(B, "df_dec.df_convp.3", 10);
+        const float *w0 = B.get("df_dec.df_convp.1.convs.0.weight"), *w1 = B.get("df_dec.df_convp.1.convs.1.weight");
+        const float* pw = B.get("df_dec.df_convp.2.weight");    // [10][10]
+        auto wd = [&](int k, int oc) -> float {                 // dense grouped-conv weight, k = kt*64 + cin
+            int kt = k / 64, cin = k % 64, g = cin / 32;
+            if (oc / 5 != g) return 0.f;
+            const float* w = g == 0 ? w0 : w1;
+            return w[((oc % 5) * 32 + (cin % 32)) * 5 + kt];
+        };
+        m->convp_frag = A.add(pack_frag(320, 10, 1, [&](int k, int n) {
+            float acc = 0.f;
+            for (int oc = 0; oc < 10; ++oc) acc += pw[n * 10 + oc] * wd(k, oc);
+            return acc * f.scale[n];
+        }));
+        m->convp_bias = A.add(f.shift);
+    }
+    m->df_lin_in = build_gl(A, B, "df_dec.df_gru.linear_in.0", 8, d.H / 8, d.emb / 8);
+    m->df_gru0 = build_gru256(A, B, "df_dec.df_gru.gru.0.grucell");
+    m->df_gru1 = build_gru256(A, B, "df_dec.df_gru.gru.1.grucell");
+    m->df_skip = build_gl(A, B, "df_dec.df_skip", 16, d.H / 16, d.emb / 16);
+    m->df_out = build_gl(A, B, "df_dec.df_out.0", 16, d.D * 2 * d.O / 16, d.H / 16);
+
+    // ---- STFT / iSTFT as real-DFT GEMMs ----
+    m->window = A.add(vorbis(d.win));
+    {
+        const int N2 = 2 * d.F, NT = 7;
+        m->stft_groups = ((N2 + 15) / 16 + NT - 1) / NT;
+        std::vector<float> frag;
+        for (int g = 0; g < m->stft_groups; ++g) {
+            auto f = pack_frag(d.win, NT * 16, NT, [&](int k, int n) -> float {
+                int ng = g * NT * 16 + n;
+                if (ng >= N2) return 0.f;
+                int fb = ng / 2; long idx = ((long)fb * k) % d.win;
+                double ang = 2.0 * M_PI * (double)idx / d.win;
+                return (ng & 1) ? (float)(-std::sin(ang)) : (float)std::cos(ang);
+            });
+            frag.insert(frag.end(), f.begin(), f.end());
+        }
+        m->stft_frag = A.add(frag);
+    }
+    {
+        const int NT = 5;
+        m->istft_K = ((2 * d.F + 47) / 48) * 48;
+        m->istft_groups = d.win / (NT * 16);
+        std::vector<float> frag;
+        for (int g = 0; g < m->istft_groups; ++g) {
+            auto f = pack_frag(m->istft_K, NT * 16, NT, [&](int k, int n) -> float {
+                if (k >= 2 * d.F) return 0.f;
+                int fb = k / 2, ng = g * NT * 16 + n;
+                double cf = (fb == 0 || fb == d.F - 1) ? 1.0 : 2.0;
+                long idx = ((long)fb * ng) % d.win;
+                double ang = 2.0 * M_PI * (double)idx / d.win;
+                double v = (k & 1) ? -cf * std::sin(ang) : cf * std::cos(ang);
+                if ((k & 1) && (fb == 0 || fb == d.F - 1)) v = 0.0;   // irfft ignores Im of DC / Nyquist
+                return (float)(v / d.win);
+            });
+            frag.insert(frag.end(), f.begin(), f.end());
+        }
+        m->istft_frag = A.add(frag);
+    }
+
+    // ---- upload ----
+    HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&m->ev0)); HIP_TRY(hipEventCreate(&m->ev1));
+    HIP_TRY(hipMalloc((void**)&m->consts, A.h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(m->consts, A.h.data(), A.h.size() * sizeof(float), hipMemcpyHostToDevice));
+    {
+        std::vector<int> ic(33 + d.F, 0);
+        if (!d.is48) {
+            std::vector<int> start, band_of;
+            erb_bands(d.win, d.sr, start, band_of);
+            std::copy(start.begin(), start.end(), ic.begin());
+            std::copy(band_of.begin(), band_of.end(), ic.begin() + 33);
+        }
+        HIP_TRY(hipMalloc((void**)&m->iconsts, ic.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(m->iconsts, ic.data(), ic.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    // ErbNorm / SpecNorm initial states (reference onnx_model/layers.py:455-463, 516-522)
+    m->erb_norm_init.resize(d.E); m->spec_norm_init.resize(d.D);
+    {
+        float step = (float)((-90.0 - (-60.0)) / (d.E - 1));
+        for (int i = 0; i < d.E; ++i) m->erb_norm_init[i] = -60.0f + (float)i * step;
+        float step2 = (float)((0.0001 - 0.001) / (d.D - 1));
+        for (int i = 0; i < d.D; ++i) m->spec_norm_init[i] = 0.001f + (float)i * step2;
+    }
+    HIP_TRY(hipMalloc((void**)&m->d_init_state, (size_t)d.state_size * sizeof(float)));
+    {
+        std::vector<float> st(d.state_size, 0.f);
+        std::copy(m->erb_norm_init.begin(), m->erb_norm_init.end(), st.begin() + m->L.erb_norm);
+        std::copy(m->spec_norm_init.begin(), m->spec_norm_init.end(), st.begin() + m->L.spec_norm);
+        HIP_TRY(hipMemcpy(m->d_init_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *out = m;
+    return DPDF_OK;
+}
+
+extern "C" void dpdf_destroy(dpdf_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    m->ws.release();
+    DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state};
+    for (DevBuf* b : bufs) b->release();
+    if (m->consts) (void)hipFree(m->consts);
+    if (m->iconsts) (void)hipFree(m->iconsts);
+    if (m->d_init_state) (void)hipFree(m->d_init_state);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int dpdf_set_norm_init(dpdf_model* m, const float* e, int ne, const float* s, int ns) {
+    if (!m) return set_err(DPDF_E_INVALID, "null model");
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    if (e) {
+        if (ne != m->d.E) return set_err(DPDF_E_INVALID, "erb_norm_init has %d values, model needs %d", ne, m->d.E);
+        m->erb_norm_init.assign(e, e + ne);
+        HIP_TRY(hipMemcpy(m->d_init_state + m->L.erb_norm, e, ne * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (s) {
+        if (ns != m->d.D) return set_err(DPDF_E_INVALID, "spec_norm_init has %d values, model needs %d", ns, m->d.D);
+        m->spec_norm_init.assign(s, s + ns);
+        HIP_TRY(hipMemcpy(m->d_init_state + m->L.spec_norm, s, ns * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return DPDF_OK;
+}
+extern "C" int dpdf_state_size(const dpdf_model* m) { return m ? m->d.state_size : 0; }
+extern "C" int dpdf_initial_state(const dpdf_model* m, float* state) {
+    if (!m || !state) return set_err(DPDF_E_INVALID, "null argument");
+    memset(state, 0, sizeof(float) * m->d.state_size);
+    std::copy(m->erb_norm_init.begin(), m->erb_norm_init.end(), state + m->L.erb_norm);
+    std::copy(m->spec_norm_init.begin(), m->spec_norm_init.end(), state + m->L.spec_norm);
+    return DPDF_OK;
+}
+extern "C" int dpdf_win_len(const dpdf_model* m) { return m ? m->d.win : 0; }
+extern "C" int dpdf_hop(const dpdf_model* m) { return m ? m->d.hop : 0; }
+extern "C" int dpdf_freq_bins(const dpdf_model* m) { return m ? m->d.F : 0; }
+extern "C" int dpdf_sample_rate(const dpdf_model* m) { return m ? m->d.sr : 0; }
+extern "C" int dpdf_num_frames(const dpdf_model* m, int n) { return m ? 1 + (n + m->d.win) / m->d.hop : 0; }
+extern "C" int dpdf_set_chunk_frames(dpdf_model* m, int frames) {
+    if (!m) return set_err(DPDF_E_INVALID, "null model");
+    m->chunk_frames = frames;
+    return DPDF_OK;
+}
+extern "C" int dpdf_sync(dpdf_model* m) {
+    if (!m) return set_err(DPDF_E_INVALID, "null model");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return DPDF_OK;
+}
+extern "C" int dpdf_profile_enable(dpdf_model* m, int on) {
+    if (!m) return set_err(DPDF_E_INVALID, "null model");
+    m->prof_on = on != 0;
+    if (on) m->prof.clear();
+    return DPDF_OK;
+}
+extern "C" size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap) {
+    if (!m) return 0;
+    std::string s;
+    for (auto& kv : m->prof) {
+        char line[160];
+        snprintf(line, sizeof(line), "%s %.4f %ld\n", kv.first.c_str(), kv.second.ms, kv.second.calls);
+        s += line;
+    }
+    if (buf && cap) { size_t n = std::min(cap - 1, s.size()); memcpy(buf, s.data(), n); buf[n] = 0; }
+    return s.size();
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame function for B streams x T frames (drop-in for the session.run loop)
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, float* state, float* spec_e, int flags) {
+    if (!m || !spec || !state || !spec_e) return set_err(DPDF_E_INVALID, "null argument");
+    if (B <= 0 || T < 0) return set_err(DPDF_E_INVALID, "bad batch geometry B=%d T=%d", B, T);
+    if (T == 0) return DPDF_OK;
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t nspec = (size_t)B * T * m->d.F * 2, nstate = (size_t)B * m->d.state_size;
+    const float* d_spec = spec; float* d_state = state; float* d_out = spec_e;
+    const bool host = !(flags & DPDF_DEVICE_PTRS);
+    if (host) {
+        int rc;
+        if ((rc = m->io_spec.ensure(nspec)) || (rc = m->io_spec_e.ensure(nspec)) || (rc = m->io_state.ensure(nstate))) return rc;
+        HIP_TRY(hipMemcpyAsync(m->io_spec.p, spec, nspec * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(m->io_state.p, state, nstate * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        d_spec = m->io_spec.p; d_state = m->io_state.p; d_out = m->io_spec_e.p;
+    }
+    const size_t cs = (size_t)T * m->d.F * 2;
+    const int chunk = m->chunk_frames > 0 ? m->chunk_frames : T;
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        int tc = std::min(chunk, T - t0);
+        int rc = run_chunk(m, d_spec + (size_t)t0 * m->d.F * 2, cs, B, tc, d_state, d_out, cs, t0, nullptr, 0.f);
+        if (rc) return rc;
+    }
+    if (host) {
+        HIP_TRY(hipMemcpyAsync(spec_e, d_out, nspec * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(state, d_state, nstate * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    return DPDF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// offline batch path: enhance() for B clips
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N, float attn_limit_db, float* out, int flags) {
+    if (!m || !wav || !out) return set_err(DPDF_E_INVALID, "null argument");
+    if (B <= 0 || N < 0) return set_err(DPDF_E_INVALID, "bad batch geometry B=%d N=%d", B, N);
+    if (attn_limit_db < 0.f) return set_err(DPDF_E_INVALID, "attn_limit_db must be non-negative, infinity, or None.");
+    if (N == 0) return DPDF_OK;
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    const dpdf_dims& d = m->d;
+    const int T = 1 + (N + d.win) / d.hop;
+    const bool host = !(flags & DPDF_DEVICE_PTRS);
+    const size_t nw = (size_t)B * N, nspec = (size_t)B * T * d.F * 2;
+    int rc;
+    const float* d_wav = wav; float* d_out = out;
+    if (host) {
+        if ((rc = m->io_wav.ensure(nw)) || (rc = m->io_out.ensure(nw))) return rc;
+        HIP_TRY(hipMemcpyAsync(m->io_wav.p, wav, nw * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        d_wav = m->io_wav.p; d_out = m->io_out.p;
+    }
+    if ((rc = m->raw_spec.ensure(nspec)) || (rc = m->enh_spec.ensure(nspec)) ||
+        (rc = m->batch_state.ensure((size_t)B * d.state_size)) || (rc = m->frames.ensure((size_t)B * T * d.win))) return rc;
+    // A1: analysis STFT
+    {
+        ProfScope ps(m, "stft");
+        StftA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window)};
+        BiasActStore<7> ep{m->raw_spec.p, (size_t)2 * d.F, 112, nullptr, 0, 112, ACT_NONE};
+        ep.ncol_total = 2 * d.F;
+        launch_gemm_rows<7, 64, false>(m->stream, ap, m->C(m->stft_frag), ep, B * T, d.win, m->stft_groups);
+    }
+    // A17/A20: initial state for every clip
+    {
+        size_t n = (size_t)B * d.state_size;
+        hipLaunchKernelGGL(fill_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream,
+                           m->batch_state.p, m->d_init_state, (long)d.state_size, B);
+    }
+    // A2..A13: frame function over time chunks (+ attenuation limit fused in the DF kernel)
+    const bool attn = std::isfinite(attn_limit_db);
+    const float alpha = attn ? (float)std::pow(10.0, -(double)attn_limit_db / 20.0) : 0.f;
+    const size_t cs = (size_t)T * d.F * 2;
+    const int chunk = m->chunk_frames > 0 ? m->chunk_frames : T;
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        int tc = std::min(chunk, T - t0);
+        rc = run_chunk(m, m->raw_spec.p + (size_t)t0 * d.F * 2, cs, B, tc, m->batch_state.p, m->enh_spec.p, cs, t0,
+                       attn ? m->raw_spec.p : nullptr, alpha);
+        if (rc) return rc;
+    }
+    // A14: synthesis
+    {
+        ProfScope ps(m, "istft");
+        PlainA<48> ap{m->enh_spec.p, (size_t)2 * d.F, 0, 2 * d.F};
+        WindowStore<5> ep{m->frames.p, d.win, m->C(m->window)};
+        launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups);
+        OlaArgs oa{m->frames.p, m->C(m->window), d_out, B, T, N, d.win, d.hop};
+        hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, m->stream, oa);
+    }
+    HIP_TRY(hipGetLastError());
+    if (host) {
+        HIP_TRY(hipMemcpyAsync(out, d_out, nw * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    return DPDF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident streaming (StreamEnhancer hot loop for S concurrent streams)
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpdf_streams_create(dpdf_model* m, int n_streams, dpdf_streams** out) {
+    if (!m || !out || n_streams <= 0) return set_err(DPDF_E_INVALID, "bad argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    dpdf_streams* s = new dpdf_streams();
+    s->m = m; s->S = n_streams; s->primed.assign(n_streams, 0);
+    int rc;
+    if ((rc = s->state.ensure((size_t)n_streams * m->d.state_size)) || (rc = s->in_tail.ensure((size_t)n_streams * m->d.hop)) ||
+        (rc = s->ola_tail.ensure((size_t)n_streams * m->d.hop))) { delete s; return rc; }
+    *out = s;
+    size_t n = (size_t)n_streams * m->d.state_size;
+    hipLaunchKernelGGL(fill_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, s->state.p, m->d_init_state,
+                       (long)m->d.state_size, n_streams);
+    HIP_TRY(hipMemsetAsync(s->in_tail.p, 0, (size_t)n_streams * m->d.hop * sizeof(float), m->stream));
+    HIP_TRY(hipMemsetAsync(s->ola_tail.p, 0, (size_t)n_streams * m->d.hop * sizeof(float), m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return DPDF_OK;
+}
+extern "C" void dpdf_streams_destroy(dpdf_streams* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->m->device);
+    (void)hipStreamSynchronize(s->m->stream);
+    DevBuf* bufs[] = {&s->state, &s->in_tail, &s->ola_tail, &s->spec, &s->spec_e, &s->pcm_in, &s->pcm_out};
+    for (DevBuf* b : bufs) b->release();
+    delete s;
+}
+extern "C" int dpdf_streams_reset(dpdf_streams* s, int stream) {
+    if (!s) return set_err(DPDF_E_INVALID, "null streams");
+    if (stream >= s->S) return set_err(DPDF_E_STATE, "stream %d out of range (have %d)", stream, s->S);
+    dpdf_model* m = s->m;
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    const int lo = stream < 0 ? 0 : stream, cnt = stream < 0 ? s->S : 1;
+    size_t n = (size_t)cnt * m->d.state_size;
+    hipLaunchKernelGGL(fill_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream,
+                       s->state.p + (size_t)lo * m->d.state_size, m->d_init_state, (long)m->d.state_size, cnt);
+    HIP_TRY(hipMemsetAsync(s->in_tail.p + (size_t)lo * m->d.hop, 0, (size_t)cnt * m->d.hop * sizeof(float), m->stream));
+    HIP_TRY(hipMemsetAsync(s->ola_tail.p + (size_t)lo * m->d.hop, 0, (size_t)cnt * m->d.hop * sizeof(float), m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (int i = lo; i < lo + cnt; ++i) s->primed[i] = 0;
+    return DPDF_OK;
+}
+extern "C" int dpdf_streams_prime(dpdf_streams* s, const float* pcm_in, int flags) {
+    if (!s || !pcm_in) return set_err(DPDF_E_INVALID, "null argument");
+    dpdf_model* m = s->m;
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t n = (size_t)s->S * m->d.hop;
+    HIP_TRY(hipMemcpyAsync(s->in_tail.p, pcm_in, n * sizeof(float),
+                           (flags & DPDF_DEVICE_PTRS) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < s->S; ++i) s->primed[i] = 1;
+    return DPDF_OK;
+}
+extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, int flags) {
+    if (!s || !pcm_in || !pcm_out) return set_err(DPDF_E_INVALID, "null argument");
+    if (n_hops <= 0) return set_err(DPDF_E_INVALID, "n_hops must be positive");
+    dpdf_model* m = s->m;
+    for (int i = 0; i < s->S; ++i)
+        if (!s->primed[i]) return set_err(DPDF_E_STATE, "stream %d not primed: call dpdf_streams_prime with its first hop", i);
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    const dpdf_dims& d = m->d;
+    const int S = s->S, T = n_hops;
+    const size_t npcm = (size_t)S * T * d.hop, nspec = (size_t)S * T * d.F * 2;
+    const bool host = !(flags & DPDF_DEVICE_PTRS);
+    int rc;
+    if ((rc = s->spec.ensure(nspec)) || (rc = s->spec_e.ensure(nspec)) || (rc = m->frames.ensure((size_t)S * T * d.win)) ||
+        (rc = s->pcm_in.ensure((size_t)S * (T + 1) * d.hop + npcm)) || (rc = s->pcm_out.ensure(npcm))) return rc;
+    float* xbuf = s->pcm_in.p;                       // [S][(T+1)*hop]
+    float* d_in = s->pcm_in.p + (size_t)S * (T + 1) * d.hop;
+    const float* src = pcm_in; float* dst = pcm_out;
+    if (host) {
+        HIP_TRY(hipMemcpyAsync(d_in, pcm_in, npcm * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        src = d_in; dst = s->pcm_out.p;
+    }
+    hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, s->in_tail.p, xbuf, S, T, d.hop);
+    {   // causal analysis (stream.py:119-126): frame j = xbuf[j*hop : j*hop+win] * window -> rfft.
+                StftA<64> ap{xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
+        BiasActStore<7> ep{s->spec.p, (size_t)2 * d.F, 112, nullptr, 0, 112, ACT_NONE};
+        ep.ncol_total = 2 * d.F;
+        launch_gemm_rows<7, 64, false>(m->stream, ap, m->C(m->stft_frag), ep, S * T, d.win, m->stft_groups);
+    }
+    const size_t cs = (size_t)T * d.F * 2;
+    rc = run_chunk(m, s->spec.p, cs, S, T, s->state.p, s->spec_e.p, cs, 0, nullptr, 0.f);
+    if (rc) return rc;
+    {
+        PlainA<48> ap{s->spec_e.p, (size_t)2 * d.F, 0, 2 * d.F};
+        WindowStore<5> ep{m->frames.p, d.win, m->C(m->window)};
+        launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups);
+        hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, s->ola_tail.p, dst, S, T, d.hop);
+    }
+    HIP_TRY(hipGetLastError());
+    if (host) {
+        HIP_TRY(hipMemcpyAsync(pcm_out, dst, npcm * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    return DPDF_OK;
+}
+extern "C" int dpdf_streams_get_state(dpdf_streams* s, int stream, float* state_host) {
+    if (!s || !state_host) return set_err(DPDF_E_INVALID, "null argument");
+    if (stream < 0 || stream >= s->S) return set_err(DPDF_E_STATE, "stream %d out of range (have %d)", stream, s->S);
+    dpdf_model* m = s->m;
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(state_host, s->state.p + (size_t)stream * m->d.state_size, (size_t)m->d.state_size * sizeof(float), hipMemcpyDeviceToHost));
+    return DPDF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug: fetch an intermediate tensor of the LAST chunk (per-stage parity tests).  Layouts are the
+// engine's own channels-last forms: e0 [B][Tc][Ec][64], c0 [B][4+Tc][D][64] (halo 4), ...
+// ------------------------------------------------------------------------------------------------
+extern "C" long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, long cap) {
+    if (!m || !name) return -1;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (hipSetDevice(m->device) != hipSuccess) return -1;
+    const dpdf_dims& d = m->d; Workspace& w = m->ws;
+    const long B = m->dbg_B, Tc = m->dbg_Tc, BT = B * Tc;
+    const float* src = nullptr; long n = 0;
+    std::string s(name);
+    if (s == "feat_erb") { src = w.feat_erb.p; n = B * (Tc + 2) * d.E; }
+    else if (s == "feat_spec") { src = w.feat_spec.p; n = B * (Tc + 2) * 2 * d.D; }
+    else if (s == "e0") { src = w.e0.p; n = BT * d.Ec * 64; }
+    else if (s == "e1") { src = w.e1.p; n = BT * d.F1 * 64; }
+    else if (s == "e2") { src = w.e2.p; n = BT * d.F2 * 64; }
+    else if (s == "e3") { src = w.e3.p; n = BT * d.F3 * 64; }
+    else if (s == "e3_dprnn") { src = m->dbg_e3d; n = BT * d.F3 * 64; }
+    else if (s == "c0") { src = w.c0.p; n = B * (Tc + 4) * d.D * 64; }
+    else if (s == "c1") { src = w.c1.p; n = BT * d.Fd * 64; }
+    else if (s == "c1_dprnn") { src = m->dbg_c1d; n = BT * d.Fd * 64; }
+    else if (s == "emb") { src = w.emb.p; n = BT * 512; }
+    else if (s == "m") { src = w.m.p; n = BT * d.E; }
+    else if (s == "coefs") { src = w.coefs.p; n = B * (Tc + 2) * d.D * 10; }
+    else if (s == "xm") { src = w.xm.p; n = B * (Tc + 4) * d.F * 2; }
+    if (!src) return -1;
+    if (host && cap >= n) {
+        if (hipStreamSynchronize(m->stream) != hipSuccess) return -1;
+        if (hipMemcpy(host, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    return n;
+}

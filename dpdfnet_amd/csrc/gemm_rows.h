@@ -1,0 +1,390 @@
+// gemm_rows.h -- the feed-forward workhorse: out[r, :] = epi(A[r, 0:K] . W[K, N]) for millions of
+// short rows (r = (clip, frame[, band]) ), K <= 336, N <= 768.  fp32 in / fp32 accumulate on the
+// CDNA4 matrix cores (v_mfma_f32_16x16x4_f32, bit-exact fp32 FMA chains).
+//
+//   * 256-thread workgroup = 4 wavefronts; a workgroup owns a 64-row tile, each wave 16 rows x
+//     NT 16-column MFMA tiles (NT <= 8).  blockIdx.y selects the weight group / column block.
+//   * A is never read "as stored": an A-producer functor stages a [64 x KP] panel in LDS --
+//     this is where depthwise convs, sub-pixel upsampling, pathway convs, FIFO (time-halo)
+//     gathers, STFT framing/windowing are fused, so those intermediates never touch HBM.
+//   * W is pre-packed on the host into MFMA B-fragment order ([group][chunk][tile][kb][lane]),
+//     so every weight load is one coalesced 256-byte wave transaction served from L2; small
+//     panels (K*NT*16 <= 128 VGPR) are hoisted into registers once per workgroup (PERSIST_B) and
+//     reused across a grid-stride loop over row tiles.
+//   * The epilogue functor sees the accumulators in MFMA C layout (row = (lane>>4)*4+i,
+//     col = tile*16 + (lane&15)): bias/BN shift, activation, LayerNorm over the 64 channels
+//     (in-register butterfly over the 16 column lanes), residual add, scatter to halo'd tensors.
+#pragma once
+#include "common.h"
+
+constexpr int GEMM_BM = 64;
+
+// ----- tensor view: [B][Tt][Fp][C] with a time halo of H frames in front of each clip ---------
+struct TView {
+    float* p;
+    int Tt, H, Fp, C;      // frames per clip in the buffer (halo + chunk), halo, bands, channels
+    __device__ __forceinline__ float* at(int b, int t, int f) const {
+        return p + (((size_t)b * Tt + H + t) * Fp + f) * C;
+    }
+};
+
+struct RowMap {            // flat row r over (b, t, f): t in [0,Tc), f in [0,Fp)
+    int Tc, Fp;
+    __device__ __forceinline__ void split(int r, int& b, int& t, int& f) const {
+        int bt = r / Fp; f = r - bt * Fp; b = bt / Tc; t = bt - b * Tc;
+    }
+};
+
+// ================================= A producers ================================================
+// fill(As, row0, kp, grp, M): stage rows [row0,row0+64) x K columns [kp, kp+KP) into As[64][KP+4].
+
+template <int KP>
+struct PlainA {            // A[r][k] = src[r*lda + grp*gstride + k], zero for k >= kmax or r >= M
+    const float* src; size_t lda; int gstride; int kmax;
+    __device__ __forceinline__ void fill(float (*As)[KP + 4], int row0, int kp, int grp, int M) const {
+        constexpr int V = KP / 4;
+        for (int idx = threadIdx.x; idx < GEMM_BM * V; idx += 256) {
+            int r = idx / V, c4 = (idx - r * V) * 4;
+            int row = row0 + r, k = kp + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M) {
+                const float* s = src + (size_t)row * lda + (size_t)grp * gstride + k;
+                if (k + 3 < kmax) v = *(const float4*)s;
+                else {
+                    if (k < kmax) v.x = s[0];
+                    if (k + 1 < kmax) v.y = s[1];
+                    if (k + 2 < kmax) v.z = s[2];
+                }
+            }
+            *(float4*)&As[r][c4] = v;
+        }
+    }
+};
+
+// depthwise k(1,3) conv, zero pad 1, frequency stride S, fused in front of the pointwise GEMM
+// (reference Conv2dNormAct separable, onnx_model/layers.py:761-834).  K = C = 64.
+template <int S>
+struct DwConvA {
+    TView x; RowMap rm;    // rm.Fp = output bands; x.Fp = input bands
+    const float* dw;       // [64][3]
+    __device__ __forceinline__ void fill(float (*As)[64 + 4], int row0, int kp, int grp, int M) const {
+        for (int idx = threadIdx.x; idx < GEMM_BM * 16; idx += 256) {
+            int r = idx >> 4, c4 = (idx & 15) * 4;
+            int row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M) {
+                int b, t, fo; rm.split(row, b, t, fo);
+                const float* xr = x.at(b, t, 0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    int fi = fo * S + j - 1;
+                    if (fi >= 0 && fi < x.Fp) {
+                        float4 xv = *(const float4*)(xr + (size_t)fi * 64 + c4);
+                        v.x += dw[(c4 + 0) * 3 + j] * xv.x; v.y += dw[(c4 + 1) * 3 + j] * xv.y;
+                        v.z += dw[(c4 + 2) * 3 + j] * xv.z; v.w += dw[(c4 + 3) * 3 + j] * xv.w;
+                    }
+                }
+            }
+            *(float4*)&As[r][c4] = v;
+        }
+    }
+};
+
+// decoder stage: u = relu(ps*e + pb) + prev   (pathway conv = per-channel scale + BN + ReLU,
+// SURVEY appendix A.1; reference onnx_model/dpdfnet.py:361-364), then sub-pixel upsampling:
+// S depthwise k(1,3) convs on u interleaved along frequency (layers.py:895-916), S=1 = plain.
+template <int S>
+struct SubpixA {
+    TView e, prev; RowMap rm;          // rm.Fp = output bands = e.Fp * S
+    const float* ps; const float* pb;  // folded pathway scale / shift [64]
+    const float* dw;                   // [S][64][3]
+    __device__ __forceinline__ void fill(float (*As)[64 + 4], int row0, int kp, int grp, int M) const {
+        for (int idx = threadIdx.x; idx < GEMM_BM * 16; idx += 256) {
+            int r = idx >> 4, c4 = (idx & 15) * 4;
+            int row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M) {
+                int b, t, fo; rm.split(row, b, t, fo);
+                int f = fo / S, k = fo - f * S;
+                const float* er = e.at(b, t, 0);
+                const float* pr = prev.at(b, t, 0);
+                const float* w = dw + (size_t)k * 64 * 3;
+                float4 s4 = *(const float4*)(ps + c4), b4 = *(const float4*)(pb + c4);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    int fi = f + j - 1;
+                    if (fi >= 0 && fi < e.Fp) {
+                        float4 ev = *(const float4*)(er + (size_t)fi * 64 + c4);
+                        float4 pv = *(const float4*)(pr + (size_t)fi * 64 + c4);
+                        float ux = fmaxf(s4.x * ev.x + b4.x, 0.f) + pv.x;
+                        float uy = fmaxf(s4.y * ev.y + b4.y, 0.f) + pv.y;
+                        float uz = fmaxf(s4.z * ev.z + b4.z, 0.f) + pv.z;
+                        float uw = fmaxf(s4.w * ev.w + b4.w, 0.f) + pv.w;
+                        v.x += w[(c4 + 0) * 3 + j] * ux; v.y += w[(c4 + 1) * 3 + j] * uy;
+                        v.z += w[(c4 + 2) * 3 + j] * uz; v.w += w[(c4 + 3) * 3 + j] * uw;
+                    }
+                }
+            }
+            *(float4*)&As[r][c4] = v;
+        }
+    }
+};
+
+// df_conv0 front half: GroupedConv2D(2 groups, 1->32 each, k(3,3)) over the last 3 frames of
+// feat_spec (reference onnx_model/layers.py:1083-1114, dpdfnet.py:94-101); K = 64.
+struct Conv0DfA {
+    const float* fs;       // feat_spec [B][2+Tc][2][D]
+    int Tt, D; RowMap rm;  // rm.Fp = D
+    const float* w;        // [64][9]
+    __device__ __forceinline__ void fill(float (*As)[64 + 4], int row0, int kp, int grp, int M) const {
+        for (int idx = threadIdx.x; idx < GEMM_BM * 64; idx += 256) {
+            int r = idx >> 6, c = idx & 63;
+            int row = row0 + r;
+            float v = 0.f;
+            if (row < M) {
+                int b, t, f; rm.split(row, b, t, f);
+                int g = c >> 5;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) {
+                    const float* src = fs + (((size_t)b * Tt + t + kt) * 2 + g) * D;   // frame t-2+kt (+halo 2)
+#pragma unroll
+                    for (int kf = 0; kf < 3; ++kf) {
+                        int fi = f + kf - 1;
+                        if (fi >= 0 && fi < D) v += w[c * 9 + kt * 3 + kf] * src[fi];
+                    }
+                }
+            }
+            As[r][c] = v;
+        }
+    }
+};
+
+// df_convp gather: A[(b,t,f)][kt*64 + c] = c0[b, t-4+kt, f, c]  (K = 5*64, panel kp/64 = kt)
+struct ConvpA {
+    TView c0; RowMap rm;   // c0.H = 4
+    __device__ __forceinline__ void fill(float (*As)[64 + 4], int row0, int kp, int grp, int M) const {
+        const int kt = kp >> 6;
+        for (int idx = threadIdx.x; idx < GEMM_BM * 16; idx += 256) {
+            int r = idx >> 4, c4 = (idx & 15) * 4;
+            int row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M) {
+                int b, t, f; rm.split(row, b, t, f);
+                v = *(const float4*)(c0.at(b, t - 4 + kt, f) + c4);
+            }
+            *(float4*)&As[r][c4] = v;
+        }
+    }
+};
+
+// STFT framing: A[(b,t)][k] = window[k] * x_pad[b][t*hop + k - win/2], x_pad = reflect(np.pad(wav,(0,win)))
+// (reference package/src/dpdfnet/audio.py:104-117 + api.py:88)
+template <int KP>
+struct StftA {
+    const float* wav; int N; int T; int win, hop; const float* window;
+    int causal = 0;        // 1: frame t = x[t*hop : t*hop+win] (StreamEnhancer), no centre/reflect padding
+    __device__ __forceinline__ void fill(float (*As)[KP + 4], int row0, int kp, int grp, int M) const {
+        const int np_ = N + win;
+        for (int idx = threadIdx.x; idx < GEMM_BM * KP; idx += 256) {
+            int r = idx / KP, k = idx - r * KP;
+            int row = row0 + r;
+            float v = 0.f;
+            if (row < M) {
+                int b = row / T, t = row - b * T;
+                int kk = kp + k;
+                int j = t * hop + kk;
+                if (!causal) {
+                    j -= win / 2;
+                    if (j < 0) j = -j;
+                    if (j >= np_) j = 2 * (np_ - 1) - j;
+                }
+                if (j < N && kk < win) v = wav[(size_t)b * N + j] * window[kk];
+            }
+            As[r][k] = v;
+        }
+    }
+};
+
+// ================================= epilogues ==================================================
+// call(acc, row0, lane, grp, M): acc[nt][i] = C[row0 + (lane>>4)*4 + i][nt*16 + (lane&15)]
+
+template <int NT>
+struct BiasActStore {      // out[r*ldo + grp*gostride + col] = act(acc + bias[grp*gbstride + col]), col < N
+    float* out; size_t ldo; int gostride; const float* bias; int gbstride; int N; int act;
+    int ncol_total = 0;    // >0: also bound the global column grp*gostride+col (partial last group)
+    __device__ __forceinline__ void call(f32x4 (&acc)[NT], int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            int col = nt * 16 + cl;
+            if (col >= N) continue;
+            if (ncol_total > 0 && grp * gostride + col >= ncol_total) continue;
+            float bv = bias ? bias[grp * gbstride + col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = row0 + rq + i;
+                if (row < M) out[(size_t)row * ldo + (size_t)grp * gostride + col] = apply_act(acc[nt][i] + bv, act);
+            }
+        }
+    }
+};
+
+// conv output (+folded BN shift, ReLU) into a halo'd [B][Tt][Fp][64] tensor
+struct BiasReluToView {
+    TView o; RowMap rm; const float* bias;
+    __device__ __forceinline__ void call(f32x4 (&acc)[4], int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = row0 + rq + i;
+            if (row >= M) continue;
+            int b, t, f; rm.split(row, b, t, f);
+            float* dst = o.at(b, t, f);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                int col = nt * 16 + cl;
+                dst[col] = fmaxf(acc[nt][i] + bias[col], 0.f);
+            }
+        }
+    }
+};
+
+// Linear bias + LayerNorm(64, eps 1e-5, biased var) + residual  (DPRNNBlock fc_intra/ln_intra and
+// fc_inter/ln_inter, reference onnx_model/layers.py:178-193).  Rows are contiguous [M][64].
+struct LnResStore {
+    float* out; const float* res; const float* bias; const float* g; const float* be;
+    __device__ __forceinline__ void call(f32x4 (&acc)[4], int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+        float v[4][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float bv = bias[nt * 16 + cl];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[nt][i] = acc[nt][i] + bv;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = v[0][i] + v[1][i] + v[2][i] + v[3][i];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off, 64);
+            float mean = s * (1.0f / 64.0f);
+            float d0 = v[0][i] - mean, d1 = v[1][i] - mean, d2 = v[2][i] - mean, d3 = v[3][i] - mean;
+            float q = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) q += __shfl_xor(q, off, 64);
+            float inv = rsqrtf(q * (1.0f / 64.0f) + 1e-5f);
+            int row = row0 + rq + i;
+            if (row < M) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    int col = nt * 16 + cl;
+                    float y = (v[nt][i] - mean) * inv * g[col] + be[col];
+                    out[(size_t)row * 64 + col] = res[(size_t)row * 64 + col] + y;
+                }
+            }
+        }
+    }
+};
+
+// df_convp epilogue: coefs[b, t, f, k] = relu(acc + bias[k]) + df_out[b, t, f*10 + k]   (k < 10)
+// (reference onnx_model/dpdfnet.py:508-515; pointwise 10->10 + BN are folded into the GEMM weights)
+struct ConvpEpi {
+    float* coefs; int Tt; RowMap rm;   // coefs [B][2+Tc][D][10], halo 2
+    const float* dfo;                  // [B*Tc][D*10]
+    const float* bias;
+    __device__ __forceinline__ void call(f32x4 (&acc)[1], int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+        if (cl >= 10) return;
+        float bv = bias[cl];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = row0 + rq + i;
+            if (row >= M) continue;
+            int b, t, f; rm.split(row, b, t, f);
+            float v = fmaxf(acc[0][i] + bv, 0.f) + dfo[(size_t)row * 10 + cl];
+            coefs[((((size_t)b * Tt + 2 + t) * rm.Fp) + f) * 10 + cl] = v;
+        }
+    }
+};
+
+// iSTFT frame epilogue: frames[r][n] = acc * window[n]
+template <int NT>
+struct WindowStore {
+    float* out; int win; const float* window;
+    __device__ __forceinline__ void call(f32x4 (&acc)[NT], int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            int col = grp * NT * 16 + nt * 16 + cl;
+            if (col >= win) continue;
+            float wv = window[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = row0 + rq + i;
+                if (row < M) out[(size_t)row * win + col] = acc[nt][i] * wv;
+            }
+        }
+    }
+};
+
+// ================================= the kernel =================================================
+// wfrag layout: [grp][chunk c][tile nt][kb][lane]  (chunk = 16 K values; value = W[kperm(c,lane>>4,kb)][nt*16+(lane&15)])
+template <int NT, int KP, bool PERSIST_B, class AProd, class Epi>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(AProd ap, const float* __restrict__ wfrag, Epi ep,
+                                                        int M, int K) {
+    __shared__ __attribute__((aligned(16))) float As[GEMM_BM][KP + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int grp = blockIdx.y;
+    const int nchunks = K / 16;
+    const float* wf = wfrag + (size_t)grp * nchunks * NT * 256 + lane;
+    const int ntiles = (M + GEMM_BM - 1) / GEMM_BM;
+    constexpr int PB = PERSIST_B ? (KP / 16) * NT * 4 : 1;
+    float breg[PB];
+    if (PERSIST_B) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) breg[i] = wf[(size_t)i * 64];
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kp = 0; kp < K; kp += KP) {
+            __syncthreads();
+            ap.fill(As, tile * GEMM_BM, kp, grp, M);
+            __syncthreads();
+            const float* arow = &As[wave * 16 + (lane & 15)][(lane >> 4) * 4];
+#pragma unroll
+            for (int c = 0; c < KP / 16; ++c) {
+                float4 a4 = *(const float4*)(arow + c * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (PERSIST_B) {
+                        const int bi = (c * NT + nt) * 4;
+                        acc[nt] = mfma16(a4.x, breg[bi + 0], acc[nt]);
+                        acc[nt] = mfma16(a4.y, breg[bi + 1], acc[nt]);
+                        acc[nt] = mfma16(a4.z, breg[bi + 2], acc[nt]);
+                        acc[nt] = mfma16(a4.w, breg[bi + 3], acc[nt]);
+                    } else {
+                        const float* wp = wf + ((size_t)((kp / 16 + c) * NT + nt) * 4) * 64;
+                        float b0 = wp[0], b1 = wp[64], b2 = wp[128], b3 = wp[192];
+                        acc[nt] = mfma16(a4.x, b0, acc[nt]);
+                        acc[nt] = mfma16(a4.y, b1, acc[nt]);
+                        acc[nt] = mfma16(a4.z, b2, acc[nt]);
+                        acc[nt] = mfma16(a4.w, b3, acc[nt]);
+                    }
+                }
+            }
+        }
+        ep.call(acc, tile * GEMM_BM + wave * 16, lane, grp, M);
+    }
+}
+
+template <int NT, int KP, bool PERSIST_B, class AProd, class Epi>
+static inline void launch_gemm_rows(hipStream_t st, const AProd& ap, const float* wfrag, const Epi& ep,
+                                    int M, int K, int groups, int max_blocks_x = 2048) {
+    int ntiles = (M + GEMM_BM - 1) / GEMM_BM;
+    if (ntiles <= 0) return;
+    int gx = ntiles < max_blocks_x ? ntiles : max_blocks_x;
+    dim3 grid(gx, groups, 1);
+    hipLaunchKernelGGL((gemm_rows_kernel<NT, KP, PERSIST_B, AProd, Epi>), grid, dim3(256), 0, st, ap, wfrag, ep, M, K);
+}

@@ -1,0 +1,216 @@
+// gru_scan.h -- recurrent scans on the CDNA4 matrix cores.
+//
+// gru64_scan_kernel: the DPRNN work-horse (85 % of the model's FLOPs).  One kernel serves both
+// recurrences of a DPRNN block (reference onnx_model/layers.py:159-196):
+//   * intra-band bi-GRU: rows = frames (clip,t), steps = frequency positions, h0 = 0, 2 directions;
+//   * inter-band GRUCell: rows = (clip, band position), steps = frames, h carried in the state.
+// A 256-thread workgroup (4 waves) owns 16 rows; wave w owns hidden units [16w,16w+16) of all
+// three gates.  Both W_ih and W_hh slices (96 VGPRs of MFMA B fragments) stay in registers for the
+// whole scan; per step the wave issues 96 v_mfma_f32_16x16x4_f32 (x-part + h-part), does the
+// gate math lane-locally in the MFMA C layout, and exchanges its 16x16 slice of h' with the
+// other three waves through a double-buffered 4 KB LDS tile (one barrier per step).  Nothing
+// but x (read once) and h' (written once) touches HBM: the [rows,192] gate pre-activations of
+// the reference's formulation never exist.
+//
+// gru256_scan_kernel: the five 256-wide GRU cells (emb/erb-decoder/df-decoder stacks,
+// reference onnx_model/layers.py:1168-1188, 1235-1259).  Input projections W_ih x (+biases) are
+// hoisted out of the recurrence into one big MFMA GEMM over all frames; the scan only carries
+// h W_hh^T.  16 rows per workgroup, 16 waves (one per 16 hidden units), W_hh fragments streamed
+// from L2 each step, h exchanged through LDS.
+#pragma once
+#include "common.h"
+
+struct Gru64Args {
+    const float* x;        // inputs, channels-last rows of 64
+    float* out;            // h' for every step
+    const float* wfrag;    // [dir][wave][part ih/hh][gate r,z,n][chunk][kb][lane]
+    const float* bias;     // [dir][4][64]: b_ir+b_hr | b_iz+b_hz | b_in | b_hn
+    float* hstate;         // optional carried state (h0 in, final h out), else h0 = 0
+    int nrows, nsteps, ndirs;
+    int rdiv;              // row r -> hi = r / rdiv, lo = r % rdiv
+    long x_hi, x_lo, x_step;
+    long o_hi, o_lo, o_step;
+    int o_dir_off;         // column offset of direction d in the output row (d * 64)
+    long h_hi, h_lo;
+};
+
+__global__ __launch_bounds__(256, 2) void gru64_scan_kernel(Gru64Args a) {
+    __shared__ __attribute__((aligned(16))) float Hs[2][16][68];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dir = blockIdx.y;
+    const int row0 = blockIdx.x * 16;
+    const int cl = lane & 15, q = lane >> 4;
+
+    // --- weights: registers for the whole scan --------------------------------------------
+    float wih[3][16], whh[3][16];
+    {
+        const float* wp = a.wfrag + ((size_t)(dir * 4 + w) * 2) * 3 * 16 * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                wih[g][j] = wp[(size_t)((0 * 3 + g) * 16 + j) * 64];
+                whh[g][j] = wp[(size_t)((1 * 3 + g) * 16 + j) * 64];
+            }
+    }
+    const float* bp = a.bias + (size_t)dir * 256 + 16 * w + cl;
+    const float b_r = bp[0], b_z = bp[64], b_in = bp[128], b_hn = bp[192];
+
+    // --- row addressing ----------------------------------------------------------------------
+    // A-operand view: this lane feeds row (row0 + cl); C view: rows row0 + q*4 + i
+    int ra = row0 + cl; if (ra >= a.nrows) ra = a.nrows - 1;
+    const long xa_base = (long)(ra / a.rdiv) * a.x_hi + (long)(ra % a.rdiv) * a.x_lo + 4 * q;
+    long oc_base[4]; bool oc_ok[4];
+    float h_own[4];
+    float4 ha[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int rc = row0 + q * 4 + i;
+        oc_ok[i] = rc < a.nrows;
+        if (rc >= a.nrows) rc = a.nrows - 1;
+        oc_base[i] = (long)(rc / a.rdiv) * a.o_hi + (long)(rc % a.rdiv) * a.o_lo + dir * a.o_dir_off + 16 * w + cl;
+        h_own[i] = a.hstate ? a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] : 0.f;
+    }
+    if (a.hstate) {
+        const float* hp = a.hstate + (long)(ra / a.rdiv) * a.h_hi + (long)(ra % a.rdiv) * a.h_lo + 4 * q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ha[c] = *(const float4*)(hp + 16 * c);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ha[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    float4 xa[4];
+    {
+        const int p0 = dir ? a.nsteps - 1 : 0;
+        const float* xp = a.x + xa_base + (long)p0 * a.x_step;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xa[c] = *(const float4*)(xp + 16 * c);
+    }
+    int buf = 0;
+    for (int s = 0; s < a.nsteps; ++s) {
+        const int pos = dir ? a.nsteps - 1 - s : s;
+        // prefetch next step's x fragments
+        float4 xn[4];
+        {
+            int sn = s + 1 < a.nsteps ? s + 1 : s;
+            const int pn = dir ? a.nsteps - 1 - sn : sn;
+            const float* xp = a.x + xa_base + (long)pn * a.x_step;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xn[c] = *(const float4*)(xp + 16 * c);
+        }
+        f32x4 ar = {b_r, b_r, b_r, b_r}, az = {b_z, b_z, b_z, b_z};
+        f32x4 axn = {b_in, b_in, b_in, b_in}, ahn = {b_hn, b_hn, b_hn, b_hn};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float xv[4] = {xa[c].x, xa[c].y, xa[c].z, xa[c].w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                ar = mfma16(xv[kb], wih[0][c * 4 + kb], ar);
+                az = mfma16(xv[kb], wih[1][c * 4 + kb], az);
+                axn = mfma16(xv[kb], wih[2][c * 4 + kb], axn);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float hv[4] = {ha[c].x, ha[c].y, ha[c].z, ha[c].w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                ar = mfma16(hv[kb], whh[0][c * 4 + kb], ar);
+                az = mfma16(hv[kb], whh[1][c * 4 + kb], az);
+                ahn = mfma16(hv[kb], whh[2][c * 4 + kb], ahn);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r = sigmoid_f(ar[i]);
+            float z = sigmoid_f(az[i]);
+            float n = tanh_f(axn[i] + r * ahn[i]);
+            float h = (1.0f - z) * n + z * h_own[i];
+            h_own[i] = h;
+            Hs[buf][q * 4 + i][16 * w + cl] = h;
+            if (oc_ok[i]) a.out[oc_base[i] + (long)pos * a.o_step] = h;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ha[c] = *(const float4*)&Hs[buf][cl][16 * c + 4 * q];
+        buf ^= 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xa[c] = xn[c];
+    }
+    if (a.hstate) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int rc = row0 + q * 4 + i;
+            if (rc < a.nrows)
+                a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] = h_own[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct Gru256Args {
+    const float* gi;       // [B*Tc][768]: W_ih x + (b_ir+b_hr | b_iz+b_hz | b_in)
+    float* out;            // [B*Tc][256]
+    const float* whh_frag; // [wave 16][gate 3][chunk 16][kb 4][lane 64]
+    const float* b_hn;     // [256]
+    float* hstate;         // h[b*h_stride + j] (flat reference state), in/out
+    long h_stride;
+    int B, Tc;
+};
+
+__global__ __launch_bounds__(1024) void gru256_scan_kernel(Gru256Args a) {
+    __shared__ __attribute__((aligned(16))) float Hs[2][16][260];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int cl = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const float* wf = a.whh_frag + (size_t)w * 3 * 64 * 64 + lane;
+    const float bhn = a.b_hn[16 * w + cl];
+
+    int rc[4]; bool ok[4]; float h_own[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = row0 + q * 4 + i;
+        ok[i] = r < a.B;
+        rc[i] = ok[i] ? r : a.B - 1;
+        h_own[i] = a.hstate[(long)rc[i] * a.h_stride + 16 * w + cl];
+        Hs[0][q * 4 + i][16 * w + cl] = h_own[i];
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int t = 0; t < a.Tc; ++t) {
+        f32x4 ar, az, axn, ahn = {bhn, bhn, bhn, bhn};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* g = a.gi + ((size_t)rc[i] * a.Tc + t) * 768 + 16 * w + cl;
+            ar[i] = g[0]; az[i] = g[256]; axn[i] = g[512];
+        }
+        const float* hrow = &Hs[buf][cl][4 * q];
+#pragma unroll 4
+        for (int c = 0; c < 16; ++c) {
+            float4 h4 = *(const float4*)(hrow + 16 * c);
+            const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                ar = mfma16(hv[kb], wf[(size_t)((0 * 16 + c) * 4 + kb) * 64], ar);
+                az = mfma16(hv[kb], wf[(size_t)((1 * 16 + c) * 4 + kb) * 64], az);
+                ahn = mfma16(hv[kb], wf[(size_t)((2 * 16 + c) * 4 + kb) * 64], ahn);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r = sigmoid_f(ar[i]);
+            float z = sigmoid_f(az[i]);
+            float n = tanh_f(axn[i] + r * ahn[i]);
+            float h = (1.0f - z) * n + z * h_own[i];
+            h_own[i] = h;
+            Hs[buf ^ 1][q * 4 + i][16 * w + cl] = h;
+            if (ok[i]) a.out[((size_t)rc[i] * a.Tc + t) * 256 + 16 * w + cl] = h;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ok[i]) a.hstate[(long)rc[i] * a.h_stride + 16 * w + cl] = h_own[i];
+}

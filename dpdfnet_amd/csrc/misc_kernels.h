@@ -1,0 +1,383 @@
+// misc_kernels.h -- the HBM-bound, non-GEMM stages of the frame function and the I/O glue:
+// feature extraction + EMA norms, erb_conv0, mask-decoder tail, mask / deep-filter apply,
+// overlap-add, and the import/export between the reference's flat state vector and the
+// time-halo form the batched kernels use.
+#pragma once
+#include "common.h"
+#include "gemm_rows.h"
+
+// ---------------------------------------------------------------------------------------------
+// features A (parallel over frames): raw spec -> scaled spec (x wnorm), ERB log-power (16 kHz) or
+// per-bin log-magnitude (48 kHz).  Reference onnx_model/dpdfnet.py:831-834 (16k),
+// onnx_model/dpdfnet_48khz_hr.py:903-906 (48k), export wrapper export_dpdfnet_to_onnx.py:22.
+// One workgroup per frame.
+struct FeatAArgs {
+    const float* raw;      // [B][Tc][F][2] unnormalised (chunk view: frame stride given)
+    size_t raw_clip_stride;  // floats between clips in raw
+    float* xs;             // [B][2+Tc][F][2] scaled spec (halo 2)
+    float* feat_erb;       // [B][2+Tc][E]  (dB values here; normalised in place by features B)
+    const int* band_start; // [33] (16k) band edges, or null for 48k
+    int B, Tc, F, E, is48; float wnorm;
+};
+__global__ __launch_bounds__(256) void feat_a_kernel(FeatAArgs a) {
+    __shared__ float pw[512];
+    const int bt = blockIdx.x;
+    const int b = bt / a.Tc, t = bt - b * a.Tc;
+    const float* src = a.raw + (size_t)b * a.raw_clip_stride + (size_t)t * a.F * 2;
+    float* xd = a.xs + ((size_t)b * (a.Tc + 2) + 2 + t) * a.F * 2;
+    float* fe = a.feat_erb + ((size_t)b * (a.Tc + 2) + 2 + t) * a.E;
+    for (int f = threadIdx.x; f < a.F; f += 256) {
+        float2 v = *(const float2*)(src + 2 * f);
+        v.x *= a.wnorm; v.y *= a.wnorm;
+        *(float2*)(xd + 2 * f) = v;
+        float p = v.x * v.x + v.y * v.y;
+        if (a.is48) fe[f] = 10.0f * log10f(sqrtf(p) + 1e-10f);
+        else pw[f] = p;
+    }
+    if (!a.is48) {
+        __syncthreads();
+        const int e = threadIdx.x;
+        if (e < a.E) {
+            const int s = a.band_start[e], n = a.band_start[e + 1] - s;
+            const float inv = 1.0f / (float)n;
+            float acc = 0.f;
+            for (int j = 0; j < n; ++j) acc += pw[s + j] * inv;
+            fe[e] = 10.0f * log10f(acc + 1e-10f);
+        }
+    }
+}
+
+// features B (scan over frames): exponential mean normalisation of the ERB / magnitude features
+// and unit-normalisation of the complex DF bins.  Reference onnx_model/layers.py:498-506
+// (ErbNorm), 637-661 (MagNorm48, fixed sigma 40), 561-572 (SpecNorm/SpecNorm48).
+// Thread (b, j): j < E -> erb band j; E <= j < E + D -> DF bin j - E.  State read/written in the
+// reference flat state vector.
+struct FeatBArgs {
+    float* feat_erb;       // [B][2+Tc][E] in place
+    const float* xs;       // [B][2+Tc][F][2]
+    float* feat_spec;      // [B][2+Tc][2][D]
+    float* state; long S; int off_erb, off_spec;
+    int B, Tc, F, E, D;
+};
+__global__ void feat_b_kernel(FeatBArgs a) {
+    const int b = blockIdx.x;
+    const int j = threadIdx.x;
+    const float al = 0.98f, be = (float)(1.0 - 0.98);
+    const int Tt = a.Tc + 2;
+    if (j < a.E) {
+        float mu = a.state[b * a.S + a.off_erb + j];
+        float* p = a.feat_erb + ((size_t)b * Tt + 2) * a.E + j;
+#pragma unroll 4
+        for (int t = 0; t < a.Tc; ++t) {
+            float x = p[(size_t)t * a.E];
+            mu = al * mu + be * x;
+            p[(size_t)t * a.E] = (x - mu) / 40.0f;
+        }
+        a.state[b * a.S + a.off_erb + j] = mu;
+    } else if (j < a.E + a.D) {
+        const int f = j - a.E;
+        float s = a.state[b * a.S + a.off_spec + f];
+        const float* xp = a.xs + ((size_t)b * Tt + 2) * a.F * 2 + 2 * f;
+        float* o = a.feat_spec + ((size_t)b * Tt + 2) * 2 * a.D + f;
+#pragma unroll 4
+        for (int t = 0; t < a.Tc; ++t) {
+            float2 v = *(const float2*)(xp + (size_t)t * a.F * 2);
+            float mag = sqrtf(v.x * v.x + v.y * v.y);
+            s = al * s + be * mag;
+            float den = sqrtf(s + 1e-12f);
+            o[(size_t)t * 2 * a.D] = v.x / den;
+            o[(size_t)t * 2 * a.D + a.D] = v.y / den;
+        }
+        a.state[b * a.S + a.off_spec + f] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// erb_conv0: dense Conv2d 1->64 k(3,3) over (3 frames, bands) + folded BN + ReLU
+// (reference onnx_model/dpdfnet.py:74-81, 206-211; 48 kHz runs on bins [0,480) hr.py:263).
+struct Conv0ErbArgs {
+    const float* feat;     // [B][2+Tc][E]
+    float* e0;             // [B][Tc][Ec][64]
+    const float* w;        // [64][9] (BN folded)
+    const float* bias;     // [64]
+    int B, Tc, E, Ec;
+};
+__global__ __launch_bounds__(256) void conv0_erb_kernel(Conv0ErbArgs a) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // (row, c4)
+    const size_t total = (size_t)a.B * a.Tc * a.Ec * 16;
+    if (idx >= total) return;
+    const int c4 = (int)(idx & 15) * 4;
+    const size_t row = idx >> 4;
+    const int f = (int)(row % a.Ec);
+    const size_t bt = row / a.Ec;
+    const int b = (int)(bt / a.Tc), t = (int)(bt - (size_t)b * a.Tc);
+    float4 acc = *(const float4*)(a.bias + c4);
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+        const float* src = a.feat + ((size_t)b * (a.Tc + 2) + t + kt) * a.E;
+#pragma unroll
+        for (int kf = 0; kf < 3; ++kf) {
+            int fi = f + kf - 1;
+            if (fi >= 0 && fi < a.Ec) {
+                float x = src[fi];
+                int k = kt * 3 + kf;
+                acc.x += a.w[(c4 + 0) * 9 + k] * x; acc.y += a.w[(c4 + 1) * 9 + k] * x;
+                acc.z += a.w[(c4 + 2) * 9 + k] * x; acc.w += a.w[(c4 + 3) * 9 + k] * x;
+            }
+        }
+    }
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    *(float4*)(a.e0 + row * 64 + c4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mask-decoder tail: u = relu(ps*e0 + pb) + d1 ; m = sigmoid(bias + sum_{c,k} w[c][k] u[f+k-1][c])
+// (conv0p pathway + conv0_out dense 64->1 k(1,3) + BN + Sigmoid, reference
+// onnx_model/dpdfnet.py:320-323, 364).  One wavefront per output band, lane = channel.
+struct MaskOutArgs {
+    const float* e0; const float* d1;  // [B][Tc][Ec][64]
+    float* m;                          // [B][Tc][Em]
+    const float* ps; const float* pb;  // [64]
+    const float* w;                    // [64][3] (BN folded)
+    float bias;
+    int rows;                          // B*Tc*Ec
+    int Ec, Em, is48;
+};
+__global__ __launch_bounds__(256) void mask_out_kernel(MaskOutArgs a) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (size_t)a.rows) return;
+    const int f = (int)(row % a.Ec);
+    const size_t bt = row / a.Ec;
+    const float ps = a.ps[lane], pb = a.pb[lane];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int fi = f + k - 1;
+        if (fi >= 0 && fi < a.Ec) {
+            size_t o = (bt * a.Ec + fi) * 64 + lane;
+            float u = fmaxf(ps * a.e0[o] + pb, 0.f) + a.d1[o];
+            acc += a.w[lane * 3 + k] * u;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) {
+        float mv = sigmoid_f(acc + a.bias);
+        a.m[bt * a.Em + f] = mv;
+        if (a.is48 && f == a.Ec - 2) a.m[bt * a.Em + a.Ec] = mv;   // F.pad reflect (0,1): m[480] = m[478]
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mask.forward / MagnitudeMask.forward: masked spec of the frame from two steps ago
+// (reference onnx_model/layers.py:414-445, dpdfnet_48khz_hr.py:55-69).
+struct MaskApplyArgs {
+    const float* xs;       // [B][2+Tc][F][2]
+    const float* m;        // [B][Tc][Em]
+    float* xm;             // [B][4+Tc][F][2]
+    const int* band_of;    // [F] (16k) or null
+    int B, Tc, F, Em;
+};
+__global__ void mask_apply_kernel(MaskApplyArgs a) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)a.B * a.Tc * a.F;
+    if (idx >= total) return;
+    const int f = (int)(idx % a.F);
+    const size_t bt = idx / a.F;
+    const int b = (int)(bt / a.Tc), t = (int)(bt - (size_t)b * a.Tc);
+    float g = a.m[bt * a.Em + (a.band_of ? a.band_of[f] : f)];
+    float2 v = *(const float2*)(a.xs + (((size_t)b * (a.Tc + 2) + t) * a.F + f) * 2);   // frame t-2 (+halo 2)
+    v.x *= g; v.y *= g;
+    *(float2*)(a.xm + (((size_t)b * (a.Tc + 4) + 4 + t) * a.F + f) * 2) = v;
+}
+
+// DF.forward + df_real (reference onnx_model/multiframe.py:200-232, 140-154), x 1/wnorm
+// (export wrapper) and, for the offline path, apply_attn_limit (package/src/dpdfnet/audio.py:41-76).
+struct DfApplyArgs {
+    const float* xm;       // [B][4+Tc][F][2]
+    const float* coefs;    // [B][2+Tc][D][10]
+    float* out;            // [B][out_T][F][2] written at frame out_t0 + t
+    size_t out_clip_stride; int out_t0;
+    const float* raw;      // attn-limit noisy reference (same geometry as out) or null
+    float alpha, beta;
+    int B, Tc, F, D; float inv_wnorm;
+};
+__global__ void df_apply_kernel(DfApplyArgs a) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)a.B * a.Tc * a.F;
+    if (idx >= total) return;
+    const int f = (int)(idx % a.F);
+    const size_t bt = idx / a.F;
+    const int b = (int)(bt / a.Tc), t = (int)(bt - (size_t)b * a.Tc);
+    const float* xb = a.xm + (((size_t)b * (a.Tc + 4) + t) * a.F + f) * 2;     // frame t-4
+    const size_t fs = (size_t)a.F * 2;
+    float re, im;
+    if (f < a.D) {
+        const float* c = a.coefs + (((size_t)b * (a.Tc + 2) + t) * a.D + f) * 10;   // frame t-2 (+halo 2)
+        float rr = 0.f, ii = 0.f, ri = 0.f, ir = 0.f;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            float2 s = *(const float2*)(xb + n * fs);
+            float cr = c[2 * n], ci = c[2 * n + 1];
+            rr += s.x * cr; ii += s.y * ci; ri += s.x * ci; ir += s.y * cr;
+        }
+        re = rr - ii; im = ri + ir;
+    } else {
+        float2 s = *(const float2*)(xb + 2 * fs);
+        re = s.x; im = s.y;
+    }
+    re *= a.inv_wnorm; im *= a.inv_wnorm;
+    const int tg = a.out_t0 + t;
+    float* o = a.out + (size_t)b * a.out_clip_stride + ((size_t)tg * a.F + f) * 2;
+    if (a.raw) {
+        float nr = 0.f, ni = 0.f;
+        if (tg >= 4) {
+            const float* r = a.raw + (size_t)b * a.out_clip_stride + ((size_t)(tg - 4) * a.F + f) * 2;
+            nr = r[0]; ni = r[1];
+        }
+        re = a.alpha * nr + a.beta * re;
+        im = a.alpha * ni + a.beta * im;
+    }
+    o[0] = re; o[1] = im;
+}
+
+// ---------------------------------------------------------------------------------------------
+// overlap-add + window-sum-square normalisation + centre trim + 2*win alignment shift + fit to N
+// (reference package/src/dpdfnet/audio.py:120-136, 30-38)
+struct OlaArgs {
+    const float* frames;   // [B][T][win] windowed synthesis frames
+    const float* window;
+    float* out;            // [B][N]
+    int B, T, N, win, hop;
+};
+__global__ void ola_kernel(OlaArgs a) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)a.B * a.N) return;
+    const int b = (int)(idx / a.N), i = (int)(idx - (size_t)b * a.N);
+    const long ylen = (long)a.hop * (a.T - 1);
+    const long src = (long)i + 2L * a.win;
+    float v = 0.f;
+    if (src < ylen) {
+        const long p = src + a.win / 2;
+        const int t1 = (int)(p / a.hop);
+        const int t0 = t1 - 1;
+        float y = 0.f, wss = 0.f;
+        if (t0 >= 0) {
+            int k = (int)(p - (long)t0 * a.hop);
+            if (k < a.win) { y += a.frames[((size_t)b * a.T + t0) * a.win + k]; wss += a.window[k] * a.window[k]; }
+        }
+        if (t1 < a.T) {
+            int k = (int)(p - (long)t1 * a.hop);
+            y += a.frames[((size_t)b * a.T + t1) * a.win + k]; wss += a.window[k] * a.window[k];
+        }
+        v = wss > 1.17549435e-38f ? y / wss : y;
+    }
+    a.out[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat reference state <-> time-halo tensors (CyclicBuffer semantics, reference
+// onnx_model/layers.py:68-107: each FIFO holds the last `cap` frames, oldest first).
+// import: halo frame (-cap+1+j) <- buf[1+j];  export: buf[j] <- frame (Tc-cap+j).
+struct StateIoArgs {
+    float* state; long S;
+    float* feat_erb; float* feat_spec; float* c0; float* xs; float* coefs; float* xm;
+    int off_erb_buf, off_df_buf, off_convp, off_mask, off_coefs, off_spec;
+    int B, Tc, E, D, F;
+    int do_export;
+};
+__device__ __forceinline__ void fifo_io(float* st, float* tensor_frame0 /* frame t=0 of clip */, long frame_sz,
+                                        int cap, int Tc, int do_export, int tid, int nthreads) {
+    // plain layout: state frame j <-> tensor frame (export: Tc-cap+j, import: j-cap, j>=1)
+    for (int j = do_export ? 0 : 1; j < cap; ++j) {
+        long tf = do_export ? (long)Tc - cap + j : (long)j - cap;
+        float* tp = tensor_frame0 + tf * frame_sz;
+        float* sp = st + (long)j * frame_sz;
+        for (long i = tid; i < frame_sz; i += nthreads) {
+            if (do_export) sp[i] = tp[i]; else tp[i] = sp[i];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
+    const int b = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
+    float* st = a.state + (long)b * a.S;
+    const int Tc = a.Tc;
+    if (seg == 0) {
+        fifo_io(st + a.off_erb_buf, a.feat_erb + ((size_t)b * (Tc + 2) + 2) * a.E, a.E, 3, Tc, a.do_export, tid, 256);
+    } else if (seg == 1) {
+        fifo_io(st + a.off_df_buf, a.feat_spec + ((size_t)b * (Tc + 2) + 2) * 2 * a.D, 2 * a.D, 3, Tc, a.do_export, tid, 256);
+    } else if (seg == 2) {
+        fifo_io(st + a.off_mask, a.xs + ((size_t)b * (Tc + 2) + 2) * a.F * 2, a.F * 2, 3, Tc, a.do_export, tid, 256);
+    } else if (seg == 3) {
+        fifo_io(st + a.off_spec, a.xm + ((size_t)b * (Tc + 4) + 4) * a.F * 2, a.F * 2, 5, Tc, a.do_export, tid, 256);
+    } else if (seg == 4) {
+        // df_convp_buf [5][64][D] (channel-first) <-> c0 [B][4+Tc][D][64]
+        const long fsz = 64L * a.D;
+        float* t0 = a.c0 + ((size_t)b * (Tc + 4) + 4) * fsz;
+        for (int j = a.do_export ? 0 : 1; j < 5; ++j) {
+            long tf = a.do_export ? (long)Tc - 5 + j : (long)j - 5;
+            float* tp = t0 + tf * fsz;
+            float* sp = st + a.off_convp + (long)j * fsz;
+            for (long i = tid; i < fsz; i += 256) {
+                int c = (int)(i / a.D), f = (int)(i - (long)c * a.D);       // state index = c*D + f
+                if (a.do_export) sp[i] = tp[(long)f * 64 + c]; else tp[(long)f * 64 + c] = sp[i];
+            }
+        }
+    } else if (seg == 5) {
+        // coefs_buf [3][5][D][2] <-> coefs [B][2+Tc][D][10]
+        const long fsz = 10L * a.D;
+        float* t0 = a.coefs + ((size_t)b * (Tc + 2) + 2) * fsz;
+        for (int j = a.do_export ? 0 : 1; j < 3; ++j) {
+            long tf = a.do_export ? (long)Tc - 3 + j : (long)j - 3;
+            float* tp = t0 + tf * fsz;
+            float* sp = st + a.off_coefs + (long)j * fsz;
+            for (long i = tid; i < fsz; i += 256) {
+                int n = (int)(i / (2 * a.D)); int rem = (int)(i - (long)n * 2 * a.D);
+                int f = rem >> 1, p = rem & 1;                               // state index = (n*D + f)*2 + p
+                if (a.do_export) sp[i] = tp[(long)f * 10 + 2 * n + p]; else tp[(long)f * 10 + 2 * n + p] = sp[i];
+            }
+        }
+    }
+}
+
+__global__ void fill_state_kernel(float* state, const float* init, long S, int B) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)S * B) return;
+    state[idx] = init[idx % S];
+}
+
+// y += x (n multiple of 4)
+__global__ void axpy_kernel(float* y, const float* x, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 a = *(float4*)(y + i), b = *(const float4*)(x + i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    *(float4*)(y + i) = a;
+}
+
+// streaming glue (reference package/src/dpdfnet/stream.py:116-156): causal analysis buffer and
+// overlap-add with carried tails, hop = win/2.
+//   xbuf[s] = in_tail[s] (hop samples) ++ pcm_in[s] (n_hops*hop samples); new in_tail = last hop samples
+__global__ void stream_stage_in_kernel(const float* pcm_in, float* in_tail, float* xbuf, int S, int n_hops, int hop) {
+    const int s = blockIdx.x;
+    const int n = n_hops * hop;
+    float* xb = xbuf + (size_t)s * (n + hop);
+    for (int i = threadIdx.x; i < hop; i += blockDim.x) xb[i] = in_tail[(size_t)s * hop + i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) xb[hop + i] = pcm_in[(size_t)s * n + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < hop; i += blockDim.x) in_tail[(size_t)s * hop + i] = xb[n + i];
+}
+//   out hop j = (j ? frames[j-1][hop:] : ola_tail) + frames[j][:hop];  new ola_tail = frames[T-1][hop:]
+__global__ void stream_ola_kernel(const float* frames, float* ola_tail, float* pcm_out, int S, int n_hops, int hop) {
+    const int s = blockIdx.x;
+    const int win = 2 * hop;
+    const float* fr = frames + (size_t)s * n_hops * win;
+    for (int idx = threadIdx.x; idx < n_hops * hop; idx += blockDim.x) {
+        int j = idx / hop, i = idx - j * hop;
+        float prev = j ? fr[(size_t)(j - 1) * win + hop + i] : ola_tail[(size_t)s * hop + i];
+        pcm_out[(size_t)s * n_hops * hop + idx] = prev + fr[(size_t)j * win + i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hop; i += blockDim.x) ola_tail[(size_t)s * hop + i] = fr[(size_t)(n_hops - 1) * win + hop + i];
+}

@@ -1,0 +1,110 @@
+/*
+ * dpdfnet_hip.h -- C ABI of the MI355X-native DPDFNet enhancement engine (libdpdfnet_hip.so).
+ *
+ * The reference has no C ABI: its runtime seam is the Python `RuntimeModel` around an
+ * onnxruntime CPU session (reference package/src/dpdfnet/onnx_backend.py:11-18, 81-99), called
+ * once per 10 ms frame from `enhance()` (package/src/dpdfnet/api.py:96-104) and
+ * `StreamEnhancer.process()` (package/src/dpdfnet/stream.py:129-135).  This header is what a
+ * binding for that seam binds instead (ctypes stub: INTEGRATION.md).  Plain pointers and
+ * sizes only; every entry point returns 0 on success or a negative DPDF_E_* code, with a
+ * thread-local message available from dpdf_last_error().
+ *
+ * Threading: a dpdf_model is immutable after creation; calls that run work take the model's
+ * internal lock (one HIP stream + one workspace per model).  Use one model per host thread for
+ * concurrency (the reference uses one ORT session per thread, cli.py:251-259).
+ */
+#ifndef DPDFNET_HIP_H
+#define DPDFNET_HIP_H
+
+#include <stddef.h>
+#include "dpdf_manifest.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPDF_OK 0
+#define DPDF_E_INVALID (-1)   /* bad argument / size mismatch       -> ValueError   */
+#define DPDF_E_RUNTIME (-2)   /* HIP runtime / no device / OOM      -> RuntimeError */
+#define DPDF_E_STATE   (-3)   /* stream index / state misuse        -> ValueError   */
+
+/* flags for the pointer-taking entry points */
+#define DPDF_HOST_PTRS   0    /* wav/spec/state/out are host pointers (copied over PCIe)  */
+#define DPDF_DEVICE_PTRS 1    /* ... are device pointers on the model's GPU (HBM-resident) */
+
+typedef struct dpdf_model dpdf_model;
+typedef struct dpdf_streams dpdf_streams;
+
+int dpdf_abi_version(void);
+const char* dpdf_last_error(void);
+int dpdf_device_count(void);
+
+/* weight-blob layout queries (no GPU needed).  dpdf_manifest_text writes one
+ * "name offset count d0,d1,.." line per tensor; returns the byte count needed (excl. NUL). */
+size_t dpdf_weight_count(const dpdf_cfg* cfg);
+size_t dpdf_manifest_text(const dpdf_cfg* cfg, char* buf, size_t cap);
+int dpdf_query_dims(const dpdf_cfg* cfg, dpdf_dims* out);
+
+/* Replaces build_runtime_model(onnx_path) (onnx_backend.py:81-99): builds the frame-function
+ * handle on GPU `device` from the flat fp32 checkpoint blob (layout: dpdf_manifest.h).
+ * BatchNorm folding and MFMA-fragment packing of every matrix happen here, once. */
+int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_floats, int device, dpdf_model** out);
+void dpdf_destroy(dpdf_model* m);
+
+/* Replaces load_initial_state_from_metadata (onnx_backend.py:52-78).  The two norm init
+ * vectors default to the reference's linspace initialisation; a weight file may carry the
+ * exported `erb_norm_init` / `spec_norm_init` metadata instead (48 kHz empirical tables). */
+int dpdf_set_norm_init(dpdf_model* m, const float* erb_norm_init, int n_erb, const float* spec_norm_init, int n_spec);
+int dpdf_state_size(const dpdf_model* m);                  /* S of the reference flat state */
+int dpdf_initial_state(const dpdf_model* m, float* state); /* host pointer, S floats         */
+int dpdf_win_len(const dpdf_model* m);                     /* infer_win_len (onnx_backend.py:102-107) */
+int dpdf_hop(const dpdf_model* m);
+int dpdf_freq_bins(const dpdf_model* m);
+int dpdf_sample_rate(const dpdf_model* m);
+
+/* Replaces the per-frame session.run loop (api.py:96-104 / stream.py:129-135), for B independent
+ * streams and T consecutive frames in ONE call:
+ *   spec   [B,T,F,2]  unnormalised STFT frames (what the reference feeds as "spec")
+ *   state  [B,S]      reference flat state vectors, updated IN PLACE (state_in -> state_out)
+ *   spec_e [B,T,F,2]  enhanced frames (what session.run returns as "spec_e")
+ * T = 1 is exactly one session.run per stream. */
+int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, float* state, float* spec_e, int flags);
+
+/* Replaces enhance() (api.py:51-113) from the padded-waveform stage on, for a batch of B mono
+ * clips of N samples each at the model sample rate: tail pad, centre/reflect STFT, T frames of
+ * the frame function from the initial state, attenuation limit, iSTFT, 2*win alignment shift,
+ * fit to N.  wav/out: [B,N].  attn_limit_db: NaN or +inf = off (reference None/inf). */
+int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N, float attn_limit_db, float* out, int flags);
+int dpdf_num_frames(const dpdf_model* m, int n_samples);   /* T = 1 + (N + win)/hop */
+
+/* Device-resident streaming (StreamEnhancer.process hot loop, stream.py:116-156, for S
+ * concurrent streams): state, analysis tail and overlap-add tail live in HBM.
+ *   pcm_in  [S, n_hops*hop]  new samples per stream (host or device per flags)
+ *   pcm_out [S, n_hops*hop]  committed output hops
+ * The very first call of a stream needs win samples before the first frame: call with the
+ * stream's first hop through dpdf_streams_prime (buffers it, emits nothing). */
+int dpdf_streams_create(dpdf_model* m, int n_streams, dpdf_streams** out);
+void dpdf_streams_destroy(dpdf_streams* s);
+int dpdf_streams_reset(dpdf_streams* s, int stream /* -1 = all */);
+int dpdf_streams_prime(dpdf_streams* s, const float* pcm_in, int flags);            /* [S,hop] */
+int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, int flags);
+int dpdf_streams_get_state(dpdf_streams* s, int stream, float* state_host);          /* S floats */
+
+/* timing hooks for bench.py: HIP events on the model's own stream. */
+int dpdf_sync(dpdf_model* m);
+/* Enable per-kernel-class timing (HIP events around each launch class on the model stream);
+ * dpdf_profile_report writes "name total_ms calls" lines.  Off by default. */
+int dpdf_profile_enable(dpdf_model* m, int on);
+size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap);
+/* Set the time-chunk length used by dpdf_enhance_batch (frames per chunk; <=0 = whole clip). */
+int dpdf_set_chunk_frames(dpdf_model* m, int frames);
+
+/* Debug/test hook: copy an intermediate tensor of the last processed chunk to the host
+ * ("e0","e1","e2","e3","e3_dprnn","c0","c1","c1_dprnn","emb","m","coefs","xm","feat_erb",
+ * "feat_spec"; engine-native channels-last layouts).  Returns the element count, -1 if unknown. */
+long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, long cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPDFNET_HIP_H */
