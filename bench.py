@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the DPDFNet enhancement hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole offline hot path (`dpdf_enhance_batch`: centre/reflect STFT ->
+frame function over every frame -> attenuation-limit -> iSTFT/OLA/alignment) over one batch of
+synthetic clips per GPU, inputs and outputs resident in HBM.  Workload = BASELINE.json's metric
+configuration: dpdfnet4 @ 16 kHz, 256 clips x 10 s per GPU (configs[2] is 2048 clips over 8 GPUs
+= 256 per GPU, so per-GPU work is fixed: weak scaling).  One process per GPU; for N > 1 the driver
+launches this file under torch.distributed.run and the enhanced PCM of every rank is gathered to
+rank 0 over RCCL inside the timed region (the only collective on the path).
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, measured
+with HIP events on the engine's own stream during the timed steps) and `cpu_baseline` (the CPU
+oracle -- a port of the reference's frame-at-a-time execution model -- timed on the host cores on
+a bounded sample; the reference's own CPU runtime, onnxruntime + downloaded .onnx files, is not
+available offline).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+METRIC = "frames/s (10 ms hop) per MI355X, dpdfnet4@16 kHz; PESQ Δ vs ref ≤0.001"
+MODEL, SR, NB = "dpdfnet4", 16000, 4
+CLIP_SECONDS = 10.0
+WEIGHT_SEED = 20260417
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+GRU64_FLOP_PER_ROW_STEP = 2 * 3 * 64 * (64 + 64)   # r,z,n gates x 64 units x (W_ih x + W_hh h), MAC = 2 FLOP
+FLOP_PER_FRAME = 45.18e6               # algorithmic FLOP / frame, dpdfnet4
+
+
+def synth_clips(n_clips: int, n: int, sr: int, first_seed: int) -> np.ndarray:
+    """x = 0.05 N(0,1) + 0.1 sin(2 pi f0 t)(1 + sin(2 pi 3 t)), f0 ~ U[100,1000] Hz."""
+    t = np.arange(n, dtype=np.float32) / np.float32(sr)
+    out = np.empty((n_clips, n), dtype=np.float32)
+    for i in range(n_clips):
+        rng = np.random.default_rng(first_seed + i)
+        f0 = np.float32(rng.uniform(100.0, 1000.0))
+        x = 0.05 * rng.standard_normal(n, dtype=np.float32)
+        x += np.float32(0.1) * np.sin(np.float32(2 * np.pi) * f0 * t) * (1.0 + np.sin(np.float32(2 * np.pi * 3.0) * t))
+        out[i] = np.clip(x, -1.0, 1.0)
+    return out
+
+
+def cpu_baseline(blob: np.ndarray, seconds_per_clip: float, clips_per_thread: int) -> dict:
+    """Time the CPU oracle (oracle/dpdf_oracle.c) the way the reference runs: one clip per thread,
+    frame at a time, batch 1 (reference package/src/dpdfnet/cli.py:249-259)."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    n = int(seconds_per_clip * SR)
+    clips = synth_clips(cores * clips_per_thread, n, SR, 99000)
+    oracles = [orc.Oracle(SR, NB, blob) for _ in range(cores)]
+    frames = oracles[0].num_frames(n)
+
+    def work(i: int) -> None:
+        for j in range(clips_per_thread):
+            oracles[i].enhance(clips[i * clips_per_thread + j])
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt = time.perf_counter() - t0
+    total = cores * clips_per_thread * frames
+    return {
+        "value": total / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{cores * clips_per_thread} clips x {seconds_per_clip:g} s ({total} frames), one clip per thread, "
+                  f"oracle/dpdf_oracle.c fp32 frame-at-a-time; {dt:.1f} s wall",
+        "ms_per_frame_per_thread": 1e3 * dt / (clips_per_thread * frames),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("DPDF_CHUNK_FRAMES", "0")),
+                    help="time-chunk length in frames (0 = engine default)")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clip-seconds", type=float, default=5.0)
+    ap.add_argument("--cpu-clips-per-thread", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from dpdfnet_amd import backend
+    from dpdfnet_amd.weights import synth_blob
+    from dpdfnet_amd.multi_gpu import shard_range, gather_to_root
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    blob = synth_blob(backend.manifest(SR, NB), WEIGHT_SEED)
+    model = backend.HipModel(SR, NB, blob, device=local_rank)
+    if args.chunk:
+        model.set_chunk_frames(args.chunk)
+    B, N = args.clips, int(CLIP_SECONDS * SR)
+    T = model.num_frames(N)
+    lo, hi = shard_range(B * world, world, rank)          # contiguous block of clips per rank
+    wav_host = synth_clips(B, N, SR, WEIGHT_SEED + lo)
+    wav = torch.from_numpy(wav_host).cuda()
+    out = torch.empty_like(wav)
+    gathered = None
+    do_gather = world > 1 and not args.no_gather
+    gather_note = "none (single GPU)" if world == 1 else ("rccl gather to rank 0" if do_gather else "disabled")
+
+    def step() -> None:
+        model.enhance_batch_device(wav.data_ptr(), B, N, out.data_ptr(), None)
+
+    def sync() -> None:
+        model.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if do_gather:
+        try:
+            gathered = gather_to_root(out, world, rank)
+            torch.cuda.synchronize()
+        except Exception as exc:  # keep the compute number even if the collective is unavailable
+            do_gather = False
+            gather_note = f"failed, excluded: {type(exc).__name__}: {exc}"
+
+    model.profile(True)
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if do_gather:
+            model.sync()
+            gathered = gather_to_root(out, world, rank, gathered)
+    sync()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    prof = model.profile_report()
+    model.profile(False)
+
+    if rank == 0:
+        finite = bool(torch.isfinite(out).all().item())
+        total_frames = world * B * T * args.steps
+        value = total_frames / dt
+        # dominant kernel: gru64_scan_kernel, DF-branch intra-band bi-GRU launches
+        name = "gru64_intra_df"
+        ms, calls = prof.get(name, (0.0, 0))
+        launches_per_step = max(1, calls // max(1, args.steps))
+        flops_total = args.steps * NB * (B * T) * 48 * 2 * GRU64_FLOP_PER_ROW_STEP
+        achieved = flops_total / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        gru64_ms = sum(v[0] for k, v in prof.items() if k.startswith("gru64_"))
+        roofline = {
+            "bound": "mfma", "kernel": "gru64_scan_kernel (DF-branch intra-band bi-GRU launch)",
+            "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "avg_launch_ms": ms / calls if calls else None, "launches": calls,
+            "flop_per_launch": flops_total / calls if calls else None,
+            "whole_path_frac": value * FLOP_PER_FRAME / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
+            "per_class_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
+            "gru64_share_of_step": gru64_ms / (dt * 1e3) if dt > 0 else None,
+        }
+        line = {
+            "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{MODEL} @16 kHz, {B} clips x {CLIP_SECONDS:g} s per GPU (T={T} frames/clip), "
+                                   "seeded synthetic weights + clips, inputs/outputs resident in HBM",
+                       "clips_per_gpu": B, "frames_per_clip": T, "chunk_frames": args.chunk,
+                       "sharding": f"utterances, contiguous blocks per rank; collective: {gather_note}"},
+            "finite_output": finite,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(blob, args.cpu_clip_seconds, args.cpu_clips_per_thread)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    model.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,185 @@
+"""Public offline API (reference package/src/dpdfnet/api.py:16-280).
+
+`enhance()` keeps the reference signature and semantics; the per-frame `session.run` loop of the
+reference (api.py:96-104) is replaced by ONE call into the HIP engine (`dpdf_enhance_batch`) that
+runs STFT, all frames, attenuation limit and iSTFT on the GPU.  `enhance_batch()` is the
+extension that makes the GPU worthwhile: many clips per call."""
+from __future__ import annotations
+
+import wave
+from pathlib import Path
+from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from .models import DEFAULT_MODEL, available_model_entries, resolve_model
+from .runtime import build_runtime_model, infer_win_len
+
+ProgressCb = Optional[Callable[[int, int], None]]
+
+
+def available_models() -> List[Dict[str, Any]]:
+    return available_model_entries()
+
+
+def download(model: Optional[str] = None, *, force: bool = False, quiet: bool = False, verbose: bool = False):
+    """The reference downloads ONNX files from Hugging Face (api.py:22-48).  This build has no
+    network path: place weight files in DPDFNET_MODEL_DIR instead."""
+    if quiet and verbose:
+        raise ValueError("quiet=True and verbose=True are mutually exclusive.")
+    raise RuntimeError(
+        "download() is unavailable in the MI355X build (no network access): copy <model>.npz/.safetensors/.pth "
+        "into DPDFNET_MODEL_DIR or pass onnx_path=<weight file>."
+    )
+
+
+def _device_from_env() -> int:
+    import os
+    return int(os.environ.get("DPDFNET_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def enhance(
+    audio: np.ndarray,
+    sample_rate: int,
+    *,
+    model: str = DEFAULT_MODEL,
+    onnx_path: Optional[Union[str, Path]] = None,
+    attn_limit_db: Optional[float] = None,
+    verbose: bool = False,
+    progress_callback: ProgressCb = None,
+) -> np.ndarray:
+    """Enhance one clip; returns float32 mono of the input length (reference api.py:51-113).
+    `onnx_path` is the weight-file path (or "synthetic:<seed>")."""
+    from .audio import to_mono
+
+    waveform = to_mono(np.asarray(audio, dtype=np.float32))
+    resolved = resolve_model(model=model, onnx_path=onnx_path, auto_download=True, verbose=verbose)
+    runtime = build_runtime_model(resolved.onnx_path, resolved.info, _device_from_env())
+    return _enhance_with_runtime(waveform, sample_rate, runtime=runtime, model_sample_rate=resolved.info.sample_rate,
+                                 attn_limit_db=attn_limit_db, progress_callback=progress_callback)
+
+
+def _enhance_with_runtime(
+    audio: np.ndarray,
+    sample_rate: int,
+    *,
+    runtime,
+    model_sample_rate: int,
+    attn_limit_db: Optional[float] = None,
+    progress_callback: ProgressCb = None,
+) -> np.ndarray:
+    """Like `enhance()` with a pre-built runtime (reference api.py:116-169)."""
+    from .audio import ensure_sample_rate, fit_length, to_mono, validate_attn_limit_db
+
+    waveform = to_mono(np.asarray(audio, dtype=np.float32))
+    sr_in = int(sample_rate)
+    attn = validate_attn_limit_db(attn_limit_db)
+    wav_model = ensure_sample_rate(waveform, sr_in, model_sample_rate)
+    win_len = infer_win_len(runtime.session, model_sample_rate)
+    total_frames = 1 + (wav_model.shape[0] + win_len) // (win_len // 2)   # api.py:88 pad + centre STFT
+    if progress_callback is not None:
+        progress_callback(0, total_frames)
+    if wav_model.shape[0] == 0:
+        return waveform.copy()
+    enhanced_model_sr = runtime.session.enhance_batch(wav_model[None, :], attn)[0]
+    if progress_callback is not None:
+        # the GPU path has no per-frame host loop; keep the (done,total) protocol of api.py:94-104
+        for t in range(total_frames):
+            progress_callback(t + 1, total_frames)
+    enhanced = ensure_sample_rate(enhanced_model_sr, model_sample_rate, sr_in)
+    return fit_length(enhanced, waveform.shape[0]).astype(np.float32, copy=False)
+
+
+def enhance_batch(
+    audio: Union[np.ndarray, Sequence[np.ndarray]],
+    sample_rate: int,
+    *,
+    model: str = DEFAULT_MODEL,
+    onnx_path: Optional[Union[str, Path]] = None,
+    attn_limit_db: Optional[float] = None,
+    verbose: bool = False,
+) -> List[np.ndarray]:
+    """Enhance many mono clips in one GPU batch.  Clips may differ in length: they are grouped by
+    length (each clip's result equals `enhance()` on it alone; padding would change the reference's
+    tail handling, SURVEY appendix A.4, so equal-length groups are batched instead)."""
+    from .audio import ensure_sample_rate, fit_length, to_mono, validate_attn_limit_db
+
+    clips = [to_mono(np.asarray(a, dtype=np.float32)) for a in (audio if not isinstance(audio, np.ndarray) or audio.ndim != 2 else list(audio))]
+    attn = validate_attn_limit_db(attn_limit_db)
+    resolved = resolve_model(model=model, onnx_path=onnx_path, auto_download=True, verbose=verbose)
+    runtime = build_runtime_model(resolved.onnx_path, resolved.info, _device_from_env())
+    msr, sr_in = resolved.info.sample_rate, int(sample_rate)
+    model_clips = [ensure_sample_rate(c, sr_in, msr) for c in clips]
+    out: List[Optional[np.ndarray]] = [None] * len(clips)
+    by_len: Dict[int, List[int]] = {}
+    for i, c in enumerate(model_clips):
+        by_len.setdefault(int(c.shape[0]), []).append(i)
+    for n, idxs in by_len.items():
+        if n == 0:
+            for i in idxs:
+                out[i] = clips[i].copy()
+            continue
+        res = runtime.session.enhance_batch(np.stack([model_clips[i] for i in idxs]), attn)
+        for j, i in enumerate(idxs):
+            e = ensure_sample_rate(res[j], msr, sr_in)
+            out[i] = fit_length(e, clips[i].shape[0]).astype(np.float32, copy=False)
+    return out  # type: ignore[return-value]
+
+
+# ----------------------------------------------------------------------------------------------
+# file wrappers (reference api.py:172-280).  soundfile is optional; PCM16 WAV via the stdlib otherwise.
+# ----------------------------------------------------------------------------------------------
+def _read_audio(path: Path):
+    try:
+        import soundfile as sf  # type: ignore
+        audio, sr = sf.read(str(path), always_2d=False)
+        return np.asarray(audio, dtype=np.float32), int(sr)
+    except ImportError:
+        pass
+    if path.suffix.lower() != ".wav":
+        raise ValueError(f"Unsupported audio format {path.suffix!r} for file: {path} (only .wav without soundfile)")
+    with wave.open(str(path), "rb") as w:
+        sr, ch, sw, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if sw == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif sw == 4:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif sw == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError(f"Unsupported WAV sample width {sw} in {path}")
+    if ch > 1:
+        x = x.reshape(-1, ch)
+    return x, int(sr)
+
+
+def _write_pcm16(path: Path, audio: np.ndarray, sr: int) -> None:
+    from .audio import pcm16_safe
+    path.parent.mkdir(parents=True, exist_ok=True)
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(int(sr))
+        w.writeframes(pcm16_safe(audio).astype("<i2").tobytes())
+
+
+def enhance_file(
+    input_path: Union[str, Path],
+    output_path: Optional[Union[str, Path]] = None,
+    *,
+    model: str = DEFAULT_MODEL,
+    onnx_path: Optional[Union[str, Path]] = None,
+    attn_limit_db: Optional[float] = None,
+    verbose: bool = False,
+    progress_callback: ProgressCb = None,
+) -> Path:
+    in_path = Path(input_path).expanduser().resolve()
+    if not in_path.is_file():
+        raise FileNotFoundError(f"Input file not found: {in_path}")
+    audio, sr = _read_audio(in_path)
+    enhanced = enhance(audio=audio, sample_rate=int(sr), model=model, onnx_path=onnx_path,
+                       attn_limit_db=attn_limit_db, verbose=verbose, progress_callback=progress_callback)
+    out_path = in_path.with_name(f"{in_path.stem}_enhanced.wav") if output_path is None else Path(output_path).expanduser().resolve()
+    _write_pcm16(out_path, enhanced, int(sr))
+    return out_path

@@ -1,0 +1,105 @@
+"""Host-side audio helpers of the enhancement path (reference package/src/dpdfnet/audio.py).
+
+The STFT / iSTFT / attenuation-limit of the OFFLINE path run on the GPU inside
+`dpdf_enhance_batch`; what stays on the host is the cheap glue with reference-pinned semantics."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from fractions import Fraction
+from typing import Optional
+
+import numpy as np
+
+ATTN_LIMIT_NOISY_FRAME_OFFSET = 4   # reference audio.py:8 (2 frames feature look-ahead + 2 frames DF look-ahead)
+
+
+def to_mono(audio: np.ndarray) -> np.ndarray:
+    """[samples] or [samples, channels] -> float32 mono (reference audio.py:11-17)."""
+    x = np.asarray(audio, dtype=np.float32)
+    if x.ndim == 1:
+        return x
+    if x.ndim != 2:
+        raise ValueError(f"Expected mono/stereo audio, got shape {x.shape}")
+    return np.mean(x, axis=1, dtype=np.float32)
+
+
+def ensure_sample_rate(audio: np.ndarray, sample_rate: int, target_sample_rate: int) -> np.ndarray:
+    """Identity when the rates match (the on-path case, reference audio.py:20-22).  Otherwise a
+    polyphase (Kaiser-windowed sinc) resampler -- the reference delegates to librosa/soxr_hq,
+    whose source is not in the repository: parity for mismatched rates is UNPINNED."""
+    x = np.asarray(audio, dtype=np.float32)
+    if int(sample_rate) == int(target_sample_rate):
+        return x
+    from scipy.signal import resample_poly
+    frac = Fraction(int(target_sample_rate), int(sample_rate))
+    if x.size == 0:
+        return x
+    return resample_poly(x.astype(np.float64), frac.numerator, frac.denominator).astype(np.float32)
+
+
+def fit_length(audio: np.ndarray, target_len: int) -> np.ndarray:
+    """Truncate or zero-pad to `target_len` (reference audio.py:30-38)."""
+    x = np.asarray(audio, dtype=np.float32).reshape(-1)
+    if x.shape[0] == target_len:
+        return x
+    if x.shape[0] > target_len:
+        return x[:target_len]
+    out = np.zeros(target_len, dtype=np.float32)
+    out[: x.shape[0]] = x
+    return out
+
+
+def validate_attn_limit_db(attn_limit_db: Optional[float]) -> Optional[float]:
+    """None / +inf = off; negative or NaN is an error (reference audio.py:41-47)."""
+    if attn_limit_db is None:
+        return None
+    value = float(attn_limit_db)
+    if np.isnan(value) or value < 0.0:
+        raise ValueError("attn_limit_db must be non-negative, infinity, or None.")
+    return value
+
+
+def apply_attn_limit(spec_noisy: np.ndarray, spec_enh: np.ndarray, attn_limit_db: Optional[float]) -> np.ndarray:
+    """alpha * noisy[t-4] + (1-alpha) * enh[t] on [1,T,F,2] spectra (reference audio.py:50-76).
+    Host twin of the blend fused into the GPU deep-filter kernel (used by the spectral API)."""
+    value = validate_attn_limit_db(attn_limit_db)
+    enhanced = np.asarray(spec_enh, dtype=np.float32)
+    if value is None:
+        return enhanced
+    noisy = np.asarray(spec_noisy, dtype=np.float32)
+    if noisy.shape != enhanced.shape:
+        raise ValueError(
+            "spec_noisy and spec_enh must have matching shapes, "
+            f"got {noisy.shape} and {enhanced.shape}."
+        )
+    shifted = np.zeros_like(noisy)
+    k = ATTN_LIMIT_NOISY_FRAME_OFFSET
+    if noisy.shape[1] > k:
+        shifted[:, k:] = noisy[:, :-k]
+    alpha = float(10.0 ** (-value / 20.0))
+    return np.ascontiguousarray(alpha * shifted + (1.0 - alpha) * enhanced, dtype=np.float32)
+
+
+def pcm16_safe(audio: np.ndarray) -> np.ndarray:
+    """Clip to [-1,1] and scale to int16 (reference audio.py:79-81)."""
+    x = np.clip(np.asarray(audio, dtype=np.float32), -1.0, 1.0)
+    return (x * 32767.0).astype(np.int16)
+
+
+def vorbis_window(window_len: int) -> np.ndarray:
+    """sin(pi/2 sin^2(pi (n+1/2)/N)) (reference audio.py:84-88); power-complementary at 50 % overlap."""
+    n = np.arange(window_len)
+    s = np.sin(0.5 * np.pi * (n + 0.5) / (window_len / 2))
+    return np.sin(0.5 * np.pi * s * s).astype(np.float32)
+
+
+@dataclass(frozen=True)
+class StftConfig:
+    win_len: int
+    hop_size: int
+    window: np.ndarray
+
+
+def make_stft_config(win_len: int) -> StftConfig:
+    """hop = win/2, vorbis window (reference audio.py:98-101)."""
+    return StftConfig(win_len=int(win_len), hop_size=int(win_len) // 2, window=vorbis_window(int(win_len)))

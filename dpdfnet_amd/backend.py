@@ -222,6 +222,9 @@ class HipModel:
         db = float("nan") if attn_limit_db is None else float(attn_limit_db)
         _check(self._L.dpdf_enhance_batch(self._h, wav_ptr, int(B), int(N), db, out_ptr, DPDF_DEVICE_PTRS))
 
+    def open_streams(self, n_streams: int) -> "HipStreams":
+        return HipStreams(self, n_streams)
+
     def sync(self) -> None:
         _check(self._L.dpdf_sync(self._h))
 

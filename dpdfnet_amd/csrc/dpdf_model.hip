@@ -192,6 +192,8 @@ struct dpdf_model {
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;
+    std::vector<hipEvent_t> prof_events; int prof_used = 0;
+    std::vector<std::pair<const char*, int>> prof_pending;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; int dbg_B = 0, dbg_Tc = 0;
     const float* C(size_t off) const { return consts + off; }
@@ -206,17 +208,24 @@ struct dpdf_streams {
 namespace {
 
 struct ProfScope {
-    dpdf_model* m; const char* name;
+    // Records a HIP event pair around a launch class on the model's stream; NO host sync here --
+    // elapsed times are resolved in dpdf_profile_report after the stream has drained, so profiling
+    // can stay on inside a timed region.
+    dpdf_model* m; const char* name; int idx = -1;
     ProfScope(dpdf_model* m_, const char* n) : m(m_), name(n) {
-        if (m->prof_on) (void)hipEventRecord(m->ev0, m->stream);
+        if (!m->prof_on) return;
+        if (m->prof_used + 2 > (int)m->prof_events.size()) {
+            size_t old = m->prof_events.size();
+            m->prof_events.resize(old + 512, nullptr);
+            for (size_t i = old; i < m->prof_events.size(); ++i) (void)hipEventCreate(&m->prof_events[i]);
+        }
+        idx = m->prof_used; m->prof_used += 2;
+        (void)hipEventRecord(m->prof_events[idx], m->stream);
     }
     ~ProfScope() {
-        if (m->prof_on) {
-            (void)hipEventRecord(m->ev1, m->stream);
-            (void)hipEventSynchronize(m->ev1);
-            float ms = 0; (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
-            auto& e = m->prof[name]; e.ms += ms; e.calls++;
-        }
+        if (idx < 0) return;
+        (void)hipEventRecord(m->prof_events[idx + 1], m->stream);
+        m->prof_pending.push_back({name, idx});
     }
 };
 
@@ -431,7 +440,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         const DprnnW& w = blocks[bi];
         {   // intra-band bi-GRU over frequency, h0 = 0
-            ProfScope ps(m, "dprnn_intra_scan");
+            ProfScope ps(m, Fp >= 48 ? "gru64_intra_df" : "gru64_intra_erb");
             Gru64Args a{};
             a.x = x; a.out = m->ws.hcat.p; a.wfrag = m->C(w.intra.wfrag); a.bias = m->C(w.intra.bias); a.hstate = nullptr;
             a.nrows = B * Tc; a.nsteps = Fp; a.ndirs = 2; a.rdiv = 1;
@@ -447,7 +456,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
         }
         std::swap(x, y);
         {   // inter-band GRUCell over time, one hidden state per band position
-            ProfScope ps(m, "dprnn_inter_scan");
+            ProfScope ps(m, Fp >= 48 ? "gru64_inter_df" : "gru64_inter_erb");
             Gru64Args a{};
             a.x = x; a.out = m->ws.hin.p; a.wfrag = m->C(w.inter.wfrag); a.bias = m->C(w.inter.bias);
             a.hstate = state + soff + (long)bi * Fp * 64;
@@ -808,6 +817,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     if (m->consts) (void)hipFree(m->consts);
     if (m->iconsts) (void)hipFree(m->iconsts);
     if (m->d_init_state) (void)hipFree(m->d_init_state);
+    for (hipEvent_t e : m->prof_events) if (e) (void)hipEventDestroy(e);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -856,12 +866,23 @@ extern "C" int dpdf_sync(dpdf_model* m) {
 }
 extern "C" int dpdf_profile_enable(dpdf_model* m, int on) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
+    std::lock_guard<std::mutex> lk(m->mu);
     m->prof_on = on != 0;
-    if (on) m->prof.clear();
+    if (on) { m->prof.clear(); m->prof_pending.clear(); m->prof_used = 0; }
     return DPDF_OK;
 }
 extern "C" size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap) {
     if (!m) return 0;
+    std::lock_guard<std::mutex> lk(m->mu);
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    for (auto& pe : m->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->prof_events[pe.second], m->prof_events[pe.second + 1]) == hipSuccess) {
+            auto& e = m->prof[pe.first]; e.ms += ms; e.calls++;
+        }
+    }
+    m->prof_pending.clear(); m->prof_used = 0;
     std::string s;
     for (auto& kv : m->prof) {
         char line[160];

@@ -105,7 +105,9 @@ def synth_blob(entries: List[ManifestEntry], seed: int) -> np.ndarray:
 # ----------------------------------------------------------------------------------------------
 def streaming_key(k: str) -> str:
     """Offline-twin checkpoint key -> streaming-module key (reference onnx_model/dpdfnet.py:876-888)."""
-    if "inter_gru" in k and "grucell" not in k:
+    if "grucell" in k:                       # already a streaming-module key
+        return k
+    if "inter_gru" in k:
         return k.replace("_l0", "").replace("inter_gru.", "inter_gru.grucell.")
     if "gru.gru" in k:
         layer = k[-1]

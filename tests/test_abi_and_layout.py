@@ -1,0 +1,122 @@
+"""CPU: the C-ABI library loads and exports everything include/dpdfnet_hip.h declares; the weight
+manifest is consistent; the product path has no oracle/CPU fallback; repository layout rules."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared_symbols():
+    txt = (ROOT / "include" / "dpdfnet_hip.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpdf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dpdfnet_amd import backend
+    L = backend.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for sym in declared:
+        assert hasattr(L, sym), f"libdpdfnet_hip.so does not export {sym}"
+    assert set(declared) == set(backend.EXPORTED_SYMBOLS)
+    assert L.dpdf_abi_version() == 1
+
+
+def test_manifest_agrees_between_product_and_oracle():
+    from dpdfnet_amd import backend
+    from oracle import oracle as orc
+    for sr, nb in [(16000, 0), (16000, 2), (16000, 4), (16000, 8), (48000, 2), (48000, 8)]:
+        a = backend.manifest(sr, nb)
+        b = orc.manifest_text(sr, nb)
+        from dpdfnet_amd.weights import parse_manifest_text
+        assert a == parse_manifest_text(b)
+        d = backend.query_dims(sr, nb)
+        assert d.state_size > 0 and d.win == (320 if sr == 16000 else 960)
+    with pytest.raises(ValueError):
+        backend.manifest(44100, 2)
+
+
+def test_param_counts_match_readme_figures():
+    """README.md:32-41 parameter counts (dpdfnet2/4/8, 48k-2/8), minus the dead lsnr head."""
+    from dpdfnet_amd import backend
+    def nparams(sr, nb):
+        return sum(e.count for e in backend.manifest(sr, nb) if "running_" not in e.name) + 513
+    assert abs(nparams(16000, 2) / 1e6 - 2.49) < 0.01
+    assert abs(nparams(16000, 4) / 1e6 - 2.84) < 0.01
+    assert abs(nparams(16000, 8) / 1e6 - 3.54) < 0.01
+    assert abs(nparams(48000, 2) / 1e6 - 2.58) < 0.01
+    assert abs(nparams(48000, 8) / 1e6 - 3.63) < 0.01
+
+
+def test_pack_unpack_roundtrip_and_key_forms():
+    from dpdfnet_amd import backend, weights
+    ents = backend.manifest(16000, 1)
+    blob = weights.synth_blob(ents, 5)
+    sd = weights.unpack_to_streaming_state_dict(ents, blob)
+    np.testing.assert_array_equal(weights.pack_state_dict(ents, sd), blob)
+    # offline-twin key names (reference onnx_model/dpdfnet.py:876-888) and einsum grouped linears
+    off = {}
+    for k, v in sd.items():
+        if "inter_gru.grucell." in k:
+            k = k.replace("inter_gru.grucell.", "inter_gru.") + "_l0"
+        m = re.match(r"(.*\.gru)\.(\d)\.grucell\.(.*)", k)
+        if m:
+            k = f"{m.group(1)}.{m.group(3)}_l{m.group(2)}"
+        off[k] = v
+    assert any(k.endswith("_l1") for k in off)
+    np.testing.assert_array_equal(weights.pack_state_dict(ents, off), blob)
+    ein = {k: v for k, v in sd.items() if ".layers." not in k}
+    for e in ents:
+        if len(e.shape) == 3:
+            p = e.name[:-len(".weight")]
+            G = e.shape[0]
+            ein[p + ".weight"] = np.stack([sd[f"{p}.layers.{g}.weight"].T for g in range(G)])
+            ein[p + ".bias"] = np.concatenate([sd[f"{p}.layers.{g}.bias"] for g in range(G)])
+    np.testing.assert_array_equal(weights.pack_state_dict(ents, ein), blob)
+
+
+def test_weight_file_roundtrip(tmp_path):
+    from dpdfnet_amd import backend, weights
+    ents = backend.manifest(16000, 0)
+    blob = weights.synth_blob(ents, 3)
+    p = weights.save_blob(tmp_path / "baseline.npz", blob, erb_norm_init=np.arange(32, dtype=np.float32))
+    b2, extras = weights.load_weight_file(p, ents)
+    np.testing.assert_array_equal(b2, blob)
+    assert extras["erb_norm_init"].shape == (32,)
+    with pytest.raises(FileNotFoundError):
+        weights.load_weight_file(tmp_path / "missing.npz", ents)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a HIP device dpdf_create must fail (RuntimeError), never run on the CPU."""
+    from dpdfnet_amd import backend, weights
+    if backend.device_count() > 0:
+        pytest.skip("GPU present")
+    blob = weights.synth_blob(backend.manifest(16000, 0), 1)
+    with pytest.raises(RuntimeError, match="no HIP device|hip"):
+        backend.HipModel(16000, 0, blob)
+    with pytest.raises(ValueError):
+        backend.HipModel(16000, 0, blob[:-1])
+
+
+def test_product_never_touches_oracle_or_reference():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    ref_mount = "/root/" + "reference"
+    for p in list((ROOT / "dpdfnet_amd").rglob("*.py")) + list((ROOT / "dpdfnet_amd" / "csrc").glob("*")):
+        txt = p.read_text()
+        assert "oracle" not in txt.lower(), p
+        assert ref_mount not in txt, p
+    for p in [ROOT / "bench.py", ROOT / "__graft_entry__.py"] + list((ROOT / "tests").glob("test_*.py")):
+        assert ref_mount not in p.read_text(), p
+    assert "oracle/_ref/" in (ROOT / ".gitignore").read_text()
+
+
+def test_layout():
+    for rel in ["bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/dpdfnet_hip.h",
+                "oracle/dpdf_oracle.c", "tests/golden/make_golden.py", "profiles"]:
+        assert (ROOT / rel).exists(), rel

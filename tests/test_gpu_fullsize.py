@@ -1,0 +1,100 @@
+"""GPU (-m gpu): BASELINE.json configurations at FULL size, through size-independent properties
+(the oracle needs ~4.5 ms per frame, so it checks a few whole clips, not all 256):
+  * spot clips of the big batch against the CPU oracle on the same clip (full 10 s),
+  * batch-slot invariance (the same clip in two slots gives bit-identical output),
+  * causality/prefix property: enhance(x[:n0]) == enhance(x)[:n0 - tail] (the model only sees 2+2
+    frames of look-ahead),
+  * time-chunk invariance, finiteness, the reference's zero tail,
+  * config 5: 64 concurrent device-resident 48 kHz streams, hop by hop, against the oracle."""
+import numpy as np
+import pytest
+
+from tests.util import rms, synth_clip
+
+pytestmark = pytest.mark.gpu
+WAVE_TOL = 2e-6
+
+
+def _model(be, sr, nb, seed=20260417):
+    from dpdfnet_amd.weights import synth_blob
+    blob = synth_blob(be.manifest(sr, nb), seed)
+    return be.HipModel(sr, nb, blob, 0), blob
+
+
+@pytest.fixture(scope="module")
+def be():
+    from dpdfnet_amd import backend
+    assert backend.device_count() >= 1
+    return backend
+
+
+@pytest.mark.parametrize("nb,B,check_oracle", [(2, 256, True), (4, 256, True), (8, 256, False)])
+def test_baseline_batch_configs_full_size(be, nb, B, check_oracle):
+    """configs[1] dpdfnet2 / configs[2] per-GPU shard dpdfnet4 / configs[3] dpdfnet8: 256 x 10 s."""
+    from oracle import oracle as orc
+    sr, n = 16000, 160000
+    m, blob = _model(be, sr, nb)
+    m.set_chunk_frames(128)
+    base = [synth_clip(n, sr, 9000 + i) for i in range(6)]
+    idx = np.arange(B) % 6
+    idx[200] = idx[3]                                   # slots 3 and 200 hold the same clip
+    wav = np.stack([base[i] for i in idx])
+    wav[7, 40000:] = 0.0                                # a clip that goes silent
+    out = m.enhance_batch(wav, None)
+    assert out.shape == wav.shape and np.isfinite(out).all()
+    np.testing.assert_array_equal(out[3], out[200])
+    np.testing.assert_array_equal(out[0], out[6])
+    assert np.all(out[:, -m.win_len:] == 0.0)
+    assert m.num_frames(n) == 1003
+    if check_oracle:
+        o = orc.Oracle(sr, nb, blob)
+        for b in (0, 7):
+            err = rms(out[b] - o.enhance(wav[b]))
+            assert err < WAVE_TOL, (b, err)
+    # prefix/causality on a slice of the batch
+    n0 = 48000
+    pre = m.enhance_batch(wav[:4, :n0], None)
+    keep = n0 - 4 * m.win_len
+    assert rms(pre[:, :keep] - out[:4, :keep]) < WAVE_TOL
+    # chunk invariance at size
+    m.set_chunk_frames(200)
+    out2 = m.enhance_batch(wav[:32], None)
+    assert rms(out2 - out[:32]) < 1e-6
+    m.close()
+
+
+def test_config5_64_streams_48khz_dpdfnet8(be):
+    """configs[4]: 64 concurrent StreamEnhancer states on dpdfnet8_48khz_hr, 10 ms hops."""
+    from oracle import oracle as orc
+    sr, nb, S, hops = 48000, 8, 64, 40
+    m, blob = _model(be, sr, nb)
+    hop, win = m.hop, m.win_len
+    streams = be.HipStreams(m, S)
+    pcm = np.stack([synth_clip((hops + 1) * hop, sr, 700 + i) for i in range(S)])
+    streams.prime(pcm[:, :hop])
+    outs = []
+    for j0, k in ((0, 1), (1, 1), (2, 8), (10, 30)):                      # hop-by-hop then multi-hop calls
+        outs.append(streams.process(pcm[:, (1 + j0) * hop:(1 + j0 + k) * hop]))
+    got = np.concatenate(outs, axis=1)
+    assert got.shape == (S, hops * hop) and np.isfinite(got).all()
+    # oracle: causal STFT (stream.py:119-126) -> frame function -> OLA (stream.py:138-155), numpy host DSP
+    o = orc.Oracle(sr, nb, blob)
+    w = o.window()
+    for s in (0, 63):
+        x = pcm[s]
+        spec = np.stack([np.fft.rfft(x[j * hop: j * hop + win] * w) for j in range(hops)])
+        spec_ri = np.stack([spec.real, spec.imag], axis=-1).astype(np.float32)
+        spec_e, st = o.run_frames(spec_ri)
+        ola = np.zeros(win, dtype=np.float32)
+        ref = []
+        for j in range(hops):
+            fr = (np.fft.irfft(spec_e[j, :, 0] + 1j * spec_e[j, :, 1], n=win) * w).astype(np.float32)
+            ola += fr
+            ref.append(ola[:hop].copy())
+            ola[:hop] = ola[hop:]; ola[hop:] = 0.0
+        ref = np.concatenate(ref)
+        assert rms(got[s] - ref) < WAVE_TOL, (s, rms(got[s] - ref))
+        assert np.abs(streams.get_state(s) - st).max() < 5e-4
+    streams.reset(5)
+    np.testing.assert_array_equal(streams.get_state(5), m.initial_state())
+    streams.close(); m.close()

@@ -1,0 +1,193 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against (a) the CPU oracle on the
+same seeded inputs, (b) the committed reference goldens, and (c) size-independent properties at
+BASELINE.json's full sizes.  Tolerance from BASELINE.json north_star: waveform RMS error < 1e-4 vs
+the reference; we assert 50x tighter (2e-6) on waveforms and relative 1e-4 on every stage."""
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN, MODEL_TAGS, golden_blob, load_golden, make_oracle, norm_inits, rms, synth_clip
+
+pytestmark = pytest.mark.gpu
+
+WAVE_TOL = 2e-6          # RMS, signals are O(0.05)
+STAGE_REL_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def be():
+    from dpdfnet_amd import backend
+    assert backend.device_count() >= 1, "no GPU visible: the HIP engine has no CPU fallback"
+    return backend
+
+
+@pytest.fixture(scope="module", params=MODEL_TAGS)
+def case(request, be):
+    g, meta = load_golden(request.param)
+    blob = golden_blob(meta)
+    e, s = norm_inits(meta["sample_rate"])
+    m = be.HipModel(meta["sample_rate"], meta["nb"], blob, 0, e, s)
+    yield g, meta, make_oracle(meta, blob), m
+    m.close()
+
+
+def test_initial_state_and_geometry(case):
+    g, meta, o, m = case
+    assert m.state_size == meta["state_size"] == o.state_size
+    np.testing.assert_array_equal(m.initial_state(), g["init_state"])
+    assert (m.win_len, m.hop, m.freq_bins) == (o.win_len, o.hop, o.freq_bins)
+    assert m.num_frames(meta["n"]) == meta["T"]
+
+
+def test_run_frames_matches_oracle_and_golden(case):
+    g, meta, o, m = case
+    spec = o.stft(g["wav"])
+    ref, st_ref = o.run_frames(spec)
+    m.set_chunk_frames(0)
+    out, st = m.run_frames(spec, m.initial_state())
+    scale = float(np.abs(ref).max())
+    assert np.abs(out - ref).max() < STAGE_REL_TOL * scale
+    assert rms(out - ref) < 1e-5 * scale
+    assert np.abs(st - st_ref).max() < 2e-4
+    assert np.abs(out[:64] - g["spec_e_head"]).max() < STAGE_REL_TOL * scale
+    assert np.abs(st - g["state_out"]).max() < 2e-4
+
+
+def test_stage_tensors_match_reference_probes(case, be):
+    g, meta, o, m = case
+    spec = o.stft(g["wav"])
+    T = spec.shape[0]
+    m.set_chunk_frames(0)
+    m.run_frames(spec, m.initial_state())
+    d = be.query_dims(meta["sample_rate"], meta["nb"])
+    shapes = {"e0": d.Ec, "e1": d.F1, "e2": d.F2, "e3": d.F3, "e3_dprnn": d.F3, "c1": d.Fd, "c1_dprnn": d.Fd}
+    checked = 0
+    for t in meta["probe_frames"]:
+        for name, Fp in shapes.items():
+            key = f"f{t}_{name}"
+            if key not in g.files:
+                continue
+            mine = m.debug_fetch(name).reshape(T, Fp, 64)[t].T.reshape(-1)     # -> reference [C][F]
+            ref = g[key]
+            assert np.abs(mine - ref).max() < STAGE_REL_TOL * max(1.0, float(np.abs(ref).max())), (t, name)
+            checked += 1
+        c0 = m.debug_fetch("c0").reshape(T + 4, d.D, 64)[4 + t].T.reshape(-1)
+        assert np.abs(c0 - g[f"f{t}_c0"]).max() < STAGE_REL_TOL * max(1.0, float(np.abs(g[f"f{t}_c0"]).max()))
+        emb = m.debug_fetch("emb").reshape(T, 512)[t]
+        assert np.abs(emb - g[f"f{t}_emb"]).max() < STAGE_REL_TOL * max(1.0, float(np.abs(g[f"f{t}_emb"]).max()))
+        mk = m.debug_fetch("m").reshape(T, d.E)[t]
+        ref_m = g[f"f{t}_m"]
+        assert np.abs(mk[: ref_m.size] - ref_m).max() < 1e-5
+        ck = m.debug_fetch("coefs").reshape(T + 2, d.D * 10)[2 + t]
+        assert np.abs(ck - g[f"f{t}_coefs_fk"]).max() < STAGE_REL_TOL * max(1.0, float(np.abs(ck).max()))
+        fe = m.debug_fetch("feat_erb").reshape(T + 2, d.E)[2 + t]
+        # log-domain feature of near-silent bins amplifies the (oracle-double vs torch-fp32) STFT rounding
+        assert np.abs(fe - g[f"f{t}_feat_erb"]).max() < 5e-5
+    assert checked >= 10
+
+
+@pytest.mark.parametrize("chunk", [1, 3, 16, 50])
+def test_time_chunking_and_state_carry_invariance(case, chunk):
+    """Splitting T frames into chunks (state carried in the reference flat layout) changes nothing;
+    chunk = 1 is literally one session.run per frame."""
+    g, meta, o, m = case
+    spec = o.stft(g["wav"])[:40]
+    m.set_chunk_frames(0)
+    ref, st_ref = m.run_frames(spec, m.initial_state())
+    m.set_chunk_frames(chunk)
+    out, st = m.run_frames(spec, m.initial_state())
+    m.set_chunk_frames(0)
+    np.testing.assert_allclose(out, ref, atol=1e-5 * float(np.abs(ref).max()))
+    np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5)
+
+
+def test_frame_by_frame_host_loop_is_a_drop_in_for_session_run(case):
+    """The reference's hot loop verbatim (api.py:96-104): one call per frame, state through the host."""
+    g, meta, o, m = case
+    spec = o.stft(g["wav"])[:12]
+    ref, st_ref = o.run_frames(spec)
+    st = m.initial_state()
+    frames = []
+    for t in range(spec.shape[0]):
+        y, st = m.run_frames(spec[t:t + 1], st)
+        frames.append(y)
+    out = np.concatenate(frames)
+    assert np.abs(out - ref).max() < STAGE_REL_TOL * float(np.abs(ref).max())
+    assert np.abs(st - st_ref).max() < 2e-4
+
+
+def test_enhance_batch_matches_reference_waveforms(case):
+    g, meta, o, m = case
+    wav = g["wav"]
+    for chunk in (0, 37):
+        m.set_chunk_frames(chunk)
+        for key, db in (("enhanced", None), ("enhanced_attn0", 0.0), ("enhanced_attn12", 12.0)):
+            out = m.enhance_batch(wav[None], db)[0]
+            assert rms(out - g[key]) < WAVE_TOL, (key, chunk, rms(out - g[key]))
+            assert np.all(out[-m.win_len:] == 0.0)            # reference quirk: last 2 hops are zero
+    m.set_chunk_frames(0)
+
+
+def test_batch_rows_are_independent_and_ragged_sizes(case):
+    g, meta, o, m = case
+    sr = meta["sample_rate"]
+    for n in (1, m.hop - 1, m.win_len + 7, 3 * m.hop):          # tiny / non-multiple-of-hop lengths
+        wav = np.stack([synth_clip(n, sr, 50 + i) for i in range(3)])
+        out = m.enhance_batch(wav)
+        for i in range(3):
+            assert rms(out[i] - o.enhance(wav[i])) < WAVE_TOL, (n, i)
+    wav = np.stack([synth_clip(2000, sr, 60 + i) for i in range(5)] + [synth_clip(2000, sr, 60)])
+    out = m.enhance_batch(wav, 6.0)
+    np.testing.assert_array_equal(out[0], out[5])                # same clip, different batch slot
+    for i in (1, 4):
+        assert rms(out[i] - o.enhance(wav[i], 6.0)) < WAVE_TOL
+
+
+def test_error_behaviour(case):
+    g, meta, o, m = case
+    with pytest.raises(ValueError, match="attn_limit_db"):
+        m.enhance_batch(g["wav"][None], -2.0)
+    with pytest.raises(ValueError):
+        m.run_frames(np.zeros((2, 3, m.freq_bins + 1, 2), np.float32), m.initial_state())
+    with pytest.raises(ValueError):
+        m.run_frames(np.zeros((1, 3, m.freq_bins, 2), np.float32), np.zeros(5, np.float32))
+    assert m.enhance_batch(np.zeros((2, 0), np.float32)).shape == (2, 0)
+
+
+# ----- StreamEnhancer on the device-resident streaming path ------------------------------------
+@pytest.mark.parametrize("tag", ["16k_nb2", "48k_nb1"])
+def test_stream_enhancer_matches_reference_stream_goldens(tag, be, tmp_path, monkeypatch):
+    """Reference StreamEnhancer driven by the real frame function (stream_*.npz 'real_*')."""
+    from dpdfnet_amd import stream, weights
+    from dpdfnet_amd.models import ModelInfo, ResolvedModel
+    g, meta = load_golden(tag)
+    sr = meta["sample_rate"]
+    e, s = norm_inits(sr)
+    wfile = weights.save_blob(tmp_path / "w.npz", golden_blob(meta), erb_norm_init=e, spec_norm_init=s)
+    info = ModelInfo(name=f"test_{tag}", sample_rate=sr, frame_ms=20.0, description="", onnx_filename="w.onnx",
+                     dprnn_num_blocks=meta["nb"])
+    monkeypatch.setattr(stream, "resolve_model", lambda **_k: ResolvedModel(info=info, onnx_path=wfile))
+    G = np.load(GOLDEN / f"stream_{tag}.npz")
+    wav = G["wav"]
+    hop = 160 if sr == 16000 else 480
+    for chunk in (7, hop, 171, 512, len(wav)):
+        se = stream.StreamEnhancer(model="ignored")
+        parts = [se.process(wav[i:i + chunk]) for i in range(0, len(wav), chunk)]
+        parts.append(se.flush())
+        got = np.concatenate(parts)
+        ref = G[f"real_chunk{chunk}"]
+        assert got.shape == ref.shape, chunk
+        assert rms(got - ref) < WAVE_TOL, (chunk, rms(got - ref))
+        se.reset()
+        assert len(se.process(wav[: 2 * hop - 1])) == 0 and len(se.process(wav[:1])) == hop
+
+
+def test_package_enhance_with_synthetic_weights_matches_oracle(be):
+    import dpdfnet_amd
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import synth_blob
+    wav = synth_clip(12000, 16000, 5)
+    out = dpdfnet_amd.enhance(wav, 16000, model="dpdfnet2", onnx_path="synthetic:77", attn_limit_db=9.0)
+    ref = orc.Oracle(16000, 2, synth_blob(be.manifest(16000, 2), 77)).enhance(wav, 9.0)
+    assert out.shape == wav.shape and rms(out - ref) < WAVE_TOL
+    outs = dpdfnet_amd.enhance_batch([wav, wav[:5000]], 16000, model="dpdfnet2", onnx_path="synthetic:77")
+    assert rms(outs[1] - orc.Oracle(16000, 2, synth_blob(be.manifest(16000, 2), 77)).enhance(wav[:5000])) < WAVE_TOL

@@ -1,0 +1,237 @@
+"""CPU: behaviour of the drop-in Python surface, re-expressed from the reference's own test-suite
+(reference package/tests/test_package_behaviors.py) against dpdfnet_amd with numpy passthrough
+doubles substituted at the same seam the reference's tests patch (resolve_model /
+build_runtime_model / infer_win_len)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN, PassthroughSession
+
+
+def _patch(monkeypatch, win=320, sr=16000, zero=False):
+    from dpdfnet_amd import api, stream
+    from dpdfnet_amd.models import ModelInfo, ResolvedModel
+    from dpdfnet_amd.runtime import RuntimeModel
+    sess = PassthroughSession(win, sr, zero)
+    info = ModelInfo(name="fake", sample_rate=sr, frame_ms=20.0, description="", onnx_filename="fake.onnx")
+    rt = RuntimeModel(session=sess, init_state=np.zeros(1, np.float32), info=info)
+    for mod in (api, stream):
+        monkeypatch.setattr(mod, "resolve_model", lambda **_k: ResolvedModel(info=info, onnx_path="synthetic:0"))
+        monkeypatch.setattr(mod, "build_runtime_model", lambda *_a, **_k: rt)
+        monkeypatch.setattr(mod, "infer_win_len", lambda _s, _sr: win)
+    return sess
+
+
+def test_import_surface():
+    import dpdfnet_amd
+    for name in ("enhance", "enhance_file", "StreamEnhancer", "available_models", "download", "enhance_batch"):
+        assert hasattr(dpdfnet_amd, name)
+    with pytest.raises(AttributeError):
+        dpdfnet_amd.nope
+
+
+def test_enhance_progress_callback_protocol(monkeypatch):
+    from dpdfnet_amd import api
+    _patch(monkeypatch, win=8)
+    updates = []
+    api.enhance(np.zeros(8, np.float32), 16000, progress_callback=lambda d, t: updates.append((d, t)))
+    T = 1 + (8 + 8) // 4
+    assert updates[0] == (0, T) and updates[-1] == (T, T) and len(updates) == T + 1
+
+
+def test_offline_passthrough_reconstructs_shifted_signal(monkeypatch):
+    from dpdfnet_amd import api
+    WIN = 320
+    _patch(monkeypatch, win=WIN)
+    rng = np.random.default_rng(7)
+    signal = (rng.standard_normal(8000) * 0.5).astype(np.float32)
+    out = api.enhance(signal, 16000)
+    assert out.shape == signal.shape and out.dtype == np.float32
+    shift = 2 * WIN
+    np.testing.assert_allclose(out[: len(signal) - shift], signal[shift:], atol=1e-4)
+
+
+def test_attn_limit_zero_db_returns_aligned_noisy(monkeypatch):
+    """0 dB => alpha = 1: output is the noisy input delayed 4 frames then advanced 2*win = aligned."""
+    from dpdfnet_amd import api
+    WIN = 320
+    _patch(monkeypatch, win=WIN, zero=True)
+    rng = np.random.default_rng(3)
+    signal = (rng.standard_normal(6400) * 0.3).astype(np.float32)
+    out = api.enhance(signal, 16000, attn_limit_db=0.0)
+    np.testing.assert_allclose(out[: len(signal) - WIN], signal[: len(signal) - WIN], atol=1e-4)
+    off = api.enhance(signal, 16000, attn_limit_db=float("inf"))
+    assert np.allclose(off, 0.0)
+    with pytest.raises(ValueError, match="attn_limit_db"):
+        api.enhance(signal, 16000, attn_limit_db=-1.0)
+    with pytest.raises(ValueError, match="attn_limit_db"):
+        api.enhance(signal, 16000, attn_limit_db=float("nan"))
+
+
+def test_enhance_stereo_and_batch(monkeypatch):
+    from dpdfnet_amd import api
+    sess = _patch(monkeypatch)
+    stereo = np.zeros((1000, 2), np.float32)
+    assert api.enhance(stereo, 16000).shape == (1000,)
+    with pytest.raises(ValueError, match="mono/stereo"):
+        api.enhance(np.zeros((2, 3, 4), np.float32), 16000)
+    clips = [np.zeros(800, np.float32), np.zeros(1600, np.float32), np.zeros(800, np.float32), np.zeros(0, np.float32)]
+    sess.calls.clear()
+    outs = api.enhance_batch(clips, 16000)
+    assert [o.shape[0] for o in outs] == [800, 1600, 800, 0]
+    assert sorted(c[0] for c in sess.calls) == [(1, 1600), (2, 800)]     # grouped by length
+
+
+def _stream(monkeypatch, win=8, zero=True):
+    _patch(monkeypatch, win=win, zero=zero)
+    from dpdfnet_amd import StreamEnhancer
+    return StreamEnhancer(model="dpdfnet2")
+
+
+def test_stream_buffers_small_chunks(monkeypatch):
+    e = _stream(monkeypatch, win=8)
+    assert len(e.process(np.zeros(3, np.float32), sample_rate=16000)) == 0
+    assert len(e.process(np.zeros(5, np.float32), sample_rate=16000)) == 4
+
+
+def test_stream_misaligned_block_size(monkeypatch):
+    WIN, HOP = 320, 160
+    e = _stream(monkeypatch, win=WIN)
+    total, CHUNK, fed, outs = 16000, 171, 0, []
+    while fed < total:
+        n = min(CHUNK, total - fed)
+        outs.append(e.process(np.zeros(n, np.float32), sample_rate=16000))
+        fed += n
+    assert sum(len(o) for o in outs) == ((total - WIN) // HOP + 1) * HOP
+    assert all(o.dtype == np.float32 for o in outs)
+
+
+def test_stream_reset_flush_and_errors(monkeypatch):
+    e = _stream(monkeypatch, win=8)
+    e.process(np.zeros(5, np.float32), sample_rate=16000)
+    e.reset()
+    assert len(e.process(np.zeros(5, np.float32), sample_rate=16000)) == 0
+    out = e.flush()
+    assert len(out) > 0 and out.dtype == np.float32
+    e2 = _stream(monkeypatch, win=8)
+    assert len(e2.flush()) == 0
+    e2.process(np.zeros(3, np.float32), sample_rate=16000)
+    with pytest.raises(ValueError, match="Sample rate changed"):
+        e2.process(np.zeros(3, np.float32), sample_rate=8000)
+    assert len(e2.process(np.zeros(0, np.float32), sample_rate=16000)) == 0
+    assert e2.process(np.zeros((10, 2), np.float32), sample_rate=16000).dtype == np.float32
+
+
+def _stream_all(e, signal, block):
+    parts = [e.process(signal[i:i + block], sample_rate=16000) for i in range(0, len(signal), block)]
+    parts.append(e.flush())
+    return np.concatenate(parts)
+
+
+def test_stream_passthrough_reconstructs_signal(monkeypatch):
+    WIN, HOP = 320, 160
+    e = _stream(monkeypatch, win=WIN, zero=False)
+    rng = np.random.default_rng(123)
+    signal = (rng.standard_normal(8000) * 0.5).astype(np.float32)
+    out = e.process(signal, sample_rate=16000)
+    np.testing.assert_allclose(out[HOP:], signal[HOP: len(out)], atol=1e-5)
+
+
+@pytest.mark.parametrize("block", [7, 64, 160, 171, 320, 512, 1000])
+def test_stream_block_size_invariance(monkeypatch, block):
+    rng = np.random.default_rng(42)
+    signal = (rng.standard_normal(4000) * 0.5).astype(np.float32)
+    ref = _stream_all(_stream(monkeypatch, win=320, zero=False), signal, 1)
+    got = _stream_all(_stream(monkeypatch, win=320, zero=False), signal, block)
+    assert len(got) == len(ref)
+    np.testing.assert_allclose(got, ref, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,chunk", [("16k_nb2", 7), ("16k_nb2", 160), ("16k_nb2", 171), ("16k_nb2", 512),
+                                       ("48k_nb1", 171), ("48k_nb1", 480)])
+def test_stream_buffering_matches_reference_goldens(monkeypatch, tag, chunk):
+    """Sample-exact agreement of the chunk re-blocking with the REFERENCE StreamEnhancer driven by
+    a passthrough session (stream_*.npz, made by tests/golden/make_golden.py)."""
+    G = np.load(GOLDEN / f"stream_{tag}.npz")
+    win = 320 if tag.startswith("16k") else 960
+    sr = 16000 if tag.startswith("16k") else 48000
+    _patch(monkeypatch, win=win, sr=sr, zero=False)
+    from dpdfnet_amd import StreamEnhancer
+    e = StreamEnhancer(model="dpdfnet2")
+    wav = G["wav"]
+    parts = [e.process(wav[i:i + chunk]) for i in range(0, len(wav), chunk)]
+    parts.append(e.flush())
+    got = np.concatenate(parts)
+    ref = G[f"pass_chunk{chunk}"]
+    assert len(parts[-1]) == int(G[f"pass_chunk{chunk}_nflush"])
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=2e-6)
+
+
+# ----- audio.py unit behaviours (reference tests :641-733) --------------------------------------
+def test_audio_helpers_known_answers():
+    from dpdfnet_amd import audio
+    H = np.load(GOLDEN / "host_dsp.npz")
+    np.testing.assert_array_equal(audio.to_mono(H["stereo"]), H["mono"])
+    np.testing.assert_array_equal(audio.pcm16_safe(H["x"]), H["pcm16"])
+    np.testing.assert_array_equal(audio.fit_length(H["x"], 40), H["fit_short"])
+    np.testing.assert_array_equal(audio.fit_length(H["x"], 80), H["fit_long"])
+    for key, db in (("attn0", 0.0), ("attn6", 6.0), ("attn_inf", float("inf")), ("attn_none", None)):
+        np.testing.assert_allclose(audio.apply_attn_limit(H["noisy"], H["enh"], db), H[key], atol=1e-6)
+    with pytest.raises(ValueError):
+        audio.apply_attn_limit(H["noisy"], H["enh"], -3.0)
+    with pytest.raises(ValueError):
+        audio.apply_attn_limit(H["noisy"], H["enh"][:, :3], 3.0)
+    C = np.load(GOLDEN / "constants.npz")
+    np.testing.assert_allclose(audio.vorbis_window(320), C["pkg_window_320"], atol=1e-7)
+    np.testing.assert_allclose(audio.vorbis_window(960), C["pkg_window_960"], atol=1e-7)
+
+
+def test_vorbis_window_cola_and_stft_config():
+    from dpdfnet_amd import audio
+    for win in (320, 960):
+        cfg = audio.make_stft_config(win)
+        assert cfg.hop_size == win // 2
+        w = cfg.window.astype(np.float64)
+        np.testing.assert_allclose(w[: win // 2] ** 2 + w[win // 2:] ** 2, 1.0, atol=1e-6)
+    x = np.arange(10, dtype=np.float32)
+    assert audio.ensure_sample_rate(x, 16000, 16000) is not None
+    np.testing.assert_array_equal(audio.ensure_sample_rate(x, 16000, 16000), x)
+    assert abs(len(audio.ensure_sample_rate(np.zeros(4800, np.float32), 48000, 16000)) - 1600) <= 1
+
+
+def test_model_registry_and_resolution(tmp_path, monkeypatch):
+    from dpdfnet_amd import models, api
+    assert models.supported_models() == sorted(["baseline", "dpdfnet2", "dpdfnet4", "dpdfnet8",
+                                                "dpdfnet2_48khz_hr", "dpdfnet8_48khz_hr"])
+    assert models.get_model_info("dpdfnet8_48khz_hr").sample_rate == 48000
+    with pytest.raises(ValueError, match="Unsupported model"):
+        models.get_model_info("nope")
+    monkeypatch.setenv("DPDFNET_MODEL_DIR", str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        models.resolve_model(model="dpdfnet2")
+    (tmp_path / "dpdfnet2.npz").write_bytes(b"x")
+    assert models.resolve_model(model="dpdfnet2").onnx_path == (tmp_path / "dpdfnet2.npz").resolve()
+    rows = {r["name"]: r for r in api.available_models()}
+    assert rows["dpdfnet2"]["ready"] and not rows["dpdfnet4"]["ready"]
+    assert models.resolve_model(model="dpdfnet4", onnx_path="synthetic:7").onnx_path == "synthetic:7"
+    with pytest.raises(FileNotFoundError):
+        models.resolve_model(model="dpdfnet4", onnx_path=tmp_path / "missing.npz")
+    with pytest.raises(ValueError):
+        api.download(quiet=True, verbose=True)
+
+
+def test_enhance_file_wav_roundtrip(tmp_path, monkeypatch):
+    from dpdfnet_amd import api
+    _patch(monkeypatch)
+    x = (0.1 * np.sin(np.arange(3200) * 0.05)).astype(np.float32)
+    src = tmp_path / "in.wav"
+    api._write_pcm16(src, x, 16000)
+    out = api.enhance_file(src)
+    assert out.name == "in_enhanced.wav" and out.is_file()
+    y, sr = api._read_audio(out)
+    assert sr == 16000 and y.shape == x.shape
+    with pytest.raises(FileNotFoundError):
+        api.enhance_file(tmp_path / "missing.wav")

@@ -1,0 +1,61 @@
+"""CPU: the N>1 sharding path over gloo, world_size 2 (RCCL on the GPU box uses the same code)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_shard_range_partitions_exactly():
+    from dpdfnet_amd.multi_gpu import shard_range, shard_sizes
+    for n in (0, 1, 7, 256, 2048, 2049):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(shard_sizes(n, w)) - min(shard_sizes(n, w)) <= 1
+    assert shard_range(2048, 8, 3) == (768, 1024)
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _worker(rank: int, world: int, port: int, q):
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+    from dpdfnet_amd.multi_gpu import gather_ragged_to_root, gather_to_root, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total, n = 5, 16
+        full = np.arange(total * n, dtype=np.float32).reshape(total, n)
+        lo, hi = shard_range(total, world, rank)
+        local = full[lo:hi] * 2.0                         # "enhance" = x2 on this rank's clips
+        got = gather_ragged_to_root(local, [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)], rank)
+        eq = torch.full((3, n), float(rank))
+        g2 = gather_to_root(eq, world, rank)
+        dist.barrier()
+        if rank == 0:
+            q.put((np.array_equal(got, full * 2.0), [float(g2[r].mean()) for r in range(world)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, means = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok and means == [0.0, 1.0]

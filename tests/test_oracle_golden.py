@@ -1,0 +1,100 @@
+"""CPU: the oracle (oracle/dpdf_oracle.c) against the goldens captured from the reference's own
+PyTorch streaming modules (tests/golden/make_golden.py).  This is what pins the oracle."""
+import json
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN, MODEL_TAGS, golden_blob, load_golden, make_oracle, rms
+
+PROBES = ["feat_erb", "e0", "e1", "e2", "e3", "e3_dprnn", "c0", "c1", "c1_dprnn", "emb", "m"]
+
+
+@pytest.fixture(scope="module", params=MODEL_TAGS)
+def case(request):
+    g, meta = load_golden(request.param)
+    blob = golden_blob(meta)
+    assert blob.size == meta["n_weights"]
+    return g, meta, make_oracle(meta, blob)
+
+
+def test_state_size_and_initial_state(case):
+    g, meta, o = case
+    assert o.state_size == meta["state_size"]
+    np.testing.assert_array_equal(o.initial_state(), g["init_state"])
+
+
+def test_stft_matches_reference(case):
+    g, meta, o = case
+    spec = o.stft(g["wav"])
+    assert spec.shape[0] == meta["T"]
+    scale = float(np.abs(g["spec_head"]).max())
+    assert np.abs(spec[:8] - g["spec_head"]).max() < 2e-7 * scale + 1e-6
+    assert np.abs(spec[-4:] - g["spec_tail"]).max() < 2e-7 * scale + 1e-6
+
+
+def test_frame_function_stages_and_state(case):
+    g, meta, o = case
+    spec = o.stft(g["wav"])
+    st = o.initial_state()
+    out = np.zeros_like(spec)
+    for t in range(spec.shape[0]):
+        out[t], st = o.frame(spec[t], st)
+        if t in meta["probe_frames"]:
+            for name in PROBES:
+                key = f"f{t}_{name}"
+                if key in g.files:
+                    ref = g[key]
+                    got = o.probe(name)
+                    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+                    assert np.abs(got - ref).max() < 3e-5 * max(1.0, float(np.abs(ref).max())), (t, name)
+            # coefs: reference [D][10] (f, 2n+p) vs probe [O][D][2]
+            ck = g[f"f{t}_coefs_fk"].reshape(96, 5, 2).transpose(1, 0, 2).reshape(-1)
+            assert np.abs(o.probe("coefs") - ck).max() < 3e-5 * max(1.0, float(np.abs(ck).max()))
+    scale = float(np.abs(g["spec_e_head"]).max())
+    assert np.abs(out[:64] - g["spec_e_head"]).max() < 1e-5 * scale
+    assert np.abs(st - g["state_out"]).max() < 1e-4
+
+
+def test_enhance_waveform_within_budget(case):
+    """north_star tolerance: waveform RMS error < 1e-4 vs the reference (we get ~1e-7)."""
+    g, meta, o = case
+    wav = g["wav"]
+    for key, db in (("enhanced", None), ("enhanced_attn0", 0.0), ("enhanced_attn12", 12.0)):
+        err = rms(o.enhance(wav, db) - g[key])
+        assert err < 1e-6, (key, err)
+    # reference quirk: the last 2 hops of the output are exactly zero
+    enh = o.enhance(wav)
+    assert np.all(enh[-o.win_len:] == 0.0)
+
+
+def test_constants_match_reference():
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import parse_manifest_text, synth_blob
+    C = np.load(GOLDEN / "constants.npz")
+    sizes = json.loads(bytes(C["state_sizes_json"]).decode())
+    for key, s in sizes.items():
+        sr, nb = (int(x) for x in key.split("_"))
+        blob = synth_blob(parse_manifest_text(orc.manifest_text(sr, nb)), 1)
+        o = orc.Oracle(sr, nb, blob)
+        assert o.state_size == s, key
+        if sr == 16000:
+            np.testing.assert_array_equal(np.array(o.erb_widths()), C["erb_widths_16k"])
+            np.testing.assert_allclose(o.window(), C["window_320"], atol=1e-7)
+            np.testing.assert_allclose(o.window(), C["pkg_window_320"], atol=1e-7)
+            st = o.initial_state()
+            np.testing.assert_array_equal(st[:32], C["erb_norm_init_16k"])
+            np.testing.assert_array_equal(st[32:128], C["spec_norm_init_16k"])
+        else:
+            np.testing.assert_allclose(o.window(), C["window_960"], atol=1e-7)
+
+
+def test_oracle_attn_limit_known_answers():
+    """apply_attn_limit known answers produced by the reference function (host_dsp.npz)."""
+    from oracle import oracle as orc
+    H = np.load(GOLDEN / "host_dsp.npz")
+    noisy, enh = H["noisy"][0], H["enh"][0]
+    np.testing.assert_allclose(orc.Oracle.attn_limit(noisy, enh, 0.0), H["attn0"][0], atol=1e-7)
+    np.testing.assert_allclose(orc.Oracle.attn_limit(noisy, enh, 6.0), H["attn6"][0], atol=1e-6)
+    np.testing.assert_array_equal(orc.Oracle.attn_limit(noisy, enh, float("inf")), H["attn_inf"][0])
+    np.testing.assert_array_equal(orc.Oracle.attn_limit(noisy, enh, float("nan")), H["attn_none"][0])
