@@ -129,7 +129,7 @@ struct SepConvW { size_t dw, pwfrag, bias; int nsub; };        // arena offsets
 struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs; };
 struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
-struct Gru256W { size_t ih_frag, ih_bias, hh_frag, b_hn; };
+struct Gru256W { size_t ih_frag, ih_bias, hh_frag, b_hn; };   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b; };
 
 }  // namespace
@@ -175,6 +175,8 @@ struct dpdf_model {
     std::vector<float> erb_norm_init, spec_norm_init;
     float* d_init_state = nullptr;     // [S]
     int chunk_frames = 0;
+    unsigned long long* gru_xbuf = nullptr; int gru_xbuf_tiles = 0; unsigned gru_epoch = 0; int* d_err = nullptr;
+    int use_gru256_cluster = 1;
     // prepared weights (arena offsets)
     size_t conv0_w, conv0_b;
     SepConvW erb_conv1, erb_conv2, erb_conv3, df_conv1, convt3, convt2, convt1;
@@ -400,6 +402,21 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
     return DPDF_OK;
 }
 
+int ensure_gru_xbuf(dpdf_model* m, int ntiles) {
+    if (ntiles <= m->gru_xbuf_tiles && m->gru_xbuf && m->d_err) return DPDF_OK;
+    if (m->gru_xbuf) { (void)hipStreamSynchronize(m->stream); (void)hipFree(m->gru_xbuf); m->gru_xbuf = nullptr; }
+    const size_t bytes = (size_t)ntiles * 2 * 16 * 256 * 8;
+    if (hipMalloc((void**)&m->gru_xbuf, bytes) != hipSuccess) { m->gru_xbuf_tiles = 0; return DPDF_E_RUNTIME; }
+    (void)hipMemsetAsync(m->gru_xbuf, 0, bytes, m->stream);
+    m->gru_epoch = 0;
+    m->gru_xbuf_tiles = ntiles;
+    if (!m->d_err) {
+        if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return DPDF_E_RUNTIME;
+        (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->stream);
+    }
+    return DPDF_OK;
+}
+
 template <int NT, int KP>
 void run_gl(dpdf_model* m, const GlW& g, const float* in, size_t lda, float* out, size_t ldo, int M, int act) {
     PlainA<KP> ap{in, lda, g.Ig, g.Ig};
@@ -427,8 +444,19 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
     }
     {
         ProfScope ps(m, "gru256_scan");
-        Gru256Args a{m->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
-        hipLaunchKernelGGL(gru256_scan_kernel, dim3((B + 15) / 16), dim3(1024), 0, m->stream, a);
+        const int ntiles = (B + 15) / 16;
+        if (m->use_gru256_cluster && ensure_gru_xbuf(m, ntiles) == DPDF_OK) {
+            if (m->gru_epoch > 0xF0000000u) {     // epoch wrap: re-zero the granules (once per ~4e9 steps)
+                (void)hipMemsetAsync(m->gru_xbuf, 0, (size_t)m->gru_xbuf_tiles * 2 * 16 * 256 * 8, m->stream);
+                m->gru_epoch = 0;
+            }
+            Gru256CArgs a{m->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc, m->gru_xbuf, m->gru_epoch, m->d_err};
+            m->gru_epoch += (unsigned)Tc;
+            hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->stream, a);
+        } else {
+            Gru256Args a{m->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
+            hipLaunchKernelGGL(gru256_scan_kernel, dim3(ntiles), dim3(1024), 0, m->stream, a);
+        }
     }
 }
 
@@ -816,6 +844,8 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     for (DevBuf* b : bufs) b->release();
     if (m->consts) (void)hipFree(m->consts);
     if (m->iconsts) (void)hipFree(m->iconsts);
+    if (m->gru_xbuf) (void)hipFree(m->gru_xbuf);
+    if (m->d_err) (void)hipFree(m->d_err);
     if (m->d_init_state) (void)hipFree(m->d_init_state);
     for (hipEvent_t e : m->prof_events) if (e) (void)hipEventDestroy(e);
     if (m->ev0) (void)hipEventDestroy(m->ev0);

@@ -214,3 +214,139 @@ __global__ __launch_bounds__(1024) void gru256_scan_kernel(Gru256Args a) {
     for (int i = 0; i < 4; ++i)
         if (ok[i]) a.hstate[(long)rc[i] * a.h_stride + 16 * w + cl] = h_own[i];
 }
+
+// ---------------------------------------------------------------------------------------------
+// gru256_cluster_kernel: the same recurrence spread over a CLUSTER of 4 workgroups per 16-row tile
+// so that W_hh never moves: workgroup j of a cluster owns hidden units [64j, 64j+64) of all three
+// gates; each of its 4 waves keeps its 16 units' W_hh slice (3 x 256 x 16 floats = 192 VGPRs) in
+// registers for the whole scan (one wave per SIMD).  Per step the only cross-workgroup traffic is
+// h' itself: 16 x 64 floats per workgroup, published as 8-byte {epoch, value} granules with
+// write-through (sc1) agent-scope stores and swept by the three peers with relaxed agent-scope
+// loads -- the data IS the flag (MI355X_MICROARCH.md "handoff-1to1", cdna_hip_programming.md
+// Guideline 16 recipe R2): placement-independent, no fences, no separate flag.  Epochs grow
+// monotonically across launches (host-supplied base), so the granule buffer is never re-zeroed.
+// Two slots (step parity) suffice: a peer can only be one step ahead.
+struct Gru256CArgs {
+    const float* gi;       // [B*Tc][768]
+    float* out;            // [B*Tc][256]
+    const float* whh_frag; // [j 4][wave 4][gate 3][chunk 16][kb 4][lane 64]
+    const float* b_hn;     // [256]
+    float* hstate; long h_stride;
+    int B, Tc;
+    unsigned long long* xbuf;   // [tiles][2][16][256] granules
+    unsigned epoch_base;
+    int* err;                   // set to 1 on spin timeout
+};
+
+__global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
+    __shared__ __attribute__((aligned(16))) float Hs[2][16][260];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int cl = lane & 15, q = lane >> 4;
+    const int ntiles = gridDim.x >> 2;
+    int rt, j;
+    if ((ntiles & 7) == 0) {       // keep a cluster on one XCD (block b -> XCD b % 8): speed only
+        rt = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5);
+        j = (blockIdx.x >> 3) & 3;
+    } else {
+        rt = blockIdx.x >> 2; j = blockIdx.x & 3;
+    }
+    const int row0 = rt * 16;
+    const int u0 = 64 * j + 16 * w;            // first hidden unit of this wave
+
+    float wr[64], wz[64], wn[64];
+    {
+        const float* wf = a.whh_frag + ((size_t)(j * 4 + w) * 3) * 64 * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            wr[k] = wf[(size_t)(0 * 64 + k) * 64];
+            wz[k] = wf[(size_t)(1 * 64 + k) * 64];
+            wn[k] = wf[(size_t)(2 * 64 + k) * 64];
+        }
+    }
+    const float bhn = a.b_hn[u0 + cl];
+    int rc[4]; bool ok[4]; float h_own[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = row0 + q * 4 + i;
+        ok[i] = r < a.B;
+        rc[i] = ok[i] ? r : a.B - 1;
+        h_own[i] = a.hstate[(long)rc[i] * a.h_stride + u0 + cl];
+    }
+    // full h of the tile into LDS (every workgroup of the cluster reads the carried state itself)
+    for (int idx = tid; idx < 16 * 256; idx += 256) {
+        int r = idx >> 8, u = idx & 255;
+        int rr = row0 + r < a.B ? row0 + r : a.B - 1;
+        Hs[0][r][u] = a.hstate[(long)rr * a.h_stride + u];
+    }
+    __syncthreads();
+
+    unsigned long long* xb = a.xbuf + (size_t)rt * 2 * 16 * 256;
+    float gr[4], gz[4], gn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float* g = a.gi + ((size_t)rc[i] * a.Tc) * 768 + u0 + cl;
+        gr[i] = g[0]; gz[i] = g[256]; gn[i] = g[512];
+    }
+    int cur = 0;
+    for (int t = 0; t < a.Tc; ++t) {
+        f32x4 ar = {gr[0], gr[1], gr[2], gr[3]}, az = {gz[0], gz[1], gz[2], gz[3]};
+        f32x4 axn = {gn[0], gn[1], gn[2], gn[3]}, ahn = {bhn, bhn, bhn, bhn};
+        if (t + 1 < a.Tc) {        // prefetch next step's input projections (independent of h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* g = a.gi + ((size_t)rc[i] * a.Tc + t + 1) * 768 + u0 + cl;
+                gr[i] = g[0]; gz[i] = g[256]; gn[i] = g[512];
+            }
+        }
+        const float* hrow = &Hs[cur][cl][4 * q];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float4 h4 = *(const float4*)(hrow + 16 * c);
+            const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                ar = mfma16(hv[kb], wr[c * 4 + kb], ar);
+                az = mfma16(hv[kb], wz[c * 4 + kb], az);
+                ahn = mfma16(hv[kb], wn[c * 4 + kb], ahn);
+            }
+        }
+        const int nxt = cur ^ 1;
+        const unsigned epoch = a.epoch_base + (unsigned)t + 1u;
+        unsigned long long* slot = xb + (size_t)(t & 1) * 16 * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r = sigmoid_f(ar[i]);
+            float z = sigmoid_f(az[i]);
+            float n = tanh_f(axn[i] + r * ahn[i]);
+            float h = (1.0f - z) * n + z * h_own[i];
+            h_own[i] = h;
+            Hs[nxt][q * 4 + i][u0 + cl] = h;
+            __hip_atomic_store(slot + (q * 4 + i) * 256 + u0 + cl,
+                               ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(h),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok[i]) a.out[((size_t)rc[i] * a.Tc + t) * 256 + u0 + cl] = h;
+        }
+        // sweep the three peers' slices (3 x 16 rows x 64 units = 12 granules per thread)
+        if (t + 1 < a.Tc) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int idx = tid + 256 * k;
+                const int s = idx >> 10, r = (idx >> 6) & 15, u = 64 * ((j + 1 + s) & 3) + (idx & 63);
+                const unsigned long long* gp = slot + r * 256 + u;
+                unsigned long long x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while ((unsigned)(x >> 32) != epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1u << 22)) { *a.err = 1; break; }
+                }
+                Hs[nxt][r][u] = __uint_as_float((unsigned)x);
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ok[i]) a.hstate[(long)rc[i] * a.h_stride + u0 + cl] = h_own[i];
+}
