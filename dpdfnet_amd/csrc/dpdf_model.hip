@@ -566,8 +566,8 @@ int run_chunk(dpdf_model* m, const float* raw, size_t raw_clip_stride, int B, in
     {
         ProfScope ps(m, "enc_convs");
         Conv0ErbArgs ca{w.feat_erb.p, w.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
-        size_t total = (size_t)BT * d.Ec * 16;
-        hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ca);
+        size_t rows16 = ((size_t)BT * d.Ec + 15) / 16;
+        hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)std::min<size_t>(rows16, 8192)), dim3(256), 0, st, ca);
         run_dwconv_s(m, m->erb_conv1, e0v, e1v, B, Tc, d.s1);
         run_dwconv_s(m, m->erb_conv2, e1v, e2v, B, Tc, d.s2);
         run_dwconv_s(m, m->erb_conv3, e2v, e3v, B, Tc, d.s3);

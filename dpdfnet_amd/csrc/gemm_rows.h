@@ -1,5 +1,5 @@
 // gemm_rows.h -- the feed-forward workhorse: out[r, :] = epi(A[r, 0:K] . W[K, N]) for millions of
-// short rows (r = (clip, frame[, band]) ), K <= 336, N <= 768.  fp32 in / fp32 accumulate on the
+// short rows (r = (clip, frame[, band]) ), K <= 1008, N <= 768.  fp32 in / fp32 accumulate on the
 // CDNA4 matrix cores (v_mfma_f32_16x16x4_f32, bit-exact fp32 FMA chains).
 //
 //   * 256-thread workgroup = 4 wavefronts; a workgroup owns a 64-row tile, each wave 16 rows x
@@ -7,6 +7,9 @@
 //   * A is never read "as stored": an A-producer functor stages a [64 x KP] panel in LDS --
 //     this is where depthwise convs, sub-pixel upsampling, pathway convs, FIFO (time-halo)
 //     gathers, STFT framing/windowing are fused, so those intermediates never touch HBM.
+//     Producers are split into load() (global -> registers, issued BEFORE the MFMA block of the
+//     current panel) and store() (registers -> other LDS buffer, AFTER it): HBM latency of the
+//     next panel hides under the current panel's matrix work, one barrier per panel.
 //   * W is pre-packed on the host into MFMA B-fragment order ([group][chunk][tile][kb][lane]),
 //     so every weight load is one coalesced 256-byte wave transaction served from L2; small
 //     panels (K*NT*16 <= 128 VGPR) are hoisted into registers once per workgroup (PERSIST_B) and
@@ -14,6 +17,7 @@
 //   * The epilogue functor sees the accumulators in MFMA C layout (row = (lane>>4)*4+i,
 //     col = tile*16 + (lane&15)): bias/BN shift, activation, LayerNorm over the 64 channels
 //     (in-register butterfly over the 16 column lanes), residual add, scatter to halo'd tensors.
+//     Its prefetch() (residual / skip operands) is issued before the MFMA block as well.
 #pragma once
 #include "common.h"
 
@@ -35,19 +39,25 @@ struct RowMap {            // flat row r over (b, t, f): t in [0,Tc), f in [0,Fp
     }
 };
 
+struct NoRegs {};
+
 // ================================= A producers ================================================
-// fill(As, row0, kp, grp, M): stage rows [row0,row0+64) x K columns [kp, kp+KP) into As[64][KP+4].
+// load(R&, row0, kp, grp, M): issue the global loads of panel rows [row0,row0+64) x K cols [kp,kp+KP)
+// store(As, R&, row0, kp, grp, M): finish the computation and write As[64][KP+4]
 
 template <int KP>
 struct PlainA {            // A[r][k] = src[r*lda + grp*gstride + k], zero for k >= kmax or r >= M
     const float* src; size_t lda; int gstride; int kmax;
-    __device__ __forceinline__ void fill(float (*As)[KP + 4], int row0, int kp, int grp, int M) const {
-        constexpr int V = KP / 4;
-        for (int idx = threadIdx.x; idx < GEMM_BM * V; idx += 256) {
+    static constexpr int V = KP / 4, NI = (GEMM_BM * V + 255) / 256;
+    struct Regs { float4 v[NI]; };
+    __device__ __forceinline__ void load(Regs& R, int row0, int kp, int grp, int M) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
             int r = idx / V, c4 = (idx - r * V) * 4;
             int row = row0 + r, k = kp + c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < M) {
+            if (idx < GEMM_BM * V && row < M) {
                 const float* s = src + (size_t)row * lda + (size_t)grp * gstride + k;
                 if (k + 3 < kmax) v = *(const float4*)s;
                 else {
@@ -56,7 +66,15 @@ struct PlainA {            // A[r][k] = src[r*lda + grp*gstride + k], zero for k
                     if (k + 2 < kmax) v.z = s[2];
                 }
             }
-            *(float4*)&As[r][c4] = v;
+            R.v[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*As)[KP + 4], const Regs& R, int, int, int, int) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx / V, c4 = (idx - r * V) * 4;
+            if (idx < GEMM_BM * V) *(float4*)&As[r][c4] = R.v[i];
         }
     }
 };
@@ -67,23 +85,34 @@ template <int S>
 struct DwConvA {
     TView x; RowMap rm;    // rm.Fp = output bands; x.Fp = input bands
     const float* dw;       // [64][3]
-    __device__ __forceinline__ void fill(float (*As)[64 + 4], int row0, int kp, int grp, int M) const {
-        for (int idx = threadIdx.x; idx < GEMM_BM * 16; idx += 256) {
+    struct Regs { float4 v[4][3]; };
+    __device__ __forceinline__ void load(Regs& R, int row0, int, int, int M) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = threadIdx.x + i * 256;
             int r = idx >> 4, c4 = (idx & 15) * 4;
             int row = row0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < M) {
-                int b, t, fo; rm.split(row, b, t, fo);
-                const float* xr = x.at(b, t, 0);
+            int b = 0, t = 0, fo = 0;
+            if (row < M) rm.split(row, b, t, fo);
+            const float* xr = x.at(b, t, 0);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    int fi = fo * S + j - 1;
-                    if (fi >= 0 && fi < x.Fp) {
-                        float4 xv = *(const float4*)(xr + (size_t)fi * 64 + c4);
-                        v.x += dw[(c4 + 0) * 3 + j] * xv.x; v.y += dw[(c4 + 1) * 3 + j] * xv.y;
-                        v.z += dw[(c4 + 2) * 3 + j] * xv.z; v.w += dw[(c4 + 3) * 3 + j] * xv.w;
-                    }
-                }
+            for (int j = 0; j < 3; ++j) {
+                int fi = fo * S + j - 1;
+                R.v[i][j] = (row < M && fi >= 0 && fi < x.Fp) ? *(const float4*)(xr + (size_t)fi * 64 + c4)
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float (*As)[64 + 4], const Regs& R, int, int, int, int) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx >> 4, c4 = (idx & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                v.x += dw[(c4 + 0) * 3 + j] * R.v[i][j].x; v.y += dw[(c4 + 1) * 3 + j] * R.v[i][j].y;
+                v.z += dw[(c4 + 2) * 3 + j] * R.v[i][j].z; v.w += dw[(c4 + 3) * 3 + j] * R.v[i][j].w;
             }
             *(float4*)&As[r][c4] = v;
         }
@@ -98,28 +127,47 @@ struct SubpixA {
     TView e, prev; RowMap rm;          // rm.Fp = output bands = e.Fp * S
     const float* ps; const float* pb;  // folded pathway scale / shift [64]
     const float* dw;                   // [S][64][3]
-    __device__ __forceinline__ void fill(float (*As)[64 + 4], int row0, int kp, int grp, int M) const {
-        for (int idx = threadIdx.x; idx < GEMM_BM * 16; idx += 256) {
+    struct Regs { float4 ev[4][3], pv[4][3]; };
+    __device__ __forceinline__ void load(Regs& R, int row0, int, int, int M) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx >> 4, c4 = (idx & 15) * 4;
+            int row = row0 + r;
+            int b = 0, t = 0, fo = 0;
+            if (row < M) rm.split(row, b, t, fo);
+            int f = fo / S;
+            const float* er = e.at(b, t, 0);
+            const float* pr = prev.at(b, t, 0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                int fi = f + j - 1;
+                bool okk = row < M && fi >= 0 && fi < e.Fp;
+                R.ev[i][j] = okk ? *(const float4*)(er + (size_t)fi * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                R.pv[i][j] = okk ? *(const float4*)(pr + (size_t)fi * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float (*As)[64 + 4], const Regs& R, int row0, int, int, int M) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = threadIdx.x + i * 256;
             int r = idx >> 4, c4 = (idx & 15) * 4;
             int row = row0 + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < M) {
-                int b, t, fo; rm.split(row, b, t, fo);
+                int fo = row % rm.Fp;
                 int f = fo / S, k = fo - f * S;
-                const float* er = e.at(b, t, 0);
-                const float* pr = prev.at(b, t, 0);
                 const float* w = dw + (size_t)k * 64 * 3;
                 float4 s4 = *(const float4*)(ps + c4), b4 = *(const float4*)(pb + c4);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     int fi = f + j - 1;
                     if (fi >= 0 && fi < e.Fp) {
-                        float4 ev = *(const float4*)(er + (size_t)fi * 64 + c4);
-                        float4 pv = *(const float4*)(pr + (size_t)fi * 64 + c4);
-                        float ux = fmaxf(s4.x * ev.x + b4.x, 0.f) + pv.x;
-                        float uy = fmaxf(s4.y * ev.y + b4.y, 0.f) + pv.y;
-                        float uz = fmaxf(s4.z * ev.z + b4.z, 0.f) + pv.z;
-                        float uw = fmaxf(s4.w * ev.w + b4.w, 0.f) + pv.w;
+                        float ux = fmaxf(s4.x * R.ev[i][j].x + b4.x, 0.f) + R.pv[i][j].x;
+                        float uy = fmaxf(s4.y * R.ev[i][j].y + b4.y, 0.f) + R.pv[i][j].y;
+                        float uz = fmaxf(s4.z * R.ev[i][j].z + b4.z, 0.f) + R.pv[i][j].z;
+                        float uw = fmaxf(s4.w * R.ev[i][j].w + b4.w, 0.f) + R.pv[i][j].w;
                         v.x += w[(c4 + 0) * 3 + j] * ux; v.y += w[(c4 + 1) * 3 + j] * uy;
                         v.z += w[(c4 + 2) * 3 + j] * uz; v.w += w[(c4 + 3) * 3 + j] * uw;
                     }
@@ -132,25 +180,33 @@ struct SubpixA {
 
 // df_conv0 front half: GroupedConv2D(2 groups, 1->32 each, k(3,3)) over the last 3 frames of
 // feat_spec (reference onnx_model/layers.py:1083-1114, dpdfnet.py:94-101); K = 64.
+// Thread = one output channel (its 9 taps live in registers) x 16 rows; the 9 feature reads per
+// row are wave-uniform (broadcast) and L1-resident, so nothing is staged through registers.
 struct Conv0DfA {
     const float* fs;       // feat_spec [B][2+Tc][2][D]
     int Tt, D; RowMap rm;  // rm.Fp = D
     const float* w;        // [64][9]
-    __device__ __forceinline__ void fill(float (*As)[64 + 4], int row0, int kp, int grp, int M) const {
-        for (int idx = threadIdx.x; idx < GEMM_BM * 64; idx += 256) {
-            int r = idx >> 6, c = idx & 63;
-            int row = row0 + r;
+    using Regs = NoRegs;
+    __device__ __forceinline__ void load(Regs&, int, int, int, int) const {}
+    __device__ __forceinline__ void store(float (*As)[64 + 4], const Regs&, int row0, int, int, int M) const {
+        const int c = threadIdx.x & 63, g = c >> 5;
+        float wk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int r = (threadIdx.x >> 6) + 4 * i;
+            const int row = row0 + r;
             float v = 0.f;
             if (row < M) {
                 int b, t, f; rm.split(row, b, t, f);
-                int g = c >> 5;
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt) {
                     const float* src = fs + (((size_t)b * Tt + t + kt) * 2 + g) * D;   // frame t-2+kt (+halo 2)
 #pragma unroll
                     for (int kf = 0; kf < 3; ++kf) {
                         int fi = f + kf - 1;
-                        if (fi >= 0 && fi < D) v += w[c * 9 + kt * 3 + kf] * src[fi];
+                        if (fi >= 0 && fi < D) v += wk[kt * 3 + kf] * src[fi];
                     }
                 }
             }
@@ -162,9 +218,12 @@ struct Conv0DfA {
 // df_convp gather: A[(b,t,f)][kt*64 + c] = c0[b, t-4+kt, f, c]  (K = 5*64, panel kp/64 = kt)
 struct ConvpA {
     TView c0; RowMap rm;   // c0.H = 4
-    __device__ __forceinline__ void fill(float (*As)[64 + 4], int row0, int kp, int grp, int M) const {
+    struct Regs { float4 v[4]; };
+    __device__ __forceinline__ void load(Regs& R, int row0, int kp, int, int M) const {
         const int kt = kp >> 6;
-        for (int idx = threadIdx.x; idx < GEMM_BM * 16; idx += 256) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = threadIdx.x + i * 256;
             int r = idx >> 4, c4 = (idx & 15) * 4;
             int row = row0 + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -172,7 +231,14 @@ struct ConvpA {
                 int b, t, f; rm.split(row, b, t, f);
                 v = *(const float4*)(c0.at(b, t - 4 + kt, f) + c4);
             }
-            *(float4*)&As[r][c4] = v;
+            R.v[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*As)[64 + 4], const Regs& R, int, int, int, int) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = threadIdx.x + i * 256;
+            *(float4*)&As[idx >> 4][(idx & 15) * 4] = R.v[i];
         }
     }
 };
@@ -183,9 +249,13 @@ template <int KP>
 struct StftA {
     const float* wav; int N; int T; int win, hop; const float* window;
     int causal = 0;        // 1: frame t = x[t*hop : t*hop+win] (StreamEnhancer), no centre/reflect padding
-    __device__ __forceinline__ void fill(float (*As)[KP + 4], int row0, int kp, int grp, int M) const {
+    static constexpr int NI = GEMM_BM * KP / 256;
+    struct Regs { float v[NI]; };
+    __device__ __forceinline__ void load(Regs& R, int row0, int kp, int, int M) const {
         const int np_ = N + win;
-        for (int idx = threadIdx.x; idx < GEMM_BM * KP; idx += 256) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
             int r = idx / KP, k = idx - r * KP;
             int row = row0 + r;
             float v = 0.f;
@@ -200,19 +270,30 @@ struct StftA {
                 }
                 if (j < N && kk < win) v = wav[(size_t)b * N + j] * window[kk];
             }
-            As[r][k] = v;
+            R.v[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*As)[KP + 4], const Regs& R, int, int, int, int) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx / KP, k = idx - r * KP;
+            As[r][k] = R.v[i];
         }
     }
 };
 
 // ================================= epilogues ==================================================
-// call(acc, row0, lane, grp, M): acc[nt][i] = C[row0 + (lane>>4)*4 + i][nt*16 + (lane&15)]
+// prefetch(P&, row0, lane, grp, M) is issued before the MFMA block;
+// call(acc, P, row0, lane, grp, M): acc[nt][i] = C[row0 + (lane>>4)*4 + i][nt*16 + (lane&15)]
 
 template <int NT>
 struct BiasActStore {      // out[r*ldo + grp*gostride + col] = act(acc + bias[grp*gbstride + col]), col < N
     float* out; size_t ldo; int gostride; const float* bias; int gbstride; int N; int act;
     int ncol_total = 0;    // >0: also bound the global column grp*gostride+col (partial last group)
-    __device__ __forceinline__ void call(f32x4 (&acc)[NT], int row0, int lane, int grp, int M) const {
+    using Pref = NoRegs;
+    __device__ __forceinline__ void prefetch(Pref&, int, int, int, int) const {}
+    __device__ __forceinline__ void call(f32x4 (&acc)[NT], const Pref&, int row0, int lane, int grp, int M) const {
         const int cl = lane & 15, rq = (lane >> 4) * 4;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -232,8 +313,13 @@ struct BiasActStore {      // out[r*ldo + grp*gostride + col] = act(acc + bias[g
 // conv output (+folded BN shift, ReLU) into a halo'd [B][Tt][Fp][64] tensor
 struct BiasReluToView {
     TView o; RowMap rm; const float* bias;
-    __device__ __forceinline__ void call(f32x4 (&acc)[4], int row0, int lane, int grp, int M) const {
+    using Pref = NoRegs;
+    __device__ __forceinline__ void prefetch(Pref&, int, int, int, int) const {}
+    __device__ __forceinline__ void call(f32x4 (&acc)[4], const Pref&, int row0, int lane, int grp, int M) const {
         const int cl = lane & 15, rq = (lane >> 4) * 4;
+        float bv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bv[nt] = bias[nt * 16 + cl];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int row = row0 + rq + i;
@@ -241,10 +327,7 @@ struct BiasReluToView {
             int b, t, f; rm.split(row, b, t, f);
             float* dst = o.at(b, t, f);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                int col = nt * 16 + cl;
-                dst[col] = fmaxf(acc[nt][i] + bias[col], 0.f);
-            }
+            for (int nt = 0; nt < 4; ++nt) dst[nt * 16 + cl] = fmaxf(acc[nt][i] + bv[nt], 0.f);
         }
     }
 };
@@ -253,12 +336,23 @@ struct BiasReluToView {
 // fc_inter/ln_inter, reference onnx_model/layers.py:178-193).  Rows are contiguous [M][64].
 struct LnResStore {
     float* out; const float* res; const float* bias; const float* g; const float* be;
-    __device__ __forceinline__ void call(f32x4 (&acc)[4], int row0, int lane, int grp, int M) const {
+    struct Pref { float r[4][4]; };
+    __device__ __forceinline__ void prefetch(Pref& P, int row0, int lane, int, int M) const {
         const int cl = lane & 15, rq = (lane >> 4) * 4;
-        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = row0 + rq + i;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) P.r[nt][i] = row < M ? res[(size_t)row * 64 + nt * 16 + cl] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void call(f32x4 (&acc)[4], const Pref& P, int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+        float v[4][4], gg[4], bb[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             float bv = bias[nt * 16 + cl];
+            gg[nt] = g[nt * 16 + cl]; bb[nt] = be[nt * 16 + cl];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[nt][i] = acc[nt][i] + bv;
         }
@@ -277,9 +371,8 @@ struct LnResStore {
             if (row < M) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    int col = nt * 16 + cl;
-                    float y = (v[nt][i] - mean) * inv * g[col] + be[col];
-                    out[(size_t)row * 64 + col] = res[(size_t)row * 64 + col] + y;
+                    float y = (v[nt][i] - mean) * inv * gg[nt] + bb[nt];
+                    out[(size_t)row * 64 + nt * 16 + cl] = P.r[nt][i] + y;
                 }
             }
         }
@@ -292,7 +385,16 @@ struct ConvpEpi {
     float* coefs; int Tt; RowMap rm;   // coefs [B][2+Tc][D][10], halo 2
     const float* dfo;                  // [B*Tc][D*10]
     const float* bias;
-    __device__ __forceinline__ void call(f32x4 (&acc)[1], int row0, int lane, int grp, int M) const {
+    struct Pref { float d[4]; };
+    __device__ __forceinline__ void prefetch(Pref& P, int row0, int lane, int, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = row0 + rq + i;
+            P.d[i] = (cl < 10 && row < M) ? dfo[(size_t)row * 10 + cl] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void call(f32x4 (&acc)[1], const Pref& P, int row0, int lane, int grp, int M) const {
         const int cl = lane & 15, rq = (lane >> 4) * 4;
         if (cl >= 10) return;
         float bv = bias[cl];
@@ -301,7 +403,7 @@ struct ConvpEpi {
             int row = row0 + rq + i;
             if (row >= M) continue;
             int b, t, f; rm.split(row, b, t, f);
-            float v = fmaxf(acc[0][i] + bv, 0.f) + dfo[(size_t)row * 10 + cl];
+            float v = fmaxf(acc[0][i] + bv, 0.f) + P.d[i];
             coefs[((((size_t)b * Tt + 2 + t) * rm.Fp) + f) * 10 + cl] = v;
         }
     }
@@ -311,7 +413,9 @@ struct ConvpEpi {
 template <int NT>
 struct WindowStore {
     float* out; int win; const float* window;
-    __device__ __forceinline__ void call(f32x4 (&acc)[NT], int row0, int lane, int grp, int M) const {
+    using Pref = NoRegs;
+    __device__ __forceinline__ void prefetch(Pref&, int, int, int, int) const {}
+    __device__ __forceinline__ void call(f32x4 (&acc)[NT], const Pref&, int row0, int lane, int grp, int M) const {
         const int cl = lane & 15, rq = (lane >> 4) * 4;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -332,50 +436,65 @@ struct WindowStore {
 template <int NT, int KP, bool PERSIST_B, class AProd, class Epi>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(AProd ap, const float* __restrict__ wfrag, Epi ep,
                                                         int M, int K) {
-    __shared__ __attribute__((aligned(16))) float As[GEMM_BM][KP + 4];
+    __shared__ __attribute__((aligned(16))) float As[2][GEMM_BM][KP + 4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int grp = blockIdx.y;
-    const int nchunks = K / 16;
+    const int nchunks = K / 16, npanels = K / KP;
     const float* wf = wfrag + (size_t)grp * nchunks * NT * 256 + lane;
     const int ntiles = (M + GEMM_BM - 1) / GEMM_BM;
-    constexpr int PB = PERSIST_B ? (KP / 16) * NT * 4 : 1;
+    constexpr int PB = (KP / 16) * NT * 4;
     float breg[PB];
     if (PERSIST_B) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) breg[i] = wf[(size_t)i * 64];
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        f32x4 acc[NT];
+    int tile = blockIdx.x, panel = 0, cur = 0;
+    if (tile >= ntiles) return;
+    typename AProd::Regs R;
+    ap.load(R, tile * GEMM_BM, 0, grp, M);
+    ap.store(As[0], R, tile * GEMM_BM, 0, grp, M);
+    __syncthreads();
+    f32x4 acc[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int kp = 0; kp < K; kp += KP) {
-            __syncthreads();
-            ap.fill(As, tile * GEMM_BM, kp, grp, M);
-            __syncthreads();
-            const float* arow = &As[wave * 16 + (lane & 15)][(lane >> 4) * 4];
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    while (true) {
+        // next (tile, panel) in the flattened sequence
+        int ntile = tile, npanel = panel + 1;
+        if (npanel == npanels) { npanel = 0; ntile = tile + gridDim.x; }
+        const bool has_next = ntile < ntiles;
+        if (!PERSIST_B) {
+            // this panel's B fragments first: vmcnt retires in order, so the A prefetch issued after
+            // them stays in flight while the MFMA block waits only for these L2-resident loads
+            const float* wp = wf + (size_t)panel * PB * 64;
 #pragma unroll
-            for (int c = 0; c < KP / 16; ++c) {
-                float4 a4 = *(const float4*)(arow + c * 16);
+            for (int i = 0; i < PB; ++i) breg[i] = wp[(size_t)i * 64];
+        }
+        if (has_next) ap.load(R, ntile * GEMM_BM, npanel * KP, grp, M);
+        typename Epi::Pref P;
+        const bool last_panel = panel == npanels - 1;
+        if (last_panel) ep.prefetch(P, tile * GEMM_BM + wave * 16, lane, grp, M);
+        const float* arow = &As[cur][wave * 16 + (lane & 15)][(lane >> 4) * 4];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (PERSIST_B) {
-                        const int bi = (c * NT + nt) * 4;
-                        acc[nt] = mfma16(a4.x, breg[bi + 0], acc[nt]);
-                        acc[nt] = mfma16(a4.y, breg[bi + 1], acc[nt]);
-                        acc[nt] = mfma16(a4.z, breg[bi + 2], acc[nt]);
-                        acc[nt] = mfma16(a4.w, breg[bi + 3], acc[nt]);
-                    } else {
-                        const float* wp = wf + ((size_t)((kp / 16 + c) * NT + nt) * 4) * 64;
-                        float b0 = wp[0], b1 = wp[64], b2 = wp[128], b3 = wp[192];
-                        acc[nt] = mfma16(a4.x, b0, acc[nt]);
-                        acc[nt] = mfma16(a4.y, b1, acc[nt]);
-                        acc[nt] = mfma16(a4.z, b2, acc[nt]);
-                        acc[nt] = mfma16(a4.w, b3, acc[nt]);
-                    }
-                }
+        for (int c = 0; c < KP / 16; ++c) {
+            float4 a4 = *(const float4*)(arow + c * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int bi = (c * NT + nt) * 4;
+                acc[nt] = mfma16(a4.x, breg[bi + 0], acc[nt]);
+                acc[nt] = mfma16(a4.y, breg[bi + 1], acc[nt]);
+                acc[nt] = mfma16(a4.z, breg[bi + 2], acc[nt]);
+                acc[nt] = mfma16(a4.w, breg[bi + 3], acc[nt]);
             }
         }
-        ep.call(acc, tile * GEMM_BM + wave * 16, lane, grp, M);
+        if (last_panel) {
+            ep.call(acc, P, tile * GEMM_BM + wave * 16, lane, grp, M);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (!has_next) break;
+        ap.store(As[cur ^ 1], R, ntile * GEMM_BM, npanel * KP, grp, M);
+        __syncthreads();
+        cur ^= 1; tile = ntile; panel = npanel;
     }
 }
 

@@ -103,31 +103,34 @@ struct Conv0ErbArgs {
     int B, Tc, E, Ec;
 };
 __global__ __launch_bounds__(256) void conv0_erb_kernel(Conv0ErbArgs a) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // (row, c4)
-    const size_t total = (size_t)a.B * a.Tc * a.Ec * 16;
-    if (idx >= total) return;
-    const int c4 = (int)(idx & 15) * 4;
-    const size_t row = idx >> 4;
-    const int f = (int)(row % a.Ec);
-    const size_t bt = row / a.Ec;
-    const int b = (int)(bt / a.Tc), t = (int)(bt - (size_t)b * a.Tc);
-    float4 acc = *(const float4*)(a.bias + c4);
+    // thread = 4 output channels (their 36 taps + bias in registers) x a strided set of rows
+    const int c4 = (threadIdx.x & 15) * 4;
+    float w[4][9]; 
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-        const float* src = a.feat + ((size_t)b * (a.Tc + 2) + t + kt) * a.E;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int kf = 0; kf < 3; ++kf) {
-            int fi = f + kf - 1;
-            if (fi >= 0 && fi < a.Ec) {
-                float x = src[fi];
-                int k = kt * 3 + kf;
-                acc.x += a.w[(c4 + 0) * 9 + k] * x; acc.y += a.w[(c4 + 1) * 9 + k] * x;
-                acc.z += a.w[(c4 + 2) * 9 + k] * x; acc.w += a.w[(c4 + 3) * 9 + k] * x;
+        for (int k = 0; k < 9; ++k) w[j][k] = a.w[(c4 + j) * 9 + k];
+    const float4 bias = *(const float4*)(a.bias + c4);
+    const size_t rows = (size_t)a.B * a.Tc * a.Ec;
+    for (size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < rows; row += (size_t)gridDim.x * 16) {
+        const int f = (int)(row % a.Ec);
+        const size_t bt = row / a.Ec;
+        const int b = (int)(bt / a.Tc), t = (int)(bt - (size_t)b * a.Tc);
+        float4 acc = bias;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            const float* src = a.feat + ((size_t)b * (a.Tc + 2) + t + kt) * a.E;
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) {
+                int fi = f + kf - 1;
+                float x = (fi >= 0 && fi < a.Ec) ? src[fi] : 0.f;
+                acc.x += w[0][kt * 3 + kf] * x; acc.y += w[1][kt * 3 + kf] * x;
+                acc.z += w[2][kt * 3 + kf] * x; acc.w += w[3][kt * 3 + kf] * x;
             }
         }
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        *(float4*)(a.e0 + row * 64 + c4) = acc;
     }
-    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-    *(float4*)(a.e0 + row * 64 + c4) = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
