@@ -151,12 +151,27 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// Tensors that cross from stage 1 (features, encoder convs, DPRNNs) to stage 2 (embedding GRUs,
+// decoders, mask, deep filter).  Double-buffered by chunk parity so that stage 2 of chunk i runs on
+// its own HIP stream underneath stage 1 of chunk i+1.
+struct XSet {
+    DevBuf xs, e0, e1, e2, e3, xe_a, xe_b, c0, c1, xd_a, xd_b;
+    const float* e3d = nullptr; const float* c1d = nullptr;
+    void release() {
+        DevBuf* all[] = {&xs, &e0, &e1, &e2, &e3, &xe_a, &xe_b, &c0, &c1, &xd_a, &xd_b};
+        for (DevBuf* b : all) b->release();
+    }
+};
 struct Workspace {
     int Bcap = 0, Tcap = 0;
-    DevBuf xs, feat_erb, feat_spec, e0, e1, e2, e3, xe_a, xe_b, c0, c1, xd_a, xd_b, hcat, hin;
+    XSet x[2];
+    // stage-1 temporaries (DF branch on the main stream, ERB branch on its own stream)
+    DevBuf feat_erb, feat_spec, hcat, hin, hcat_e, hin_e;
+    // stage-2 temporaries
     DevBuf embin, g256a, g256b, g256c, gi, emb, demb, demb2, d3, d2, d1, m, dfo, coefs, xm;
     void release() {
-        DevBuf* all[] = {&xs, &feat_erb, &feat_spec, &e0, &e1, &e2, &e3, &xe_a, &xe_b, &c0, &c1, &xd_a, &xd_b, &hcat, &hin,
+        x[0].release(); x[1].release();
+        DevBuf* all[] = {&feat_erb, &feat_spec, &hcat, &hin, &hcat_e, &hin_e,
                          &embin, &g256a, &g256b, &g256c, &gi, &emb, &demb, &demb2, &d3, &d2, &d1, &m, &dfo, &coefs, &xm};
         for (DevBuf* b : all) b->release();
         Bcap = Tcap = 0;
@@ -168,7 +183,13 @@ struct ProfEntry { double ms = 0; long calls = 0; };
 struct dpdf_model {
     dpdf_cfg cfg; dpdf_dims d; dpdf_state_layout L;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // main stream: stage 1, DF branch; I/O
+    hipStream_t stream_b = nullptr;    // stage 2 (latency-bound GRU-256 scans, decoders)
+    hipStream_t stream_c = nullptr;    // stage 1, ERB branch
+    hipStream_t cur = nullptr;         // stream the helper launchers enqueue on
+    hipEvent_t ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr;
+    bool s2_pending[2] = {false, false};
+    int overlap = 1;                   // 0: everything on the main stream (debug / A-B timing)
     std::mutex mu;
     float* consts = nullptr;           // device arena
     int* iconsts = nullptr;            // band_start[33] | band_of[F]
@@ -197,7 +218,7 @@ struct dpdf_model {
     std::vector<hipEvent_t> prof_events; int prof_used = 0;
     std::vector<std::pair<const char*, int>> prof_pending;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; int dbg_B = 0, dbg_Tc = 0;
+    const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
     const float* C(size_t off) const { return consts + off; }
 };
 
@@ -222,11 +243,11 @@ struct ProfScope {
             for (size_t i = old; i < m->prof_events.size(); ++i) (void)hipEventCreate(&m->prof_events[i]);
         }
         idx = m->prof_used; m->prof_used += 2;
-        (void)hipEventRecord(m->prof_events[idx], m->stream);
+        (void)hipEventRecord(m->prof_events[idx], m->cur);
     }
     ~ProfScope() {
         if (idx < 0) return;
-        (void)hipEventRecord(m->prof_events[idx + 1], m->stream);
+        (void)hipEventRecord(m->prof_events[idx + 1], m->cur);
         m->prof_pending.push_back({name, idx});
     }
 };
@@ -375,28 +396,32 @@ void erb_bands(int nfft, int fs, std::vector<int>& start, std::vector<int>& band
 
 int ensure_ws(dpdf_model* m, int B, int Tc) {
     Workspace& w = m->ws;
-    if (B <= w.Bcap && Tc <= w.Tcap && (size_t)B * Tc <= (size_t)w.Bcap * w.Tcap) {
-        // buffers are sized by products of B and (Tc + halo); reuse only for an exact fit class
-        if (B == w.Bcap && Tc == w.Tcap) return DPDF_OK;
-    }
+    if (B <= w.Bcap && Tc <= w.Tcap) return DPDF_OK;    // every size below is monotone in B and Tc
+    // growing: make sure nothing in flight still uses the old buffers
+    (void)hipStreamSynchronize(m->stream); (void)hipStreamSynchronize(m->stream_b); (void)hipStreamSynchronize(m->stream_c);
+    B = std::max(B, w.Bcap); Tc = std::max(Tc, w.Tcap);
     const dpdf_dims& d = m->d;
     const size_t BT = (size_t)B * Tc;
     int rc = DPDF_OK;
-#define ENS(buf, n) do { rc = w.buf.ensure(n); if (rc) return rc; } while (0)
-    ENS(xs, (size_t)B * (Tc + 2) * d.F * 2);
-    ENS(feat_erb, (size_t)B * (Tc + 2) * d.E);
-    ENS(feat_spec, (size_t)B * (Tc + 2) * 2 * d.D);
-    ENS(e0, BT * d.Ec * 64); ENS(e1, BT * d.F1 * 64); ENS(e2, BT * d.F2 * 64); ENS(e3, BT * d.F3 * 64);
-    ENS(xe_a, BT * d.F3 * 64); ENS(xe_b, BT * d.F3 * 64);
-    ENS(c0, (size_t)B * (Tc + 4) * d.D * 64); ENS(c1, BT * d.Fd * 64);
-    ENS(xd_a, BT * d.Fd * 64); ENS(xd_b, BT * d.Fd * 64);
-    ENS(hcat, BT * d.Fd * 128); ENS(hin, BT * d.Fd * 64);
-    ENS(embin, BT * 1024); ENS(g256a, BT * 256); ENS(g256b, BT * 256); ENS(g256c, BT * 256);
-    ENS(gi, BT * 768); ENS(emb, BT * 512); ENS(demb, BT * 512);
-    ENS(demb2, BT * (size_t)d.F3 * 64);
-    ENS(d3, BT * d.F2 * 64); ENS(d2, BT * d.F1 * 64); ENS(d1, BT * d.Ec * 64);
-    ENS(m, BT * d.E); ENS(dfo, BT * d.D * 10);
-    ENS(coefs, (size_t)B * (Tc + 2) * d.D * 10); ENS(xm, (size_t)B * (Tc + 4) * d.F * 2);
+#define ENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
+    for (int k = 0; k < 2; ++k) {
+        XSet& x = w.x[k];
+        ENS(x.xs, (size_t)B * (Tc + 2) * d.F * 2);
+        ENS(x.e0, BT * d.Ec * 64); ENS(x.e1, BT * d.F1 * 64); ENS(x.e2, BT * d.F2 * 64); ENS(x.e3, BT * d.F3 * 64);
+        ENS(x.xe_a, BT * d.F3 * 64); ENS(x.xe_b, BT * d.F3 * 64);
+        ENS(x.c0, (size_t)B * (Tc + 4) * d.D * 64); ENS(x.c1, BT * d.Fd * 64);
+        ENS(x.xd_a, BT * d.Fd * 64); ENS(x.xd_b, BT * d.Fd * 64);
+    }
+    ENS(w.feat_erb, (size_t)B * (Tc + 2) * d.E);
+    ENS(w.feat_spec, (size_t)B * (Tc + 2) * 2 * d.D);
+    ENS(w.hcat, BT * d.Fd * 128); ENS(w.hin, BT * d.Fd * 64);
+    ENS(w.hcat_e, BT * d.F3 * 128); ENS(w.hin_e, BT * d.F3 * 64);
+    ENS(w.embin, BT * 1024); ENS(w.g256a, BT * 256); ENS(w.g256b, BT * 256); ENS(w.g256c, BT * 256);
+    ENS(w.gi, BT * 768); ENS(w.emb, BT * 512); ENS(w.demb, BT * 512);
+    ENS(w.demb2, BT * (size_t)d.F3 * 64);
+    ENS(w.d3, BT * d.F2 * 64); ENS(w.d2, BT * d.F1 * 64); ENS(w.d1, BT * d.Ec * 64);
+    ENS(w.m, BT * d.E); ENS(w.dfo, BT * d.D * 10);
+    ENS(w.coefs, (size_t)B * (Tc + 2) * d.D * 10); ENS(w.xm, (size_t)B * (Tc + 4) * d.F * 2);
 #undef ENS
     w.Bcap = B; w.Tcap = Tc;
     return DPDF_OK;
@@ -421,7 +446,7 @@ template <int NT, int KP>
 void run_gl(dpdf_model* m, const GlW& g, const float* in, size_t lda, float* out, size_t ldo, int M, int act) {
     PlainA<KP> ap{in, lda, g.Ig, g.Ig};
     BiasActStore<NT> ep{out, ldo, g.Og, m->C(g.bias), g.Og, g.Og, act};
-    launch_gemm_rows<NT, KP, false>(m->stream, ap, m->C(g.frag), ep, M, g.Ig, g.G);
+    launch_gemm_rows<NT, KP, false>(m->cur, ap, m->C(g.frag), ep, M, g.Ig, g.G);
 }
 void run_gl_auto(dpdf_model* m, const GlW& g, const float* in, size_t lda, float* out, size_t ldo, int M, int act) {
     if (g.NT == 1 && g.Ig % 32 == 0 && g.Ig != 64) run_gl<1, 32>(m, g, in, lda, out, ldo, M, act);
@@ -440,28 +465,28 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
         ProfScope ps(m, "gru256_proj");
         PlainA<64> ap{x, 256, 0, 256};
         BiasActStore<8> ep{m->ws.gi.p, 768, 128, m->C(g.ih_bias), 128, 128, ACT_NONE};
-        launch_gemm_rows<8, 64, false>(m->stream, ap, m->C(g.ih_frag), ep, M, 256, 6);
+        launch_gemm_rows<8, 64, false>(m->cur, ap, m->C(g.ih_frag), ep, M, 256, 6);
     }
     {
         ProfScope ps(m, "gru256_scan");
         const int ntiles = (B + 15) / 16;
         if (m->use_gru256_cluster && ensure_gru_xbuf(m, ntiles) == DPDF_OK) {
             if (m->gru_epoch > 0xF0000000u) {     // epoch wrap: re-zero the granules (once per ~4e9 steps)
-                (void)hipMemsetAsync(m->gru_xbuf, 0, (size_t)m->gru_xbuf_tiles * 2 * 16 * 256 * 8, m->stream);
+                (void)hipMemsetAsync(m->gru_xbuf, 0, (size_t)m->gru_xbuf_tiles * 2 * 16 * 256 * 8, m->cur);
                 m->gru_epoch = 0;
             }
             Gru256CArgs a{m->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc, m->gru_xbuf, m->gru_epoch, m->d_err};
             m->gru_epoch += (unsigned)Tc;
-            hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->stream, a);
+            hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->cur, a);
         } else {
             Gru256Args a{m->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
-            hipLaunchKernelGGL(gru256_scan_kernel, dim3(ntiles), dim3(1024), 0, m->stream, a);
+            hipLaunchKernelGGL(gru256_scan_kernel, dim3(ntiles), dim3(1024), 0, m->cur, a);
         }
     }
 }
 
 // DPRNN (reference onnx_model/layers.py:159-196, 278-302): x [B*Tc][Fp][64] -> same, in xa (uses xb as scratch)
-float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, float* xb, int Fp,
+float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, float* xb, float* hcat, float* hin, int Fp,
                  float* state, long S, int soff, int B, int Tc) {
     const int M = B * Tc * Fp;
     float* x = xa; float* y = xb;
@@ -470,35 +495,35 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
         {   // intra-band bi-GRU over frequency, h0 = 0
             ProfScope ps(m, Fp >= 48 ? "gru64_intra_df" : "gru64_intra_erb");
             Gru64Args a{};
-            a.x = x; a.out = m->ws.hcat.p; a.wfrag = m->C(w.intra.wfrag); a.bias = m->C(w.intra.bias); a.hstate = nullptr;
+            a.x = x; a.out = hcat; a.wfrag = m->C(w.intra.wfrag); a.bias = m->C(w.intra.bias); a.hstate = nullptr;
             a.nrows = B * Tc; a.nsteps = Fp; a.ndirs = 2; a.rdiv = 1;
             a.x_hi = (long)Fp * 64; a.x_lo = 0; a.x_step = 64;
             a.o_hi = (long)Fp * 128; a.o_lo = 0; a.o_step = 128; a.o_dir_off = 64;
-            hipLaunchKernelGGL(gru64_scan_kernel, dim3((a.nrows + 15) / 16, 2), dim3(256), 0, m->stream, a);
+            hipLaunchKernelGGL(gru64_scan_kernel, dim3((a.nrows + 15) / 16, 2), dim3(256), 0, m->cur, a);
         }
         {   // fc_intra + ln_intra + residual
             ProfScope ps(m, "dprnn_fc_ln");
-            PlainA<128> ap{m->ws.hcat.p, 128, 0, 128};
+            PlainA<128> ap{hcat, 128, 0, 128};
             LnResStore ep{y, x, m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b)};
-            launch_gemm_rows<4, 128, true>(m->stream, ap, m->C(w.fci_frag), ep, M, 128, 1);
+            launch_gemm_rows<4, 128, true>(m->cur, ap, m->C(w.fci_frag), ep, M, 128, 1);
         }
         std::swap(x, y);
         {   // inter-band GRUCell over time, one hidden state per band position
             ProfScope ps(m, Fp >= 48 ? "gru64_inter_df" : "gru64_inter_erb");
             Gru64Args a{};
-            a.x = x; a.out = m->ws.hin.p; a.wfrag = m->C(w.inter.wfrag); a.bias = m->C(w.inter.bias);
+            a.x = x; a.out = hin; a.wfrag = m->C(w.inter.wfrag); a.bias = m->C(w.inter.bias);
             a.hstate = state + soff + (long)bi * Fp * 64;
             a.nrows = B * Fp; a.nsteps = Tc; a.ndirs = 1; a.rdiv = Fp;
             a.x_hi = (long)Tc * Fp * 64; a.x_lo = 64; a.x_step = (long)Fp * 64;
             a.o_hi = a.x_hi; a.o_lo = 64; a.o_step = a.x_step; a.o_dir_off = 0;
             a.h_hi = S; a.h_lo = 64;
-            hipLaunchKernelGGL(gru64_scan_kernel, dim3((a.nrows + 15) / 16, 1), dim3(256), 0, m->stream, a);
+            hipLaunchKernelGGL(gru64_scan_kernel, dim3((a.nrows + 15) / 16, 1), dim3(256), 0, m->cur, a);
         }
         {
             ProfScope ps(m, "dprnn_fc_ln");
-            PlainA<64> ap{m->ws.hin.p, 64, 0, 64};
+            PlainA<64> ap{hin, 64, 0, 64};
             LnResStore ep{y, x, m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b)};
-            launch_gemm_rows<4, 64, true>(m->stream, ap, m->C(w.fce_frag), ep, M, 64, 1);
+            launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.fce_frag), ep, M, 64, 1);
         }
         std::swap(x, y);
     }
@@ -510,7 +535,7 @@ void run_dwconv(dpdf_model* m, const SepConvW& w, TView in, TView out, int B, in
     RowMap rm{Tc, out.Fp};
     DwConvA<S> ap{in, rm, m->C(w.dw)};
     BiasReluToView ep{out, rm, m->C(w.bias)};
-    launch_gemm_rows<4, 64, true>(m->stream, ap, m->C(w.pwfrag), ep, B * Tc * out.Fp, 64, 1);
+    launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.pwfrag), ep, B * Tc * out.Fp, 64, 1);
 }
 void run_dwconv_s(dpdf_model* m, const SepConvW& w, TView in, TView out, int B, int Tc, int stride) {
     if (stride == 1) run_dwconv<1>(m, w, in, out, B, Tc);
@@ -522,7 +547,7 @@ void run_subpix(dpdf_model* m, const SepConvW& w, const PathW& p, TView e, TView
     RowMap rm{Tc, out.Fp};
     SubpixA<S> ap{e, prev, rm, m->C(p.ps), m->C(p.pb), m->C(w.dw)};
     BiasReluToView ep{out, rm, m->C(w.bias)};
-    launch_gemm_rows<4, 64, true>(m->stream, ap, m->C(w.pwfrag), ep, B * Tc * out.Fp, 64, 1);
+    launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.pwfrag), ep, B * Tc * out.Fp, 64, 1);
 }
 void run_subpix_s(dpdf_model* m, const SepConvW& w, const PathW& p, TView e, TView prev, TView out, int B, int Tc, int s) {
     if (s == 1) run_subpix<1>(m, w, p, e, prev, out, B, Tc);
@@ -531,68 +556,119 @@ void run_subpix_s(dpdf_model* m, const SepConvW& w, const PathW& p, TView e, TVi
 }
 
 // ------------------------------------------------------------------------------------------------
-// one chunk of the frame function for B streams x Tc frames.
+// One chunk of the frame function for B streams x Tc frames, as a two-stage pipeline.
 //   raw:   unnormalised spec, frame t of clip b at raw + b*raw_clip_stride + t*F*2
 //   state: device [B][S] reference flat layout, updated in place
 //   out:   enhanced spec, frame (out_t0 + t) of clip b at out + b*out_clip_stride + ...
+// stage 1 (main stream; ERB branch forked onto stream_c): features, encoder convs, both DPRNNs.
+// stage 2 (stream_b): embedding GRU, both decoders, mask, deep filter -- mostly latency-bound
+//   256-wide GRU scans that occupy 64 of the 256 CUs, so stage 2 of chunk i runs UNDER stage 1 of
+//   chunk i+1.  The two stages touch disjoint segments of the flat state and disjoint temporaries;
+//   the tensors that cross (XSet) are double-buffered by chunk parity.
 // ------------------------------------------------------------------------------------------------
-int run_chunk(dpdf_model* m, const float* raw, size_t raw_clip_stride, int B, int Tc, float* state,
-              float* out, size_t out_clip_stride, int out_t0, const float* attn_raw, float alpha) {
-    int rc = ensure_ws(m, B, Tc);
-    if (rc) return rc;
-    const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L;
-    Workspace& w = m->ws;
-    hipStream_t st = m->stream;
-    const long S = d.state_size;
-    const int BT = B * Tc;
+struct ChunkArgs {
+    const float* raw; size_t raw_clip_stride; int B, Tc; float* state;
+    float* out; size_t out_clip_stride; int out_t0; const float* attn_raw; float alpha;
+    int parity;
+};
 
-    StateIoArgs sio{state, S, w.feat_erb.p, w.feat_spec.p, w.c0.p, w.xs.p, w.coefs.p, w.xm.p,
-                    L.erb_conv0_buf, L.df_conv0_buf, L.df_convp_buf, L.mask_buf, L.df_coefs_buf, L.df_spec_buf,
-                    B, Tc, d.E, d.D, d.F, 0};
+StateIoArgs make_sio(dpdf_model* m, const ChunkArgs& c, XSet& x) {
+    const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L; Workspace& w = m->ws;
+    return StateIoArgs{c.state, (long)d.state_size, w.feat_erb.p, w.feat_spec.p, x.c0.p, x.xs.p, w.coefs.p, w.xm.p,
+                       L.erb_conv0_buf, L.df_conv0_buf, L.df_convp_buf, L.mask_buf, L.df_coefs_buf, L.df_spec_buf,
+                       c.B, c.Tc, d.E, d.D, d.F, 0, 0, 0};
+}
+
+int run_stage1(dpdf_model* m, const ChunkArgs& c) {
+    const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L;
+    Workspace& w = m->ws; XSet& x = w.x[c.parity];
+    const int B = c.B, Tc = c.Tc, BT = B * Tc;
+    const long S = d.state_size;
+    float* state = c.state;
+    hipStream_t sA = m->stream, sC = m->overlap ? m->stream_c : m->stream;
+    m->cur = sA;
+    if (m->overlap && m->s2_pending[c.parity]) {      // stage 2 of chunk i-2 must be done with this XSet
+        HIP_TRY(hipStreamWaitEvent(sA, m->ev_s2[c.parity], 0));
+        m->s2_pending[c.parity] = false;
+    }
+    StateIoArgs sio = make_sio(m, c, x);
+    sio.seg_lo = 0; sio.seg_hi = 4;                    // erb_conv0 / df_conv0 / mask(spec) / df_convp FIFOs
     {
         ProfScope ps(m, "state_io");
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 6), dim3(256), 0, st, sio);
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 4), dim3(256), 0, sA, sio);
     }
     {
         ProfScope ps(m, "features");
-        FeatAArgs fa{raw, raw_clip_stride, w.xs.p, w.feat_erb.p, d.is48 ? nullptr : m->iconsts, B, Tc, d.F, d.E, d.is48, d.wnorm};
-        hipLaunchKernelGGL(feat_a_kernel, dim3(BT), dim3(256), 0, st, fa);
-        FeatBArgs fb{w.feat_erb.p, w.xs.p, w.feat_spec.p, state, S, L.erb_norm, L.spec_norm, B, Tc, d.F, d.E, d.D};
+        FeatAArgs fa{c.raw, c.raw_clip_stride, x.xs.p, w.feat_erb.p, d.is48 ? nullptr : m->iconsts, B, Tc, d.F, d.E, d.is48, d.wnorm};
+        hipLaunchKernelGGL(feat_a_kernel, dim3(BT), dim3(256), 0, sA, fa);
+        FeatBArgs fb{w.feat_erb.p, x.xs.p, w.feat_spec.p, state, S, L.erb_norm, L.spec_norm, B, Tc, d.F, d.E, d.D};
         int nth = ((d.E + d.D + 63) / 64) * 64;
-        hipLaunchKernelGGL(feat_b_kernel, dim3(B), dim3(nth), 0, st, fb);
+        hipLaunchKernelGGL(feat_b_kernel, dim3(B), dim3(nth), 0, sA, fb);
     }
-    // ---- encoder, ERB branch (reference onnx_model/dpdfnet.py:206-219) ----
-    TView e0v{w.e0.p, Tc, 0, d.Ec, 64}, e1v{w.e1.p, Tc, 0, d.F1, 64}, e2v{w.e2.p, Tc, 0, d.F2, 64}, e3v{w.e3.p, Tc, 0, d.F3, 64};
+    // ---- encoder, ERB branch (reference onnx_model/dpdfnet.py:206-219) on its own stream ----
+    if (sC != sA) { HIP_TRY(hipEventRecord(m->ev_fork, sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ev_fork, 0)); }
+    m->cur = sC;
+    TView e0v{x.e0.p, Tc, 0, d.Ec, 64}, e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
     {
-        ProfScope ps(m, "enc_convs");
-        Conv0ErbArgs ca{w.feat_erb.p, w.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
+        ProfScope ps(m, "enc_convs_erb");
+        Conv0ErbArgs ca{w.feat_erb.p, x.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
         size_t rows16 = ((size_t)BT * d.Ec + 15) / 16;
-        hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)std::min<size_t>(rows16, 8192)), dim3(256), 0, st, ca);
+        hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)std::min<size_t>(rows16, 8192)), dim3(256), 0, sC, ca);
         run_dwconv_s(m, m->erb_conv1, e0v, e1v, B, Tc, d.s1);
         run_dwconv_s(m, m->erb_conv2, e1v, e2v, B, Tc, d.s2);
         run_dwconv_s(m, m->erb_conv3, e2v, e3v, B, Tc, d.s3);
     }
-    float* e3d = w.e3.p;
+    x.e3d = x.e3.p;
     if (d.nb > 0) {
-        HIP_TRY(hipMemcpyAsync(w.xe_a.p, w.e3.p, (size_t)BT * d.F3 * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        e3d = run_dprnn(m, m->dprnn_erb, w.xe_a.p, w.xe_b.p, d.F3, state, S, L.dprnn_erb, B, Tc);
+        HIP_TRY(hipMemcpyAsync(x.xe_a.p, x.e3.p, (size_t)BT * d.F3 * 64 * sizeof(float), hipMemcpyDeviceToDevice, sC));
+        x.e3d = run_dprnn(m, m->dprnn_erb, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, d.F3, state, S, L.dprnn_erb, B, Tc);
     }
-    // ---- encoder, DF branch (dpdfnet.py:221-234) ----
-    TView c0v{w.c0.p, Tc + 4, 4, d.D, 64}, c1v{w.c1.p, Tc, 0, d.Fd, 64};
+    // ---- encoder, DF branch (dpdfnet.py:221-234) on the main stream ----
+    m->cur = sA;
+    TView c0v{x.c0.p, Tc + 4, 4, d.D, 64}, c1v{x.c1.p, Tc, 0, d.Fd, 64};
     {
-        ProfScope ps(m, "enc_convs");
+        ProfScope ps(m, "enc_convs_df");
         RowMap rm{Tc, d.D};
         Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm, m->C(m->dfc0_w)};
         BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
-        launch_gemm_rows<4, 64, true>(st, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 64, 1);
+        launch_gemm_rows<4, 64, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 64, 1);
         run_dwconv_s(m, m->df_conv1, c0v, c1v, B, Tc, 2);
     }
-    float* c1d = w.c1.p;
+    x.c1d = x.c1.p;
     if (d.nb > 0) {
-        HIP_TRY(hipMemcpyAsync(w.xd_a.p, w.c1.p, (size_t)BT * d.Fd * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        c1d = run_dprnn(m, m->dprnn_df, w.xd_a.p, w.xd_b.p, d.Fd, state, S, L.dprnn_df, B, Tc);
+        HIP_TRY(hipMemcpyAsync(x.xd_a.p, x.c1.p, (size_t)BT * d.Fd * 64 * sizeof(float), hipMemcpyDeviceToDevice, sA));
+        x.c1d = run_dprnn(m, m->dprnn_df, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, d.Fd, state, S, L.dprnn_df, B, Tc);
     }
-    m->dbg_e3d = e3d; m->dbg_c1d = c1d; m->dbg_B = B; m->dbg_Tc = Tc;
+    if (sC != sA) { HIP_TRY(hipEventRecord(m->ev_join, sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ev_join, 0)); }
+    {
+        ProfScope ps(m, "state_io");
+        sio.do_export = 1;
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 4), dim3(256), 0, sA, sio);
+    }
+    m->dbg_e3d = x.e3d; m->dbg_c1d = x.c1d; m->dbg_B = B; m->dbg_Tc = Tc; m->dbg_parity = c.parity;
+    HIP_TRY(hipEventRecord(m->ev_s1[c.parity], sA));
+    HIP_TRY(hipGetLastError());
+    return DPDF_OK;
+}
+
+int run_stage2(dpdf_model* m, const ChunkArgs& c) {
+    const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L;
+    Workspace& w = m->ws; XSet& x = w.x[c.parity];
+    const int B = c.B, Tc = c.Tc, BT = B * Tc;
+    const long S = d.state_size;
+    float* state = c.state;
+    hipStream_t st = m->overlap ? m->stream_b : m->stream;
+    m->cur = st;
+    if (st != m->stream) HIP_TRY(hipStreamWaitEvent(st, m->ev_s1[c.parity], 0));
+    StateIoArgs sio = make_sio(m, c, x);
+    sio.seg_lo = 4; sio.seg_hi = 6;                    // DF coefs delay / masked-spec FIFOs
+    {
+        ProfScope ps(m, "state_io");
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2), dim3(256), 0, st, sio);
+    }
+    const float* e3d = x.e3d; const float* c1d = x.c1d;
+    TView e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
+    TView c0v{x.c0.p, Tc + 4, 4, d.D, 64};
     // ---- embedding (dpdfnet.py:233-241; 48k hr.py:285-293).  channels-last [f][c] IS the (f,c) flatten ----
     {
         ProfScope ps(m, "grouped_linear");
@@ -624,7 +700,7 @@ int run_chunk(dpdf_model* m, const float* raw, size_t raw_clip_stride, int B, in
         run_subpix_s(m, m->convt3, m->conv3p, e3v, dembv, d3v, B, Tc, d.s3);
         run_subpix_s(m, m->convt2, m->conv2p, e2v, d3v, d2v, B, Tc, d.s2);
         run_subpix_s(m, m->convt1, m->conv1p, e1v, d2v, d1v, B, Tc, d.s1);
-        MaskOutArgs ma{w.e0.p, w.d1.p, w.m.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias,
+        MaskOutArgs ma{x.e0.p, w.d1.p, w.m.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias,
                        BT * d.Ec, d.Ec, d.E, d.is48};
         hipLaunchKernelGGL(mask_out_kernel, dim3((BT * d.Ec + 3) / 4), dim3(256), 0, st, ma);
     }
@@ -637,8 +713,7 @@ int run_chunk(dpdf_model* m, const float* raw, size_t raw_clip_stride, int B, in
     run_gru256(m, m->df_gru1, w.g256b.p, w.g256c.p, state, S, L.df_dec_gru + 256, B, Tc);
     {
         ProfScope ps(m, "grouped_linear");
-        // c = df_gru(emb) + df_skip(emb): accumulate the skip into g256c via a second pass
-        run_gl_auto(m, m->df_skip, w.emb.p, 512, w.g256a.p, 256, BT, ACT_NONE);
+        run_gl_auto(m, m->df_skip, w.emb.p, 512, w.g256a.p, 256, BT, ACT_NONE);   // c = df_gru(emb) + df_skip(emb)
     }
     {
         ProfScope ps(m, "df_coefs");
@@ -653,19 +728,39 @@ int run_chunk(dpdf_model* m, const float* raw, size_t raw_clip_stride, int B, in
     // ---- mask + deep filter (layers.py:414-445, multiframe.py:200-232) ----
     {
         ProfScope ps(m, "mask_df");
-        MaskApplyArgs mk{w.xs.p, w.m.p, w.xm.p, d.is48 ? nullptr : m->iconsts + 33, B, Tc, d.F, d.E};
+        MaskApplyArgs mk{x.xs.p, w.m.p, w.xm.p, d.is48 ? nullptr : m->iconsts + 33, B, Tc, d.F, d.E};
         size_t total = (size_t)BT * d.F;
         hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mk);
-        DfApplyArgs da{w.xm.p, w.coefs.p, out, out_clip_stride, out_t0, attn_raw, alpha, (float)(1.0 - (double)alpha),
+        DfApplyArgs da{w.xm.p, w.coefs.p, c.out, c.out_clip_stride, c.out_t0, c.attn_raw, c.alpha, (float)(1.0 - (double)c.alpha),
                        B, Tc, d.F, d.D, (float)(1.0 / (double)d.wnorm)};
         hipLaunchKernelGGL(df_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, da);
     }
     {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 6), dim3(256), 0, st, sio);
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2), dim3(256), 0, st, sio);
     }
+    if (st != m->stream) { HIP_TRY(hipEventRecord(m->ev_s2[c.parity], st)); m->s2_pending[c.parity] = true; }
     HIP_TRY(hipGetLastError());
+    m->cur = m->stream;
+    return DPDF_OK;
+}
+
+// all chunks of a [B][T] problem; on return every stream's work is ordered before the main stream
+int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T, float* state,
+               float* out, const float* attn_raw, float alpha) {
+    const int chunk = m->chunk_frames > 0 ? std::min(m->chunk_frames, T) : T;
+    int rc = ensure_ws(m, B, chunk);
+    if (rc) return rc;
+    int i = 0;
+    for (int t0 = 0; t0 < T; t0 += chunk, ++i) {
+        ChunkArgs c{raw + (size_t)t0 * m->d.F * 2, clip_stride, B, std::min(chunk, T - t0), state,
+                    out, clip_stride, t0, attn_raw, alpha, i & 1};
+        if ((rc = run_stage1(m, c)) || (rc = run_stage2(m, c))) return rc;
+    }
+    for (int p = 0; p < 2; ++p)
+        if (m->s2_pending[p]) { HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_s2[p], 0)); m->s2_pending[p] = false; }
+    m->cur = m->stream;
     return DPDF_OK;
 }
 
@@ -802,6 +897,15 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
 
     // ---- upload ----
     HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&m->stream_b, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&m->stream_c, hipStreamNonBlocking));
+    m->cur = m->stream;
+    for (int p = 0; p < 2; ++p) {
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_s1[p], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_s2[p], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&m->ev0)); HIP_TRY(hipEventCreate(&m->ev1));
     HIP_TRY(hipMalloc((void**)&m->consts, A.h.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(m->consts, A.h.data(), A.h.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -839,6 +943,8 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->stream_b) (void)hipStreamSynchronize(m->stream_b);
+    if (m->stream_c) (void)hipStreamSynchronize(m->stream_c);
     m->ws.release();
     DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state};
     for (DevBuf* b : bufs) b->release();
@@ -850,6 +956,11 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     for (hipEvent_t e : m->prof_events) if (e) (void)hipEventDestroy(e);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
+    for (int p = 0; p < 2; ++p) { if (m->ev_s1[p]) (void)hipEventDestroy(m->ev_s1[p]); if (m->ev_s2[p]) (void)hipEventDestroy(m->ev_s2[p]); }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->stream_b) (void)hipStreamDestroy(m->stream_b);
+    if (m->stream_c) (void)hipStreamDestroy(m->stream_c);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -886,6 +997,14 @@ extern "C" int dpdf_num_frames(const dpdf_model* m, int n) { return m ? 1 + (n +
 extern "C" int dpdf_set_chunk_frames(dpdf_model* m, int frames) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
     m->chunk_frames = frames;
+    return DPDF_OK;
+}
+extern "C" int dpdf_set_overlap(dpdf_model* m, int on) {
+    if (!m) return set_err(DPDF_E_INVALID, "null model");
+    std::lock_guard<std::mutex> lk(m->mu);
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream); (void)hipStreamSynchronize(m->stream_b); (void)hipStreamSynchronize(m->stream_c);
+    m->overlap = on != 0;
     return DPDF_OK;
 }
 extern "C" int dpdf_sync(dpdf_model* m) {
@@ -942,11 +1061,8 @@ extern "C" int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, f
         HIP_TRY(hipMemcpyAsync(m->io_state.p, state, nstate * sizeof(float), hipMemcpyHostToDevice, m->stream));
         d_spec = m->io_spec.p; d_state = m->io_state.p; d_out = m->io_spec_e.p;
     }
-    const size_t cs = (size_t)T * m->d.F * 2;
-    const int chunk = m->chunk_frames > 0 ? m->chunk_frames : T;
-    for (int t0 = 0; t0 < T; t0 += chunk) {
-        int tc = std::min(chunk, T - t0);
-        int rc = run_chunk(m, d_spec + (size_t)t0 * m->d.F * 2, cs, B, tc, d_state, d_out, cs, t0, nullptr, 0.f);
+    {
+        int rc = run_chunks(m, d_spec, (size_t)T * m->d.F * 2, B, T, d_state, d_out, nullptr, 0.f);
         if (rc) return rc;
     }
     if (host) {
@@ -998,14 +1114,9 @@ extern "C" int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N,
     // A2..A13: frame function over time chunks (+ attenuation limit fused in the DF kernel)
     const bool attn = std::isfinite(attn_limit_db);
     const float alpha = attn ? (float)std::pow(10.0, -(double)attn_limit_db / 20.0) : 0.f;
-    const size_t cs = (size_t)T * d.F * 2;
-    const int chunk = m->chunk_frames > 0 ? m->chunk_frames : T;
-    for (int t0 = 0; t0 < T; t0 += chunk) {
-        int tc = std::min(chunk, T - t0);
-        rc = run_chunk(m, m->raw_spec.p + (size_t)t0 * d.F * 2, cs, B, tc, m->batch_state.p, m->enh_spec.p, cs, t0,
-                       attn ? m->raw_spec.p : nullptr, alpha);
-        if (rc) return rc;
-    }
+    rc = run_chunks(m, m->raw_spec.p, (size_t)T * d.F * 2, B, T, m->batch_state.p, m->enh_spec.p,
+                    attn ? m->raw_spec.p : nullptr, alpha);
+    if (rc) return rc;
     // A14: synthesis
     {
         ProfScope ps(m, "istft");
@@ -1109,8 +1220,7 @@ extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_
         ep.ncol_total = 2 * d.F;
         launch_gemm_rows<7, 64, false>(m->stream, ap, m->C(m->stft_frag), ep, S * T, d.win, m->stft_groups);
     }
-    const size_t cs = (size_t)T * d.F * 2;
-    rc = run_chunk(m, s->spec.p, cs, S, T, s->state.p, s->spec_e.p, cs, 0, nullptr, 0.f);
+    rc = run_chunks(m, s->spec.p, (size_t)T * d.F * 2, S, T, s->state.p, s->spec_e.p, nullptr, 0.f);
     if (rc) return rc;
     {
         PlainA<48> ap{s->spec_e.p, (size_t)2 * d.F, 0, 2 * d.F};
@@ -1144,19 +1254,19 @@ extern "C" long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, l
     if (!m || !name) return -1;
     std::lock_guard<std::mutex> lk(m->mu);
     if (hipSetDevice(m->device) != hipSuccess) return -1;
-    const dpdf_dims& d = m->d; Workspace& w = m->ws;
+    const dpdf_dims& d = m->d; Workspace& w = m->ws; XSet& x = w.x[m->dbg_parity];
     const long B = m->dbg_B, Tc = m->dbg_Tc, BT = B * Tc;
     const float* src = nullptr; long n = 0;
     std::string s(name);
     if (s == "feat_erb") { src = w.feat_erb.p; n = B * (Tc + 2) * d.E; }
     else if (s == "feat_spec") { src = w.feat_spec.p; n = B * (Tc + 2) * 2 * d.D; }
-    else if (s == "e0") { src = w.e0.p; n = BT * d.Ec * 64; }
-    else if (s == "e1") { src = w.e1.p; n = BT * d.F1 * 64; }
-    else if (s == "e2") { src = w.e2.p; n = BT * d.F2 * 64; }
-    else if (s == "e3") { src = w.e3.p; n = BT * d.F3 * 64; }
+    else if (s == "e0") { src = x.e0.p; n = BT * d.Ec * 64; }
+    else if (s == "e1") { src = x.e1.p; n = BT * d.F1 * 64; }
+    else if (s == "e2") { src = x.e2.p; n = BT * d.F2 * 64; }
+    else if (s == "e3") { src = x.e3.p; n = BT * d.F3 * 64; }
     else if (s == "e3_dprnn") { src = m->dbg_e3d; n = BT * d.F3 * 64; }
-    else if (s == "c0") { src = w.c0.p; n = B * (Tc + 4) * d.D * 64; }
-    else if (s == "c1") { src = w.c1.p; n = BT * d.Fd * 64; }
+    else if (s == "c0") { src = x.c0.p; n = B * (Tc + 4) * d.D * 64; }
+    else if (s == "c1") { src = x.c1.p; n = BT * d.Fd * 64; }
     else if (s == "c1_dprnn") { src = m->dbg_c1d; n = BT * d.Fd * 64; }
     else if (s == "emb") { src = w.emb.p; n = BT * 512; }
     else if (s == "m") { src = w.m.p; n = BT * d.E; }

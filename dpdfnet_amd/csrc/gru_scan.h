@@ -34,7 +34,7 @@ struct Gru64Args {
     long h_hi, h_lo;
 };
 
-__global__ __launch_bounds__(256, 2) void gru64_scan_kernel(Gru64Args a) {
+__global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
     __shared__ __attribute__((aligned(16))) float Hs[2][16][68];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int dir = blockIdx.y;
@@ -58,46 +58,44 @@ __global__ __launch_bounds__(256, 2) void gru64_scan_kernel(Gru64Args a) {
 
     // --- row addressing ----------------------------------------------------------------------
     // A-operand view: this lane feeds row (row0 + cl); C view: rows row0 + q*4 + i
+    // Tile base is wave-uniform (64-bit, scalar); per-lane offsets are 32-bit deltas from it
+    // (a tile spans at most two `hi` groups, so deltas are bounded by one clip stride).
+    const int hi0 = row0 / a.rdiv, lo0 = row0 - hi0 * a.rdiv;
+    const float* xbase = a.x + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
+    float* obase = a.out + (long)hi0 * a.o_hi + (long)lo0 * a.o_lo + dir * a.o_dir_off;
     int ra = row0 + cl; if (ra >= a.nrows) ra = a.nrows - 1;
-    const long xa_base = (long)(ra / a.rdiv) * a.x_hi + (long)(ra % a.rdiv) * a.x_lo + 4 * q;
-    long oc_base[4]; bool oc_ok[4];
+    const int xa_off = (int)((long)(ra / a.rdiv - hi0) * a.x_hi + (long)(ra % a.rdiv - lo0) * a.x_lo) + 4 * q;
+    int oc_off[4]; bool oc_ok[4];
     float h_own[4];
-    float4 ha[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int rc = row0 + q * 4 + i;
         oc_ok[i] = rc < a.nrows;
         if (rc >= a.nrows) rc = a.nrows - 1;
-        oc_base[i] = (long)(rc / a.rdiv) * a.o_hi + (long)(rc % a.rdiv) * a.o_lo + dir * a.o_dir_off + 16 * w + cl;
-        h_own[i] = a.hstate ? a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] : 0.f;
+        oc_off[i] = (int)((long)(rc / a.rdiv - hi0) * a.o_hi + (long)(rc % a.rdiv - lo0) * a.o_lo) + 16 * w + cl;
+        float hv = a.hstate ? a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] : 0.f;
+        h_own[i] = hv;
+        Hs[1][q * 4 + i][16 * w + cl] = hv;      // h0 in the exchange tile, as every later h'
     }
-    if (a.hstate) {
-        const float* hp = a.hstate + (long)(ra / a.rdiv) * a.h_hi + (long)(ra % a.rdiv) * a.h_lo + 4 * q;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ha[c] = *(const float4*)(hp + 16 * c);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ha[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    __syncthreads();
 
     float4 xa[4];
     {
         const int p0 = dir ? a.nsteps - 1 : 0;
-        const float* xp = a.x + xa_base + (long)p0 * a.x_step;
+        const float* xp = xbase + xa_off + (long)p0 * a.x_step;
 #pragma unroll
         for (int c = 0; c < 4; ++c) xa[c] = *(const float4*)(xp + 16 * c);
     }
     int buf = 0;
     for (int s = 0; s < a.nsteps; ++s) {
-        const int pos = dir ? a.nsteps - 1 - s : s;
-        // prefetch next step's x fragments
-        float4 xn[4];
-        {
-            int sn = s + 1 < a.nsteps ? s + 1 : s;
-            const int pn = dir ? a.nsteps - 1 - sn : sn;
-            const float* xp = a.x + xa_base + (long)pn * a.x_step;
+        // h'(s-1) leaves for HBM at the TOP of step s: CDNA4's vmcnt counts stores, and the loop-top
+        // wait for x(s) would otherwise stall on stores issued a few cycles earlier.  Here they are
+        // a whole step (96 MFMAs) old by the time anything waits on them.
+        if (s > 0) {
+            const int pp = dir ? a.nsteps - s : s - 1;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xn[c] = *(const float4*)(xp + 16 * c);
+            for (int i = 0; i < 4; ++i)
+                if (oc_ok[i]) obase[oc_off[i] + (long)pp * a.o_step] = h_own[i];
         }
         f32x4 ar = {b_r, b_r, b_r, b_r}, az = {b_z, b_z, b_z, b_z};
         f32x4 axn = {b_in, b_in, b_in, b_in}, ahn = {b_hn, b_hn, b_hn, b_hn};
@@ -111,9 +109,19 @@ __global__ __launch_bounds__(256, 2) void gru64_scan_kernel(Gru64Args a) {
                 axn = mfma16(xv[kb], wih[2][c * 4 + kb], axn);
             }
         }
+        // x(s) is consumed: fetch x(s+1) into the same registers, it lands under the h-part MFMAs
+        {
+            const int sn = s + 1 < a.nsteps ? s + 1 : s;
+            const int pn = dir ? a.nsteps - 1 - sn : sn;
+            const float* xp = xbase + xa_off + (long)pn * a.x_step;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xa[c] = *(const float4*)(xp + 16 * c);
+        }
+        const float* hrow = &Hs[buf ^ 1][cl][4 * q];       // h(s-1): written last step (or h0)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float hv[4] = {ha[c].x, ha[c].y, ha[c].z, ha[c].w};
+            const float4 h4 = *(const float4*)(hrow + 16 * c);
+            const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 ar = mfma16(hv[kb], whh[0][c * 4 + kb], ar);
@@ -129,14 +137,15 @@ __global__ __launch_bounds__(256, 2) void gru64_scan_kernel(Gru64Args a) {
             float h = (1.0f - z) * n + z * h_own[i];
             h_own[i] = h;
             Hs[buf][q * 4 + i][16 * w + cl] = h;
-            if (oc_ok[i]) a.out[oc_base[i] + (long)pos * a.o_step] = h;
         }
         __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ha[c] = *(const float4*)&Hs[buf][cl][16 * c + 4 * q];
         buf ^= 1;
+    }
+    if (a.nsteps > 0) {
+        const int pp = dir ? 0 : a.nsteps - 1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xa[c] = xn[c];
+        for (int i = 0; i < 4; ++i)
+            if (oc_ok[i]) obase[oc_off[i] + (long)pp * a.o_step] = h_own[i];
     }
     if (a.hstate) {
 #pragma unroll

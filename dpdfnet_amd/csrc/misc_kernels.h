@@ -289,6 +289,7 @@ struct StateIoArgs {
     int off_erb_buf, off_df_buf, off_convp, off_mask, off_coefs, off_spec;
     int B, Tc, E, D, F;
     int do_export;
+    int seg_lo, seg_hi;    // this launch handles segments [seg_lo, seg_hi): 0 erb_conv0, 1 df_conv0, 2 mask spec, 3 df_convp | 4 coefs, 5 masked spec
 };
 __device__ __forceinline__ void fifo_io(float* st, float* tensor_frame0 /* frame t=0 of clip */, long frame_sz,
                                         int cap, int Tc, int do_export, int tid, int nthreads) {
@@ -303,7 +304,8 @@ __device__ __forceinline__ void fifo_io(float* st, float* tensor_frame0 /* frame
     }
 }
 __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
-    const int b = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x, seg = a.seg_lo + blockIdx.y, tid = threadIdx.x;
+    if (seg >= a.seg_hi) return;
     float* st = a.state + (long)b * a.S;
     const int Tc = a.Tc;
     if (seg == 0) {
@@ -312,9 +314,9 @@ __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
         fifo_io(st + a.off_df_buf, a.feat_spec + ((size_t)b * (Tc + 2) + 2) * 2 * a.D, 2 * a.D, 3, Tc, a.do_export, tid, 256);
     } else if (seg == 2) {
         fifo_io(st + a.off_mask, a.xs + ((size_t)b * (Tc + 2) + 2) * a.F * 2, a.F * 2, 3, Tc, a.do_export, tid, 256);
-    } else if (seg == 3) {
+    } else if (seg == 5) {
         fifo_io(st + a.off_spec, a.xm + ((size_t)b * (Tc + 4) + 4) * a.F * 2, a.F * 2, 5, Tc, a.do_export, tid, 256);
-    } else if (seg == 4) {
+    } else if (seg == 3) {
         // df_convp_buf [5][64][D] (channel-first) <-> c0 [B][4+Tc][D][64]
         const long fsz = 64L * a.D;
         float* t0 = a.c0 + ((size_t)b * (Tc + 4) + 4) * fsz;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
                 if (a.do_export) sp[i] = tp[(long)f * 64 + c]; else tp[(long)f * 64 + c] = sp[i];
             }
         }
-    } else if (seg == 5) {
+    } else if (seg == 4) {
         // coefs_buf [3][5][D][2] <-> coefs [B][2+Tc][D][10]
         const long fsz = 10L * a.D;
         float* t0 = a.coefs + ((size_t)b * (Tc + 2) + 2) * fsz;

@@ -98,6 +98,9 @@ int dpdf_profile_enable(dpdf_model* m, int on);
 size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap);
 /* Set the time-chunk length used by dpdf_enhance_batch (frames per chunk; <=0 = whole clip). */
 int dpdf_set_chunk_frames(dpdf_model* m, int frames);
+/* 1 (default): stage 2 of chunk i (GRU-256 scans, decoders) and the ERB encoder branch run on their own
+ * HIP streams underneath stage 1 of chunk i+1; 0: everything serial on one stream (A/B timing). */
+int dpdf_set_overlap(dpdf_model* m, int on);
 
 /* Debug/test hook: copy an intermediate tensor of the last processed chunk to the host
  * ("e0","e1","e2","e3","e3_dprnn","c0","c1","c1_dprnn","emb","m","coefs","xm","feat_erb",
