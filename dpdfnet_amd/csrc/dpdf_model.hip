@@ -532,7 +532,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
 
 template <int S>
 void run_dwconv(dpdf_model* m, const SepConvW& w, TView in, TView out, int B, int Tc) {
-    RowMap rm{Tc, out.Fp};
+    RowMap rm = RowMap::make(Tc, out.Fp);
     DwConvA<S> ap{in, rm, m->C(w.dw)};
     BiasReluToView ep{out, rm, m->C(w.bias)};
     launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.pwfrag), ep, B * Tc * out.Fp, 64, 1);
@@ -544,7 +544,7 @@ void run_dwconv_s(dpdf_model* m, const SepConvW& w, TView in, TView out, int B, 
 }
 template <int S>
 void run_subpix(dpdf_model* m, const SepConvW& w, const PathW& p, TView e, TView prev, TView out, int B, int Tc) {
-    RowMap rm{Tc, out.Fp};
+    RowMap rm = RowMap::make(Tc, out.Fp);
     SubpixA<S> ap{e, prev, rm, m->C(p.ps), m->C(p.pb), m->C(w.dw)};
     BiasReluToView ep{out, rm, m->C(w.bias)};
     launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.pwfrag), ep, B * Tc * out.Fp, 64, 1);
@@ -628,7 +628,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     TView c0v{x.c0.p, Tc + 4, 4, d.D, 64}, c1v{x.c1.p, Tc, 0, d.Fd, 64};
     {
         ProfScope ps(m, "enc_convs_df");
-        RowMap rm{Tc, d.D};
+        RowMap rm = RowMap::make(Tc, d.D);
         Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm, m->C(m->dfc0_w)};
         BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
         launch_gemm_rows<4, 64, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 64, 1);
@@ -720,7 +720,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         size_t n = (size_t)BT * 256;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(axpy_kernel), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, w.g256c.p, w.g256a.p, n);
         run_gl_auto(m, m->df_out, w.g256c.p, 256, w.dfo.p, (size_t)d.D * 10, BT, ACT_TANH);
-        RowMap rm{Tc, d.D};
+        RowMap rm = RowMap::make(Tc, d.D);
         ConvpA ap{c0v, rm};
         ConvpEpi ep{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
         launch_gemm_rows<1, 64, false>(st, ap, m->C(m->convp_frag), ep, BT * d.D, 320, 1);
@@ -749,7 +749,10 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
 // all chunks of a [B][T] problem; on return every stream's work is ordered before the main stream
 int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T, float* state,
                float* out, const float* attn_raw, float alpha) {
-    const int chunk = m->chunk_frames > 0 ? std::min(m->chunk_frames, T) : T;
+    // chunk_frames: >0 explicit, <0 whole sequence, 0 auto (aim at ~32k frames per launch wave)
+    int chunk = T;
+    if (m->chunk_frames > 0) chunk = std::min(m->chunk_frames, T);
+    else if (m->chunk_frames == 0) chunk = std::min(T, std::max(64, (32768 + B - 1) / B));
     int rc = ensure_ws(m, B, chunk);
     if (rc) return rc;
     int i = 0;

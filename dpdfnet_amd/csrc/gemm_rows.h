@@ -32,10 +32,26 @@ struct TView {
     }
 };
 
+// n / d for 0 <= n < 2^31 with a host-precomputed multiplier: q = umulhi(n, m) >> sh
+// (Granlund-Montgomery with s = ceil(log2 d), m = floor(2^(31+s)/d) + 1 < 2^32, sh = s - 1).
+struct FastDiv {
+    unsigned m; int sh; int d;
+    __host__ static FastDiv make(int d_) {
+        FastDiv f; f.d = d_; f.m = 0; f.sh = -1;
+        if (d_ <= 1) return f;
+        int s = 0; while ((1ll << s) < d_) ++s;
+        f.m = (unsigned)(((1ull << (31 + s)) / (unsigned long long)d_) + 1ull);
+        f.sh = s - 1;
+        return f;
+    }
+    __device__ __forceinline__ int div(int n) const { return sh < 0 ? n : (int)(__umulhi((unsigned)n, m) >> sh); }
+};
+
 struct RowMap {            // flat row r over (b, t, f): t in [0,Tc), f in [0,Fp)
-    int Tc, Fp;
+    int Tc, Fp; FastDiv dT, dF;
+    __host__ static RowMap make(int Tc_, int Fp_) { return RowMap{Tc_, Fp_, FastDiv::make(Tc_), FastDiv::make(Fp_)}; }
     __device__ __forceinline__ void split(int r, int& b, int& t, int& f) const {
-        int bt = r / Fp; f = r - bt * Fp; b = bt / Tc; t = bt - b * Tc;
+        int bt = dF.div(r); f = r - bt * Fp; b = dT.div(bt); t = bt - b * Tc;
     }
 };
 
@@ -188,29 +204,52 @@ struct Conv0DfA {
     const float* w;        // [64][9]
     using Regs = NoRegs;
     __device__ __forceinline__ void load(Regs&, int, int, int, int) const {}
+    // lane = output channel (its 9 taps in registers), wave = 16 consecutive rows: the 3x3 window
+    // slides along f, so each new row costs 3 (wave-uniform, L1-resident) loads instead of 9.
     __device__ __forceinline__ void store(float (*As)[64 + 4], const Regs&, int row0, int, int, int M) const {
-        const int c = threadIdx.x & 63, g = c >> 5;
+        const int c = threadIdx.x & 63, g = c >> 5, wv = threadIdx.x >> 6;
         float wk[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
+        int row = row0 + 16 * wv;
+        int b = 0, t = 0, f = 0;
+        if (row < M) rm.split(row, b, t, f);
+        float win[3][3];           // [kt][f-1, f, f+1]
+        const float* src = fs + (((size_t)b * Tt + t) * 2 + g) * D;      // frame t-2 (+halo 2), group g
+        auto reload = [&]() {
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                const float* p = src + (size_t)kt * 2 * D;
+                win[kt][0] = f > 0 ? p[f - 1] : 0.f;
+                win[kt][1] = p[f];
+                win[kt][2] = f + 1 < D ? p[f + 1] : 0.f;
+            }
+        };
+        if (row < M) reload();
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
-            const int r = (threadIdx.x >> 6) + 4 * i;
-            const int row = row0 + r;
             float v = 0.f;
-            if (row < M) {
-                int b, t, f; rm.split(row, b, t, f);
+            if (row + i < M) {
 #pragma unroll
-                for (int kt = 0; kt < 3; ++kt) {
-                    const float* src = fs + (((size_t)b * Tt + t + kt) * 2 + g) * D;   // frame t-2+kt (+halo 2)
+                for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-                    for (int kf = 0; kf < 3; ++kf) {
-                        int fi = f + kf - 1;
-                        if (fi >= 0 && fi < D) v += wk[kt * 3 + kf] * src[fi];
+                    for (int kf = 0; kf < 3; ++kf) v += wk[kt * 3 + kf] * win[kt][kf];
+                // advance to the next row
+                ++f;
+                if (f == D) {                       // next frame (possibly next clip)
+                    f = 0; ++t;
+                    if (t == rm.Tc) { t = 0; ++b; }
+                    src = fs + (((size_t)b * Tt + t) * 2 + g) * D;
+                    if (row + i + 1 < M) reload();
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 3; ++kt) {
+                        win[kt][0] = win[kt][1]; win[kt][1] = win[kt][2];
+                        win[kt][2] = f + 1 < D ? src[(size_t)kt * 2 * D + f + 1] : 0.f;
                     }
                 }
             }
-            As[r][c] = v;
+            As[16 * wv + i][c] = v;
         }
     }
 };
