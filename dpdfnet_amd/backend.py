@@ -232,8 +232,8 @@ class HipModel:
     def set_chunk_frames(self, frames: int) -> None:
         _check(self._L.dpdf_set_chunk_frames(self._h, int(frames)))
 
-    def set_overlap(self, on: bool) -> None:
-        _check(self._L.dpdf_set_overlap(self._h, 1 if on else 0))
+    def set_overlap(self, mask: int) -> None:
+        _check(self._L.dpdf_set_overlap(self._h, int(mask)))
 
     def debug_fetch(self, name: str) -> np.ndarray:
         n = self._L.dpdf_debug_fetch(self._h, name.encode(), None, 0)

@@ -178,25 +178,37 @@ struct Workspace {
     }
 };
 
+// One independent execution lane: its own streams, events, workspace and GRU-256 exchange buffer.
+// Clips are independent, so a batch is split over two lanes whose kernels the GPU interleaves:
+// HBM-bound phases of one lane run under MFMA-bound scans of the other.
+struct Lane {
+    hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
+    hipEvent_t ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
+    bool s2_pending[2] = {false, false};
+    Workspace ws;
+    unsigned long long* gru_xbuf = nullptr; int gru_xbuf_tiles = 0; unsigned gru_epoch = 0;
+    const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
+};
+
 struct ProfEntry { double ms = 0; long calls = 0; };
 
 struct dpdf_model {
     dpdf_cfg cfg; dpdf_dims d; dpdf_state_layout L;
     int device = 0;
-    hipStream_t stream = nullptr;      // main stream: stage 1, DF branch; I/O
-    hipStream_t stream_b = nullptr;    // stage 2 (latency-bound GRU-256 scans, decoders)
-    hipStream_t stream_c = nullptr;    // stage 1, ERB branch
+    hipStream_t stream = nullptr;      // main stream (= lanes[0].sA): I/O, STFT/iSTFT, stage 1 of lane 0
     hipStream_t cur = nullptr;         // stream the helper launchers enqueue on
-    hipEvent_t ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr;
-    bool s2_pending[2] = {false, false};
-    int overlap = 1;                   // 0: everything on the main stream (debug / A-B timing)
+    Lane lanes[2]; Lane* ln = nullptr; // current lane of the host-side enqueue loop
+    // bit 0: stage 2 on its own stream; bit 1: ERB encoder branch on its own stream (single-lane runs);
+    // bit 2: split the batch over two lanes.  0 = everything serial on the main stream (A/B timing).
+    int overlap = 3;
+    bool two_lanes_active = false;
     std::mutex mu;
     float* consts = nullptr;           // device arena
     int* iconsts = nullptr;            // band_start[33] | band_of[F]
     std::vector<float> erb_norm_init, spec_norm_init;
     float* d_init_state = nullptr;     // [S]
     int chunk_frames = 0;
-    unsigned long long* gru_xbuf = nullptr; int gru_xbuf_tiles = 0; unsigned gru_epoch = 0; int* d_err = nullptr;
+    int* d_err = nullptr;
     int use_gru256_cluster = 1;
     // prepared weights (arena offsets)
     size_t conv0_w, conv0_b;
@@ -210,7 +222,6 @@ struct dpdf_model {
     size_t convp_frag, convp_bias;
     size_t window, stft_frag, istft_frag;
     int stft_groups, istft_groups, istft_K;
-    Workspace ws;
     DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state;
     // profiling
     bool prof_on = false;
@@ -218,7 +229,6 @@ struct dpdf_model {
     std::vector<hipEvent_t> prof_events; int prof_used = 0;
     std::vector<std::pair<const char*, int>> prof_pending;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
     const float* C(size_t off) const { return consts + off; }
 };
 
@@ -395,10 +405,10 @@ void erb_bands(int nfft, int fs, std::vector<int>& start, std::vector<int>& band
 }
 
 int ensure_ws(dpdf_model* m, int B, int Tc) {
-    Workspace& w = m->ws;
+    Workspace& w = m->ln->ws;
     if (B <= w.Bcap && Tc <= w.Tcap) return DPDF_OK;    // every size below is monotone in B and Tc
     // growing: make sure nothing in flight still uses the old buffers
-    (void)hipStreamSynchronize(m->stream); (void)hipStreamSynchronize(m->stream_b); (void)hipStreamSynchronize(m->stream_c);
+    (void)hipStreamSynchronize(m->ln->sA); (void)hipStreamSynchronize(m->ln->sB); (void)hipStreamSynchronize(m->ln->sC);
     B = std::max(B, w.Bcap); Tc = std::max(Tc, w.Tcap);
     const dpdf_dims& d = m->d;
     const size_t BT = (size_t)B * Tc;
@@ -428,16 +438,16 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
 }
 
 int ensure_gru_xbuf(dpdf_model* m, int ntiles) {
-    if (ntiles <= m->gru_xbuf_tiles && m->gru_xbuf && m->d_err) return DPDF_OK;
-    if (m->gru_xbuf) { (void)hipStreamSynchronize(m->stream); (void)hipFree(m->gru_xbuf); m->gru_xbuf = nullptr; }
+    if (ntiles <= m->ln->gru_xbuf_tiles && m->ln->gru_xbuf && m->d_err) return DPDF_OK;
+    if (m->ln->gru_xbuf) { (void)hipStreamSynchronize(m->ln->sA); (void)hipFree(m->ln->gru_xbuf); m->ln->gru_xbuf = nullptr; }
     const size_t bytes = (size_t)ntiles * 2 * 16 * 256 * 8;
-    if (hipMalloc((void**)&m->gru_xbuf, bytes) != hipSuccess) { m->gru_xbuf_tiles = 0; return DPDF_E_RUNTIME; }
-    (void)hipMemsetAsync(m->gru_xbuf, 0, bytes, m->stream);
-    m->gru_epoch = 0;
-    m->gru_xbuf_tiles = ntiles;
+    if (hipMalloc((void**)&m->ln->gru_xbuf, bytes) != hipSuccess) { m->ln->gru_xbuf_tiles = 0; return DPDF_E_RUNTIME; }
+    (void)hipMemsetAsync(m->ln->gru_xbuf, 0, bytes, m->ln->sA);
+    m->ln->gru_epoch = 0;
+    m->ln->gru_xbuf_tiles = ntiles;
     if (!m->d_err) {
         if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return DPDF_E_RUNTIME;
-        (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->stream);
+        (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->ln->sA);
     }
     return DPDF_OK;
 }
@@ -464,22 +474,22 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
     {
         ProfScope ps(m, "gru256_proj");
         PlainA<64> ap{x, 256, 0, 256};
-        BiasActStore<8> ep{m->ws.gi.p, 768, 128, m->C(g.ih_bias), 128, 128, ACT_NONE};
+        BiasActStore<8> ep{m->ln->ws.gi.p, 768, 128, m->C(g.ih_bias), 128, 128, ACT_NONE};
         launch_gemm_rows<8, 64, false>(m->cur, ap, m->C(g.ih_frag), ep, M, 256, 6);
     }
     {
         ProfScope ps(m, "gru256_scan");
         const int ntiles = (B + 15) / 16;
         if (m->use_gru256_cluster && ensure_gru_xbuf(m, ntiles) == DPDF_OK) {
-            if (m->gru_epoch > 0xF0000000u) {     // epoch wrap: re-zero the granules (once per ~4e9 steps)
-                (void)hipMemsetAsync(m->gru_xbuf, 0, (size_t)m->gru_xbuf_tiles * 2 * 16 * 256 * 8, m->cur);
-                m->gru_epoch = 0;
+            if (m->ln->gru_epoch > 0xF0000000u) {     // epoch wrap: re-zero the granules (once per ~4e9 steps)
+                (void)hipMemsetAsync(m->ln->gru_xbuf, 0, (size_t)m->ln->gru_xbuf_tiles * 2 * 16 * 256 * 8, m->cur);
+                m->ln->gru_epoch = 0;
             }
-            Gru256CArgs a{m->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc, m->gru_xbuf, m->gru_epoch, m->d_err};
-            m->gru_epoch += (unsigned)Tc;
+            Gru256CArgs a{m->ln->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc, m->ln->gru_xbuf, m->ln->gru_epoch, m->d_err};
+            m->ln->gru_epoch += (unsigned)Tc;
             hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->cur, a);
         } else {
-            Gru256Args a{m->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
+            Gru256Args a{m->ln->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
             hipLaunchKernelGGL(gru256_scan_kernel, dim3(ntiles), dim3(1024), 0, m->cur, a);
         }
     }
@@ -573,7 +583,7 @@ struct ChunkArgs {
 };
 
 StateIoArgs make_sio(dpdf_model* m, const ChunkArgs& c, XSet& x) {
-    const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L; Workspace& w = m->ws;
+    const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L; Workspace& w = m->ln->ws;
     return StateIoArgs{c.state, (long)d.state_size, w.feat_erb.p, w.feat_spec.p, x.c0.p, x.xs.p, w.coefs.p, w.xm.p,
                        L.erb_conv0_buf, L.df_conv0_buf, L.df_convp_buf, L.mask_buf, L.df_coefs_buf, L.df_spec_buf,
                        c.B, c.Tc, d.E, d.D, d.F, 0, 0, 0};
@@ -581,15 +591,15 @@ StateIoArgs make_sio(dpdf_model* m, const ChunkArgs& c, XSet& x) {
 
 int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L;
-    Workspace& w = m->ws; XSet& x = w.x[c.parity];
+    Workspace& w = m->ln->ws; XSet& x = w.x[c.parity];
     const int B = c.B, Tc = c.Tc, BT = B * Tc;
     const long S = d.state_size;
     float* state = c.state;
-    hipStream_t sA = m->stream, sC = m->overlap ? m->stream_c : m->stream;
+    hipStream_t sA = m->ln->sA, sC = ((m->overlap & 2) && !m->two_lanes_active) ? m->ln->sC : m->ln->sA;
     m->cur = sA;
-    if (m->overlap && m->s2_pending[c.parity]) {      // stage 2 of chunk i-2 must be done with this XSet
-        HIP_TRY(hipStreamWaitEvent(sA, m->ev_s2[c.parity], 0));
-        m->s2_pending[c.parity] = false;
+    if (m->ln->s2_pending[c.parity]) {      // stage 2 of chunk i-2 must be done with this XSet
+        HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_s2[c.parity], 0));
+        m->ln->s2_pending[c.parity] = false;
     }
     StateIoArgs sio = make_sio(m, c, x);
     sio.seg_lo = 0; sio.seg_hi = 4;                    // erb_conv0 / df_conv0 / mask(spec) / df_convp FIFOs
@@ -606,7 +616,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         hipLaunchKernelGGL(feat_b_kernel, dim3(B), dim3(nth), 0, sA, fb);
     }
     // ---- encoder, ERB branch (reference onnx_model/dpdfnet.py:206-219) on its own stream ----
-    if (sC != sA) { HIP_TRY(hipEventRecord(m->ev_fork, sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ev_fork, 0)); }
+    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fork, sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fork, 0)); }
     m->cur = sC;
     TView e0v{x.e0.p, Tc, 0, d.Ec, 64}, e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
     {
@@ -639,27 +649,27 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         HIP_TRY(hipMemcpyAsync(x.xd_a.p, x.c1.p, (size_t)BT * d.Fd * 64 * sizeof(float), hipMemcpyDeviceToDevice, sA));
         x.c1d = run_dprnn(m, m->dprnn_df, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, d.Fd, state, S, L.dprnn_df, B, Tc);
     }
-    if (sC != sA) { HIP_TRY(hipEventRecord(m->ev_join, sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ev_join, 0)); }
+    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_join, sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_join, 0)); }
     {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;
         hipLaunchKernelGGL(state_io_kernel, dim3(B, 4), dim3(256), 0, sA, sio);
     }
-    m->dbg_e3d = x.e3d; m->dbg_c1d = x.c1d; m->dbg_B = B; m->dbg_Tc = Tc; m->dbg_parity = c.parity;
-    HIP_TRY(hipEventRecord(m->ev_s1[c.parity], sA));
+    m->ln->dbg_e3d = x.e3d; m->ln->dbg_c1d = x.c1d; m->ln->dbg_B = B; m->ln->dbg_Tc = Tc; m->ln->dbg_parity = c.parity;
+    HIP_TRY(hipEventRecord(m->ln->ev_s1[c.parity], sA));
     HIP_TRY(hipGetLastError());
     return DPDF_OK;
 }
 
 int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L;
-    Workspace& w = m->ws; XSet& x = w.x[c.parity];
+    Workspace& w = m->ln->ws; XSet& x = w.x[c.parity];
     const int B = c.B, Tc = c.Tc, BT = B * Tc;
     const long S = d.state_size;
     float* state = c.state;
-    hipStream_t st = m->overlap ? m->stream_b : m->stream;
+    hipStream_t st = (m->overlap & 1) ? m->ln->sB : m->ln->sA;
     m->cur = st;
-    if (st != m->stream) HIP_TRY(hipStreamWaitEvent(st, m->ev_s1[c.parity], 0));
+    if (st != m->ln->sA) HIP_TRY(hipStreamWaitEvent(st, m->ln->ev_s1[c.parity], 0));
     StateIoArgs sio = make_sio(m, c, x);
     sio.seg_lo = 4; sio.seg_hi = 6;                    // DF coefs delay / masked-spec FIFOs
     {
@@ -740,30 +750,56 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         sio.do_export = 1;
         hipLaunchKernelGGL(state_io_kernel, dim3(B, 2), dim3(256), 0, st, sio);
     }
-    if (st != m->stream) { HIP_TRY(hipEventRecord(m->ev_s2[c.parity], st)); m->s2_pending[c.parity] = true; }
+    if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_s2[c.parity], st)); m->ln->s2_pending[c.parity] = true; }
     HIP_TRY(hipGetLastError());
-    m->cur = m->stream;
+    m->cur = m->ln->sA;
     return DPDF_OK;
 }
 
-// all chunks of a [B][T] problem; on return every stream's work is ordered before the main stream
+// all chunks of a [B][T] problem, split over one or two lanes; on return every stream's work is
+// ordered before the main stream
 int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T, float* state,
                float* out, const float* attn_raw, float alpha) {
+    const dpdf_dims& d = m->d;
+    const bool two = (m->overlap & 4) && B >= 64;
+    const int G = two ? 2 : 1;
+    int Bg[2] = {B, 0};
+    if (two) { Bg[0] = ((B / 2 + 15) / 16) * 16; Bg[1] = B - Bg[0]; }
+    m->two_lanes_active = two;
     // chunk_frames: >0 explicit, <0 whole sequence, 0 auto (aim at ~32k frames per launch wave)
     int chunk = T;
     if (m->chunk_frames > 0) chunk = std::min(m->chunk_frames, T);
-    else if (m->chunk_frames == 0) chunk = std::min(T, std::max(64, (32768 + B - 1) / B));
-    int rc = ensure_ws(m, B, chunk);
-    if (rc) return rc;
+    else if (m->chunk_frames == 0) chunk = std::min(T, std::max(64, (32768 + Bg[0] - 1) / Bg[0]));
+    int rc;
+    for (int g = 0; g < G; ++g) {
+        m->ln = &m->lanes[g];
+        if ((rc = ensure_ws(m, Bg[g], chunk))) { m->ln = &m->lanes[0]; return rc; }
+    }
+    if (two) {       // lane 1 starts after everything already queued on the main stream
+        HIP_TRY(hipEventRecord(m->lanes[0].ev_fork, m->stream));
+        HIP_TRY(hipStreamWaitEvent(m->lanes[1].sA, m->lanes[0].ev_fork, 0));
+    }
     int i = 0;
     for (int t0 = 0; t0 < T; t0 += chunk, ++i) {
-        ChunkArgs c{raw + (size_t)t0 * m->d.F * 2, clip_stride, B, std::min(chunk, T - t0), state,
-                    out, clip_stride, t0, attn_raw, alpha, i & 1};
-        if ((rc = run_stage1(m, c)) || (rc = run_stage2(m, c))) return rc;
+        int b0 = 0;
+        for (int g = 0; g < G; ++g) {
+            m->ln = &m->lanes[g];
+            ChunkArgs c{raw + (size_t)b0 * clip_stride + (size_t)t0 * d.F * 2, clip_stride, Bg[g], std::min(chunk, T - t0),
+                        state + (size_t)b0 * d.state_size, out + (size_t)b0 * clip_stride, clip_stride, t0,
+                        attn_raw ? attn_raw + (size_t)b0 * clip_stride : nullptr, alpha, i & 1};
+            if ((rc = run_stage1(m, c)) || (rc = run_stage2(m, c))) { m->ln = &m->lanes[0]; return rc; }
+            b0 += Bg[g];
+        }
     }
-    for (int p = 0; p < 2; ++p)
-        if (m->s2_pending[p]) { HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_s2[p], 0)); m->s2_pending[p] = false; }
+    for (int g = 0; g < G; ++g) {
+        Lane& L = m->lanes[g];
+        for (int p = 0; p < 2; ++p)
+            if (L.s2_pending[p]) { HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_s2[p], 0)); L.s2_pending[p] = false; }
+        if (g > 0) { HIP_TRY(hipEventRecord(L.ev_done, L.sA)); HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_done, 0)); }
+    }
+    m->ln = &m->lanes[0];
     m->cur = m->stream;
+    m->two_lanes_active = false;
     return DPDF_OK;
 }
 
@@ -899,16 +935,22 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
     }
 
     // ---- upload ----
-    HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&m->stream_b, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&m->stream_c, hipStreamNonBlocking));
-    m->cur = m->stream;
-    for (int p = 0; p < 2; ++p) {
-        HIP_TRY(hipEventCreateWithFlags(&m->ev_s1[p], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&m->ev_s2[p], hipEventDisableTiming));
+    for (int g = 0; g < 2; ++g) {
+        Lane& L = m->lanes[g];
+        HIP_TRY(hipStreamCreateWithFlags(&L.sA, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&L.sB, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&L.sC, hipStreamNonBlocking));
+        for (int p = 0; p < 2; ++p) {
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_s1[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_s2[p], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
     }
-    HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    m->stream = m->lanes[0].sA;
+    m->cur = m->stream;
+    m->ln = &m->lanes[0];
     HIP_TRY(hipEventCreate(&m->ev0)); HIP_TRY(hipEventCreate(&m->ev1));
     HIP_TRY(hipMalloc((void**)&m->consts, A.h.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(m->consts, A.h.data(), A.h.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -945,26 +987,33 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
 extern "C" void dpdf_destroy(dpdf_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    if (m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m->stream_b) (void)hipStreamSynchronize(m->stream_b);
-    if (m->stream_c) (void)hipStreamSynchronize(m->stream_c);
-    m->ws.release();
+    for (int g = 0; g < 2; ++g) {
+        Lane& L = m->lanes[g];
+        if (L.sA) (void)hipStreamSynchronize(L.sA);
+        if (L.sB) (void)hipStreamSynchronize(L.sB);
+        if (L.sC) (void)hipStreamSynchronize(L.sC);
+        L.ws.release();
+        if (L.gru_xbuf) (void)hipFree(L.gru_xbuf);
+    }
     DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state};
     for (DevBuf* b : bufs) b->release();
     if (m->consts) (void)hipFree(m->consts);
     if (m->iconsts) (void)hipFree(m->iconsts);
-    if (m->gru_xbuf) (void)hipFree(m->gru_xbuf);
     if (m->d_err) (void)hipFree(m->d_err);
     if (m->d_init_state) (void)hipFree(m->d_init_state);
     for (hipEvent_t e : m->prof_events) if (e) (void)hipEventDestroy(e);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
-    for (int p = 0; p < 2; ++p) { if (m->ev_s1[p]) (void)hipEventDestroy(m->ev_s1[p]); if (m->ev_s2[p]) (void)hipEventDestroy(m->ev_s2[p]); }
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
-    if (m->stream_b) (void)hipStreamDestroy(m->stream_b);
-    if (m->stream_c) (void)hipStreamDestroy(m->stream_c);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    for (int g = 0; g < 2; ++g) {
+        Lane& L = m->lanes[g];
+        for (int p = 0; p < 2; ++p) { if (L.ev_s1[p]) (void)hipEventDestroy(L.ev_s1[p]); if (L.ev_s2[p]) (void)hipEventDestroy(L.ev_s2[p]); }
+        if (L.ev_fork) (void)hipEventDestroy(L.ev_fork);
+        if (L.ev_join) (void)hipEventDestroy(L.ev_join);
+        if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+        if (L.sB) (void)hipStreamDestroy(L.sB);
+        if (L.sC) (void)hipStreamDestroy(L.sC);
+        if (L.sA) (void)hipStreamDestroy(L.sA);
+    }
     delete m;
 }
 
@@ -1006,8 +1055,8 @@ extern "C" int dpdf_set_overlap(dpdf_model* m, int on) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
     std::lock_guard<std::mutex> lk(m->mu);
     (void)hipSetDevice(m->device);
-    (void)hipStreamSynchronize(m->stream); (void)hipStreamSynchronize(m->stream_b); (void)hipStreamSynchronize(m->stream_c);
-    m->overlap = on != 0;
+    for (int g = 0; g < 2; ++g) { (void)hipStreamSynchronize(m->lanes[g].sA); (void)hipStreamSynchronize(m->lanes[g].sB); (void)hipStreamSynchronize(m->lanes[g].sC); }
+    m->overlap = on;
     return DPDF_OK;
 }
 extern "C" int dpdf_sync(dpdf_model* m) {
@@ -1257,8 +1306,9 @@ extern "C" long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, l
     if (!m || !name) return -1;
     std::lock_guard<std::mutex> lk(m->mu);
     if (hipSetDevice(m->device) != hipSuccess) return -1;
-    const dpdf_dims& d = m->d; Workspace& w = m->ws; XSet& x = w.x[m->dbg_parity];
-    const long B = m->dbg_B, Tc = m->dbg_Tc, BT = B * Tc;
+    Lane& L0 = m->lanes[0];
+    const dpdf_dims& d = m->d; Workspace& w = L0.ws; XSet& x = w.x[L0.dbg_parity];
+    const long B = L0.dbg_B, Tc = L0.dbg_Tc, BT = B * Tc;
     const float* src = nullptr; long n = 0;
     std::string s(name);
     if (s == "feat_erb") { src = w.feat_erb.p; n = B * (Tc + 2) * d.E; }
@@ -1267,10 +1317,10 @@ extern "C" long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, l
     else if (s == "e1") { src = x.e1.p; n = BT * d.F1 * 64; }
     else if (s == "e2") { src = x.e2.p; n = BT * d.F2 * 64; }
     else if (s == "e3") { src = x.e3.p; n = BT * d.F3 * 64; }
-    else if (s == "e3_dprnn") { src = m->dbg_e3d; n = BT * d.F3 * 64; }
+    else if (s == "e3_dprnn") { src = L0.dbg_e3d; n = BT * d.F3 * 64; }
     else if (s == "c0") { src = x.c0.p; n = B * (Tc + 4) * d.D * 64; }
     else if (s == "c1") { src = x.c1.p; n = BT * d.Fd * 64; }
-    else if (s == "c1_dprnn") { src = m->dbg_c1d; n = BT * d.Fd * 64; }
+    else if (s == "c1_dprnn") { src = L0.dbg_c1d; n = BT * d.Fd * 64; }
     else if (s == "emb") { src = w.emb.p; n = BT * 512; }
     else if (s == "m") { src = w.m.p; n = BT * d.E; }
     else if (s == "coefs") { src = w.coefs.p; n = B * (Tc + 2) * d.D * 10; }
