@@ -19,6 +19,9 @@
 // from L2 each step, h exchanged through LDS.
 #pragma once
 #include "common.h"
+#ifndef GRU64_VARIANT
+#define GRU64_VARIANT 0   // tools/gru64_bench.hip ablations: 1 no gate math, 2 no global stores, 4 no barrier
+#endif
 
 struct Gru64Args {
     const float* x;        // inputs, channels-last rows of 64
@@ -65,14 +68,22 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
     float* obase = a.out + (long)hi0 * a.o_hi + (long)lo0 * a.o_lo + dir * a.o_dir_off;
     int ra = row0 + cl; if (ra >= a.nrows) ra = a.nrows - 1;
     const int xa_off = (int)((long)(ra / a.rdiv - hi0) * a.x_hi + (long)(ra % a.rdiv - lo0) * a.x_lo) + 4 * q;
-    int oc_off[4]; bool oc_ok[4];
+    // output: after each step's barrier the full 16x64 h' tile sits in LDS; every lane then owns one
+    // 16-byte piece of one row (row 4w + lane/16, cols 4*(lane%16)..+3): ONE global_store_dwordx4 per
+    // lane per step writes whole 256-byte rows, instead of four 64-byte-segment dword stores.
+    const int srow = 4 * w + q, scol = 4 * cl;
+    int so_off; bool so_ok;
+    {
+        int rs = row0 + srow;
+        so_ok = rs < a.nrows;
+        if (rs >= a.nrows) rs = a.nrows - 1;
+        so_off = (int)((long)(rs / a.rdiv - hi0) * a.o_hi + (long)(rs % a.rdiv - lo0) * a.o_lo) + scol;
+    }
     float h_own[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int rc = row0 + q * 4 + i;
-        oc_ok[i] = rc < a.nrows;
         if (rc >= a.nrows) rc = a.nrows - 1;
-        oc_off[i] = (int)((long)(rc / a.rdiv - hi0) * a.o_hi + (long)(rc % a.rdiv - lo0) * a.o_lo) + 16 * w + cl;
         float hv = a.hstate ? a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] : 0.f;
         h_own[i] = hv;
         Hs[1][q * 4 + i][16 * w + cl] = hv;      // h0 in the exchange tile, as every later h'
@@ -86,17 +97,13 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) xa[c] = *(const float4*)(xp + 16 * c);
     }
+    asm volatile("" :: "v"(xa[0].x), "v"(xa[1].x), "v"(xa[2].x), "v"(xa[3].x));   // no load pending at loop entry
     int buf = 0;
     for (int s = 0; s < a.nsteps; ++s) {
         // h'(s-1) leaves for HBM at the TOP of step s: CDNA4's vmcnt counts stores, and the loop-top
         // wait for x(s) would otherwise stall on stores issued a few cycles earlier.  Here they are
         // a whole step (96 MFMAs) old by the time anything waits on them.
-        if (s > 0) {
-            const int pp = dir ? a.nsteps - s : s - 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (oc_ok[i]) obase[oc_off[i] + (long)pp * a.o_step] = h_own[i];
-        }
+
         f32x4 ar = {b_r, b_r, b_r, b_r}, az = {b_z, b_z, b_z, b_z};
         f32x4 axn = {b_in, b_in, b_in, b_in}, ahn = {b_hn, b_hn, b_hn, b_hn};
 #pragma unroll
@@ -131,21 +138,32 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+#if GRU64_VARIANT & 1
+            float h = 0.01f * (ar[i] + az[i] + axn[i] + ahn[i]) + 0.5f * h_own[i];
+#else
             float r = sigmoid_f(ar[i]);
             float z = sigmoid_f(az[i]);
             float n = tanh_f(axn[i] + r * ahn[i]);
             float h = (1.0f - z) * n + z * h_own[i];
+#endif
             h_own[i] = h;
             Hs[buf][q * 4 + i][16 * w + cl] = h;
         }
+#if !(GRU64_VARIANT & 4)
         __syncthreads();
+#endif
+        // the whole h'(s) tile is in LDS now: ship this lane's 16-byte piece.  Issued last in the
+        // step, so the x(s+1) loads already in flight are OLDER (the loop-top wait is vmcnt(1)) and
+        // nothing reuses the data registers for a full step.
+        // retire the x(s+1) loads HERE (they have had the whole h-part + gate phase to land), so that the
+        // loop-top has no pending load to wait for and never stalls on the store issued below
+        asm volatile("" :: "v"(xa[0].x), "v"(xa[1].x), "v"(xa[2].x), "v"(xa[3].x));
+        if (!(GRU64_VARIANT & 2)) {
+            const int pp = dir ? a.nsteps - 1 - s : s;
+            const float4 hv4 = *(const float4*)&Hs[buf][srow][scol];
+            if (so_ok) *(float4*)(obase + so_off + (long)pp * a.o_step) = hv4;
+        }
         buf ^= 1;
-    }
-    if (a.nsteps > 0) {
-        const int pp = dir ? 0 : a.nsteps - 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (oc_ok[i]) obase[oc_off[i] + (long)pp * a.o_step] = h_own[i];
     }
     if (a.hstate) {
 #pragma unroll
