@@ -20,7 +20,7 @@
 #pragma once
 #include "common.h"
 #ifndef GRU64_VARIANT
-#define GRU64_VARIANT 0   // tools/gru64_bench.hip ablations: 1 no gate math, 2 no global stores, 4 no barrier
+#define GRU64_VARIANT 0   // tools/gru64_bench.hip ablations: 1 no gate math, 2 no global stores, 4 no barrier, 8 no x loads, 16 no LDS h reads
 #endif
 
 struct Gru64Args {
@@ -38,7 +38,9 @@ struct Gru64Args {
 };
 
 __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
+    // Hs: h exchange tiles, Xs: x staging tiles; both double-buffered, rows padded to 68 floats
     __shared__ __attribute__((aligned(16))) float Hs[2][16][68];
+    __shared__ __attribute__((aligned(16))) float Xs[2][16][68];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int dir = blockIdx.y;
     const int row0 = blockIdx.x * 16;
@@ -60,24 +62,23 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
     const float b_r = bp[0], b_z = bp[64], b_in = bp[128], b_hn = bp[192];
 
     // --- row addressing ----------------------------------------------------------------------
-    // A-operand view: this lane feeds row (row0 + cl); C view: rows row0 + q*4 + i
     // Tile base is wave-uniform (64-bit, scalar); per-lane offsets are 32-bit deltas from it
     // (a tile spans at most two `hi` groups, so deltas are bounded by one clip stride).
+    // Global I/O is cooperative and row-contiguous: lane (w, q, cl) moves the 16-byte piece
+    // [row 4w+q][cols 4cl..4cl+3] of the 16x64 tile -- ONE dwordx4 load of x and ONE dwordx4 store
+    // of h' per lane per step, whole 256-byte rows per 16 lanes.
     const int hi0 = row0 / a.rdiv, lo0 = row0 - hi0 * a.rdiv;
     const float* xbase = a.x + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
     float* obase = a.out + (long)hi0 * a.o_hi + (long)lo0 * a.o_lo + dir * a.o_dir_off;
-    int ra = row0 + cl; if (ra >= a.nrows) ra = a.nrows - 1;
-    const int xa_off = (int)((long)(ra / a.rdiv - hi0) * a.x_hi + (long)(ra % a.rdiv - lo0) * a.x_lo) + 4 * q;
-    // output: after each step's barrier the full 16x64 h' tile sits in LDS; every lane then owns one
-    // 16-byte piece of one row (row 4w + lane/16, cols 4*(lane%16)..+3): ONE global_store_dwordx4 per
-    // lane per step writes whole 256-byte rows, instead of four 64-byte-segment dword stores.
     const int srow = 4 * w + q, scol = 4 * cl;
-    int so_off; bool so_ok;
+    int sx_off, so_off; bool so_ok;
     {
         int rs = row0 + srow;
         so_ok = rs < a.nrows;
         if (rs >= a.nrows) rs = a.nrows - 1;
-        so_off = (int)((long)(rs / a.rdiv - hi0) * a.o_hi + (long)(rs % a.rdiv - lo0) * a.o_lo) + scol;
+        const int dh = rs / a.rdiv - hi0, dl = rs % a.rdiv - lo0;
+        sx_off = (int)((long)dh * a.x_hi + (long)dl * a.x_lo) + scol;
+        so_off = (int)((long)dh * a.o_hi + (long)dl * a.o_lo) + scol;
     }
     float h_own[4];
 #pragma unroll
@@ -88,27 +89,37 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
         h_own[i] = hv;
         Hs[1][q * 4 + i][16 * w + cl] = hv;      // h0 in the exchange tile, as every later h'
     }
-    __syncthreads();
-
-    float4 xa[4];
     {
         const int p0 = dir ? a.nsteps - 1 : 0;
-        const float* xp = xbase + xa_off + (long)p0 * a.x_step;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xa[c] = *(const float4*)(xp + 16 * c);
+        *(float4*)&Xs[0][srow][scol] = *(const float4*)(xbase + sx_off + (long)p0 * a.x_step);
     }
-    asm volatile("" :: "v"(xa[0].x), "v"(xa[1].x), "v"(xa[2].x), "v"(xa[3].x));   // no load pending at loop entry
+    __syncthreads();
+
     int buf = 0;
     for (int s = 0; s < a.nsteps; ++s) {
-        // h'(s-1) leaves for HBM at the TOP of step s: CDNA4's vmcnt counts stores, and the loop-top
-        // wait for x(s) would otherwise stall on stores issued a few cycles earlier.  Here they are
-        // a whole step (96 MFMAs) old by the time anything waits on them.
-
+        // Vector-memory traffic of the step, issued back to back at its very top and waited for only
+        // at its very end (vmcnt retires in order and counts stores on CDNA4):
+        //   store h'(s-1): this lane's 16-byte piece of the tile completed by the last barrier;
+        //   load  x(s+1):  this lane's 16-byte piece of the next input tile.
+        if (s > 0 && !(GRU64_VARIANT & 2)) {
+            const int pp = dir ? a.nsteps - s : s - 1;
+            const float4 hv4 = *(const float4*)&Hs[buf ^ 1][srow][scol];
+            if (so_ok) *(float4*)(obase + so_off + (long)pp * a.o_step) = hv4;
+        }
+        float4 xnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(GRU64_VARIANT & 8)) {
+            const int sn = s + 1 < a.nsteps ? s + 1 : s;
+            const int pn = dir ? a.nsteps - 1 - sn : sn;
+            xnext = *(const float4*)(xbase + sx_off + (long)pn * a.x_step);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 ar = {b_r, b_r, b_r, b_r}, az = {b_z, b_z, b_z, b_z};
         f32x4 axn = {b_in, b_in, b_in, b_in}, ahn = {b_hn, b_hn, b_hn, b_hn};
+        const float* xrow = &Xs[buf][cl][4 * q];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float xv[4] = {xa[c].x, xa[c].y, xa[c].z, xa[c].w};
+            const float4 x4 = *(const float4*)(xrow + 16 * c);
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 ar = mfma16(xv[kb], wih[0][c * 4 + kb], ar);
@@ -116,18 +127,14 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
                 axn = mfma16(xv[kb], wih[2][c * 4 + kb], axn);
             }
         }
-        // x(s) is consumed: fetch x(s+1) into the same registers, it lands under the h-part MFMAs
-        {
-            const int sn = s + 1 < a.nsteps ? s + 1 : s;
-            const int pn = dir ? a.nsteps - 1 - sn : sn;
-            const float* xp = xbase + xa_off + (long)pn * a.x_step;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) xa[c] = *(const float4*)(xp + 16 * c);
-        }
         const float* hrow = &Hs[buf ^ 1][cl][4 * q];       // h(s-1): written last step (or h0)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+#if GRU64_VARIANT & 16
+            const float4 h4 = make_float4(h_own[0], h_own[1], h_own[2], h_own[3]);
+#else
             const float4 h4 = *(const float4*)(hrow + 16 * c);
+#endif
             const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
@@ -149,21 +156,17 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
             h_own[i] = h;
             Hs[buf][q * 4 + i][16 * w + cl] = h;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        *(float4*)&Xs[buf ^ 1][srow][scol] = xnext;        // the step's only vmcnt wait: both ops are a step old
 #if !(GRU64_VARIANT & 4)
         __syncthreads();
 #endif
-        // the whole h'(s) tile is in LDS now: ship this lane's 16-byte piece.  Issued last in the
-        // step, so the x(s+1) loads already in flight are OLDER (the loop-top wait is vmcnt(1)) and
-        // nothing reuses the data registers for a full step.
-        // retire the x(s+1) loads HERE (they have had the whole h-part + gate phase to land), so that the
-        // loop-top has no pending load to wait for and never stalls on the store issued below
-        asm volatile("" :: "v"(xa[0].x), "v"(xa[1].x), "v"(xa[2].x), "v"(xa[3].x));
-        if (!(GRU64_VARIANT & 2)) {
-            const int pp = dir ? a.nsteps - 1 - s : s;
-            const float4 hv4 = *(const float4*)&Hs[buf][srow][scol];
-            if (so_ok) *(float4*)(obase + so_off + (long)pp * a.o_step) = hv4;
-        }
         buf ^= 1;
+    }
+    if (a.nsteps > 0 && !(GRU64_VARIANT & 2)) {
+        const int pp = dir ? 0 : a.nsteps - 1;
+        const float4 hv4 = *(const float4*)&Hs[buf ^ 1][srow][scol];
+        if (so_ok) *(float4*)(obase + so_off + (long)pp * a.o_step) = hv4;
     }
     if (a.hstate) {
 #pragma unroll
