@@ -184,6 +184,7 @@ struct Workspace {
 struct Lane {
     hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
     hipEvent_t ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
+    hipEvent_t ev_fk[2] = {nullptr, nullptr}, ev_jn[2] = {nullptr, nullptr};   // ERB-branch fork/join, per chunk parity
     bool s2_pending[2] = {false, false};
     Workspace ws;
     unsigned long long* gru_xbuf = nullptr; int gru_xbuf_tiles = 0; unsigned gru_epoch = 0;
@@ -616,7 +617,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         hipLaunchKernelGGL(feat_b_kernel, dim3(B), dim3(nth), 0, sA, fb);
     }
     // ---- encoder, ERB branch (reference onnx_model/dpdfnet.py:206-219) on its own stream ----
-    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fork, sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fork, 0)); }
+    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fk[c.parity], sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fk[c.parity], 0)); }
     m->cur = sC;
     TView e0v{x.e0.p, Tc, 0, d.Ec, 64}, e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
     {
@@ -649,7 +650,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         HIP_TRY(hipMemcpyAsync(x.xd_a.p, x.c1.p, (size_t)BT * d.Fd * 64 * sizeof(float), hipMemcpyDeviceToDevice, sA));
         x.c1d = run_dprnn(m, m->dprnn_df, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, d.Fd, state, S, L.dprnn_df, B, Tc);
     }
-    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_join, sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_join, 0)); }
+    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_jn[c.parity], sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_jn[c.parity], 0)); }
     {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;
@@ -943,6 +944,8 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
         for (int p = 0; p < 2; ++p) {
             HIP_TRY(hipEventCreateWithFlags(&L.ev_s1[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_s2[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_fk[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_jn[p], hipEventDisableTiming));
         }
         HIP_TRY(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
@@ -1006,7 +1009,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     for (int g = 0; g < 2; ++g) {
         Lane& L = m->lanes[g];
-        for (int p = 0; p < 2; ++p) { if (L.ev_s1[p]) (void)hipEventDestroy(L.ev_s1[p]); if (L.ev_s2[p]) (void)hipEventDestroy(L.ev_s2[p]); }
+        for (int p = 0; p < 2; ++p) { if (L.ev_s1[p]) (void)hipEventDestroy(L.ev_s1[p]); if (L.ev_s2[p]) (void)hipEventDestroy(L.ev_s2[p]); if (L.ev_fk[p]) (void)hipEventDestroy(L.ev_fk[p]); if (L.ev_jn[p]) (void)hipEventDestroy(L.ev_jn[p]); }
         if (L.ev_fork) (void)hipEventDestroy(L.ev_fork);
         if (L.ev_join) (void)hipEventDestroy(L.ev_join);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);

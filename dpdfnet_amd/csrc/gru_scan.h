@@ -356,8 +356,10 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ok[i]) a.out[((size_t)rc[i] * a.Tc + t) * 256 + u0 + cl] = h;
         }
-        // sweep the three peers' slices (3 x 16 rows x 64 units = 12 granules per thread)
-        if (t + 1 < a.Tc) {
+        // sweep the three peers' slices (3 x 16 rows x 64 units = 12 granules per thread).  Also after the
+        // LAST step: a workgroup may overwrite the carried state (below) only once every peer has
+        // provably consumed the old one, i.e. has published its own last step.
+        {
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
                 const int idx = tid + 256 * k;

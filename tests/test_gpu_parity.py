@@ -100,6 +100,25 @@ def test_time_chunking_and_state_carry_invariance(case, chunk):
     np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5)
 
 
+def test_single_frame_chunks_are_race_free_under_stream_overlap(case):
+    """Regression: with one frame per launch the 4-workgroup GRU-256 cluster has no inter-step
+    hand-off, and a fast workgroup used to overwrite the carried state before a late peer had read
+    it (seen only with stage-2 and ERB streams both active).  Hammer that path."""
+    g, meta, o, m = case
+    spec = o.stft(g["wav"])[:4]
+    m.set_chunk_frames(0)
+    ref, st_ref = m.run_frames(spec, m.initial_state())
+    m.set_chunk_frames(1)
+    m.set_overlap(3)
+    try:
+        for _ in range(60):
+            out, st = m.run_frames(spec, m.initial_state())
+            assert np.abs(out - ref).max() < 1e-5 * float(np.abs(ref).max())
+            np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5)
+    finally:
+        m.set_chunk_frames(0)
+
+
 def test_frame_by_frame_host_loop_is_a_drop_in_for_session_run(case):
     """The reference's hot loop verbatim (api.py:96-104): one call per frame, state through the host."""
     g, meta, o, m = case
