@@ -204,10 +204,20 @@ def main() -> None:
         # per frame and DPRNN block: intra = 2 directions x F' steps, inter = F' rows x 1 step
         flops_total = args.steps * NB * (B * T) * (48 + 8) * 3 * GRU64_FLOP_PER_ROW_STEP
         achieved = flops_total / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+        # separate --pmc runs of this same command, gfx950 x2 read correction applied; profiles/README.md)
+        traffic, traffic_note = None, "no PMC summary in profiles/"
+        try:
+            pmc = json.loads((ROOT / "profiles" / "r1_final_pmc_summary.json").read_text())["gru64_scan_kernel"]
+            traffic = pmc["hbm_bytes_per_dispatch_corrected"]
+            traffic_note = "bytes/launch, profiles/r1_final_pmc_summary.json (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        except Exception:
+            pass
         roofline = {
             "bound": "mfma", "kernel": "gru64_scan_kernel (all launches: intra/inter x DF/ERB)",
             "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+            "algorithmic_bytes_per_launch": NB * (B * T) * (48 + 8) * 64 * 4 * (1 + 2 + 1 + 1) * args.steps / calls if calls else None,
             "avg_launch_ms": ms / calls if calls else None, "launches": calls,
             "flop_per_launch": flops_total / calls if calls else None,
             "whole_path_frac": value * FLOP_PER_FRAME / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
