@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: 64 concurrent device-resident StreamEnhancer states, dpdfnet8_48khz_hr,
+one 10 ms hop per call.  Prints us/hop-call, frames/s and the real-time factor."""
+import sys, time, json
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
+from dpdfnet_amd import backend as be
+from dpdfnet_amd.weights import synth_blob
+
+def run(sr, nb, S, hops_per_call, calls, warm=20):
+    m = be.HipModel(sr, nb, synth_blob(be.manifest(sr, nb), 20260417), 0)
+    st = be.HipStreams(m, S)
+    rng = np.random.default_rng(0)
+    hop = m.hop
+    st.prime((0.05 * rng.standard_normal((S, hop))).astype(np.float32))
+    pcm = (0.05 * rng.standard_normal((S, hops_per_call * hop))).astype(np.float32)
+    for _ in range(warm): st.process(pcm)
+    t0 = time.perf_counter()
+    for _ in range(calls): st.process(pcm)
+    dt = time.perf_counter() - t0
+    us = 1e6 * dt / calls
+    fps = S * hops_per_call * calls / dt
+    audio_per_call = hops_per_call * hop / sr
+    print(json.dumps({"sr": sr, "nb": nb, "streams": S, "hops_per_call": hops_per_call, "us_per_call": round(us, 1),
+                      "frames_per_s": round(fps), "rtf": round((dt / calls) / audio_per_call, 4)}))
+    st.close(); m.close()
+
+if __name__ == "__main__":
+    run(48000, 8, 64, 1, 200)
+    run(48000, 8, 64, 4, 100)
+    run(48000, 8, 64, 16, 50)
+    run(16000, 2, 1, 1, 200)
+    run(16000, 4, 64, 1, 200)
