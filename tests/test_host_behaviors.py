@@ -235,3 +235,17 @@ def test_enhance_file_wav_roundtrip(tmp_path, monkeypatch):
     assert sr == 16000 and y.shape == x.shape
     with pytest.raises(FileNotFoundError):
         api.enhance_file(tmp_path / "missing.wav")
+
+
+def test_evalkit_si_snr_and_alignment():
+    from dpdfnet_amd import evalkit
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(4000).astype(np.float32)
+    assert evalkit.si_snr(x, 3.0 * x) > 70.0                       # scale invariant
+    noisy = x + 0.1 * rng.standard_normal(4000).astype(np.float32)
+    assert 18.0 < evalkit.si_snr(x, noisy) < 22.0                  # ~20 dB
+    a, b, lag = evalkit.align_by_xcorr_trim(np.concatenate([np.zeros(37, np.float32), x]), x)
+    assert lag == 37 and len(a) == len(b) == 4000
+    np.testing.assert_allclose(a, b, atol=1e-6)
+    rep = evalkit.waveform_report(noisy, x)
+    assert abs(rep["rms_error"] - 0.1) < 0.01 and rep["si_snr_db"] > 18.0
