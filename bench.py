@@ -112,6 +112,7 @@ def main() -> None:
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("DPDF_CHUNK_FRAMES", "0")),
                     help="time-chunk length in frames (0 = engine default)")
     ap.add_argument("--overlap", type=int, default=-1, help="overlap bit mask (1 stage-2 stream, 2 ERB stream, 4 two lanes; 0 serial; -1 engine default)")
+    ap.add_argument("--no-fuse", action="store_true", help="run fc+LN of the DPRNN blocks as separate kernels")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clip-seconds", type=float, default=10.0)
@@ -142,6 +143,8 @@ def main() -> None:
         model.set_chunk_frames(args.chunk)
     if args.overlap >= 0:
         model.set_overlap(args.overlap)
+    if args.no_fuse:
+        model.set_fuse_dprnn(False)
     B, N = args.clips, int(CLIP_SECONDS * SR)
     T = model.num_frames(N)
     lo, hi = shard_range(B * world, world, rank)          # contiguous block of clips per rank

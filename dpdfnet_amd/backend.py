@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = (
     "dpdf_run_frames", "dpdf_enhance_batch", "dpdf_num_frames", "dpdf_streams_create",
     "dpdf_streams_destroy", "dpdf_streams_reset", "dpdf_streams_prime", "dpdf_streams_process",
     "dpdf_streams_get_state", "dpdf_sync", "dpdf_profile_enable", "dpdf_profile_report",
-    "dpdf_set_chunk_frames", "dpdf_set_overlap", "dpdf_debug_fetch",
+    "dpdf_set_chunk_frames", "dpdf_set_overlap", "dpdf_set_fuse_dprnn", "dpdf_debug_fetch",
 )
 
 
@@ -103,6 +103,7 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_profile_report.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
         L.dpdf_set_chunk_frames.argtypes = [vp, ctypes.c_int]
         L.dpdf_set_overlap.argtypes = [vp, ctypes.c_int]
+        L.dpdf_set_fuse_dprnn.argtypes = [vp, ctypes.c_int]
         L.dpdf_debug_fetch.restype = ctypes.c_long
         L.dpdf_debug_fetch.argtypes = [vp, ctypes.c_char_p, fp, ctypes.c_long]
         _lib = L
@@ -234,6 +235,9 @@ class HipModel:
 
     def set_overlap(self, mask: int) -> None:
         _check(self._L.dpdf_set_overlap(self._h, int(mask)))
+
+    def set_fuse_dprnn(self, on: bool) -> None:
+        _check(self._L.dpdf_set_fuse_dprnn(self._h, 1 if on else 0))
 
     def debug_fetch(self, name: str) -> np.ndarray:
         n = self._L.dpdf_debug_fetch(self._h, name.encode(), None, 0)

@@ -130,7 +130,8 @@ struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs; };
 struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
 struct Gru256W { size_t ih_frag, ih_bias, hh_frag, b_hn; };   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
-struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b; };
+struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
+                size_t fci_epi, fce_epi; };   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
 
 }  // namespace
 
@@ -202,6 +203,7 @@ struct dpdf_model {
     // bit 0: stage 2 on its own stream; bit 1: ERB encoder branch on its own stream (single-lane runs);
     // bit 2: split the batch over two lanes.  0 = everything serial on the main stream (A/B timing).
     int overlap = 3;
+    int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans (0: separate GEMM kernels)
     bool two_lanes_active = false;
     std::mutex mu;
     float* consts = nullptr;           // device arena
@@ -374,6 +376,22 @@ std::vector<DprnnW> build_dprnn(Arena& A, const Blob& B, const std::string& p, i
         w.fce_b = A.add(std::vector<float>(B.get(q + ".fc_inter.bias"), B.get(q + ".fc_inter.bias") + 64));
         w.lne_g = A.add(std::vector<float>(B.get(q + ".ln_inter.weight"), B.get(q + ".ln_inter.weight") + 64));
         w.lne_b = A.add(std::vector<float>(B.get(q + ".ln_inter.bias"), B.get(q + ".ln_inter.bias") + 64));
+        {   // epilogue-fused forms: wave w owns output columns [16w,16w+16)
+            auto pack_epi = [&](const float* W, int ld, int koff) {
+                std::vector<float> f((size_t)4 * 16 * 64);
+                for (int wv = 0; wv < 4; ++wv)
+                    for (int c = 0; c < 4; ++c)
+                        for (int kb = 0; kb < 4; ++kb)
+                            for (int lane = 0; lane < 64; ++lane)
+                                f[((size_t)wv * 16 + c * 4 + kb) * 64 + lane] = W[(size_t)(16 * wv + (lane & 15)) * ld + koff + kperm(c, lane >> 4, kb)];
+                return f;
+            };
+            std::vector<float> fi = pack_epi(B.get(q + ".fc_intra.weight"), 128, 64);      // part 0: fed by hb (this scan's h')
+            std::vector<float> fi1 = pack_epi(B.get(q + ".fc_intra.weight"), 128, 0);      // part 1: fed by hf
+            fi.insert(fi.end(), fi1.begin(), fi1.end());
+            w.fci_epi = A.add(fi);
+            w.fce_epi = A.add(pack_epi(B.get(q + ".fc_inter.weight"), 64, 0));
+        }
         v.push_back(w);
     }
     return v;
@@ -501,16 +519,44 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
                  float* state, long S, int soff, int B, int Tc) {
     const int M = B * Tc * Fp;
     float* x = xa; float* y = xb;
+    const bool fused = m->fuse_dprnn && (Fp % 4 == 0);
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         const DprnnW& w = blocks[bi];
-        {   // intra-band bi-GRU over frequency, h0 = 0
+        Gru64Args ai{};     // intra-band bi-GRU over frequency, h0 = 0: rows = frames, steps = band positions
+        ai.x = x; ai.wfrag = m->C(w.intra.wfrag); ai.bias = m->C(w.intra.bias); ai.hstate = nullptr;
+        ai.nrows = B * Tc; ai.nsteps = Fp; ai.rdiv = 1;
+        ai.x_hi = (long)Fp * 64; ai.x_lo = 0; ai.x_step = 64;
+        Gru64Args ae{};     // inter-band GRUCell over time, one hidden state per band position
+        ae.wfrag = m->C(w.inter.wfrag); ae.bias = m->C(w.inter.bias);
+        ae.hstate = state + soff + (long)bi * Fp * 64;
+        ae.nrows = B * Fp; ae.nsteps = Tc; ae.ndirs = 1; ae.rdiv = Fp;
+        ae.x_hi = (long)Tc * Fp * 64; ae.x_lo = 64; ae.x_step = (long)Fp * 64;
+        ae.o_hi = ae.x_hi; ae.o_lo = 64; ae.o_step = ae.x_step; ae.o_dir_off = 0;
+        ae.h_hi = S; ae.h_lo = 64;
+        if (fused) {
+            {   // forward direction: plain scan, hf -> `hin` scratch [rows][Fp][64]
+                ProfScope ps(m, Fp >= 48 ? "gru64_intra_df" : "gru64_intra_erb");
+                ai.out = hin; ai.ndirs = 1; ai.o_hi = (long)Fp * 64; ai.o_lo = 0; ai.o_step = 64; ai.o_dir_off = 0;
+                hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ai);
+                // backward direction + fc_intra + ln_intra + residual
+                Gru64EpiArgs ea{ai, m->C(w.fci_epi), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b), hin, y};
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<2>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
+            }
+            std::swap(x, y);
+            {   // inter scan + fc_inter + ln_inter + residual
+                ProfScope ps(m, Fp >= 48 ? "gru64_inter_df" : "gru64_inter_erb");
+                ae.x = x; ae.out = nullptr;
+                Gru64EpiArgs ea{ae, m->C(w.fce_epi), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<1>), dim3((ae.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
+            }
+            std::swap(x, y);
+            continue;
+        }
+        {
             ProfScope ps(m, Fp >= 48 ? "gru64_intra_df" : "gru64_intra_erb");
-            Gru64Args a{};
-            a.x = x; a.out = hcat; a.wfrag = m->C(w.intra.wfrag); a.bias = m->C(w.intra.bias); a.hstate = nullptr;
-            a.nrows = B * Tc; a.nsteps = Fp; a.ndirs = 2; a.rdiv = 1;
-            a.x_hi = (long)Fp * 64; a.x_lo = 0; a.x_step = 64;
-            a.o_hi = (long)Fp * 128; a.o_lo = 0; a.o_step = 128; a.o_dir_off = 64;
-            hipLaunchKernelGGL(gru64_scan_kernel, dim3((a.nrows + 15) / 16, 2), dim3(256), 0, m->cur, a);
+            ai.out = hcat; ai.ndirs = 2;
+            ai.o_hi = (long)Fp * 128; ai.o_lo = 0; ai.o_step = 128; ai.o_dir_off = 64;
+            hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai);
         }
         {   // fc_intra + ln_intra + residual
             ProfScope ps(m, "dprnn_fc_ln");
@@ -519,16 +565,10 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
             launch_gemm_rows<4, 128, true>(m->cur, ap, m->C(w.fci_frag), ep, M, 128, 1);
         }
         std::swap(x, y);
-        {   // inter-band GRUCell over time, one hidden state per band position
+        {
             ProfScope ps(m, Fp >= 48 ? "gru64_inter_df" : "gru64_inter_erb");
-            Gru64Args a{};
-            a.x = x; a.out = hin; a.wfrag = m->C(w.inter.wfrag); a.bias = m->C(w.inter.bias);
-            a.hstate = state + soff + (long)bi * Fp * 64;
-            a.nrows = B * Fp; a.nsteps = Tc; a.ndirs = 1; a.rdiv = Fp;
-            a.x_hi = (long)Tc * Fp * 64; a.x_lo = 64; a.x_step = (long)Fp * 64;
-            a.o_hi = a.x_hi; a.o_lo = 64; a.o_step = a.x_step; a.o_dir_off = 0;
-            a.h_hi = S; a.h_lo = 64;
-            hipLaunchKernelGGL(gru64_scan_kernel, dim3((a.nrows + 15) / 16, 1), dim3(256), 0, m->cur, a);
+            ae.x = x; ae.out = hin;
+            hipLaunchKernelGGL(gru64_scan_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae);
         }
         {
             ProfScope ps(m, "dprnn_fc_ln");
@@ -1060,6 +1100,12 @@ extern "C" int dpdf_set_overlap(dpdf_model* m, int on) {
     (void)hipSetDevice(m->device);
     for (int g = 0; g < 2; ++g) { (void)hipStreamSynchronize(m->lanes[g].sA); (void)hipStreamSynchronize(m->lanes[g].sB); (void)hipStreamSynchronize(m->lanes[g].sC); }
     m->overlap = on;
+    return DPDF_OK;
+}
+extern "C" int dpdf_set_fuse_dprnn(dpdf_model* m, int on) {
+    if (!m) return set_err(DPDF_E_INVALID, "null model");
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->fuse_dprnn = on != 0;
     return DPDF_OK;
 }
 extern "C" int dpdf_sync(dpdf_model* m) {

@@ -382,3 +382,198 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
     for (int i = 0; i < 4; ++i)
         if (ok[i]) a.hstate[(long)rc[i] * a.h_stride + u0 + cl] = h_own[i];
 }
+
+// ---------------------------------------------------------------------------------------------
+// gru64_epi_kernel<EPI>: the same scan with the DPRNN block's Linear + LayerNorm + residual
+// (reference onnx_model/layers.py:178-181, 190-193) fused in, so neither the GRU outputs (h
+// sequences) of the inter-band scan nor the fwd|bwd concatenation of the intra-band scan make a
+// round trip through HBM, and the separate fc+LN kernels disappear.
+//   EPI = 1  inter-band scan:      y(s) = x(s) + LN(W_fc h'(s) + b)
+//   EPI = 2  intra-band BACKWARD:  y(p) = x(p) + LN(W_f hf(p) + W_b hb(p) + b), hf from the forward
+//            scan (run first, plain gru64_scan_kernel), p = position of step s
+// Everything is row-local.  The fc product rides on the h-part MFMAs of the NEXT step (same A
+// fragments of h'), lands in an LDS tile in MFMA C layout, and is normalised one barrier later by
+// the row-contiguous lanes (16 lanes x 4 values = one 64-channel row: LayerNorm statistics are two
+// 4-step butterflies inside a 16-lane group), which also hold the residual piece and issue the one
+// coalesced 16-byte store per lane.  Output therefore lags the recurrence by two steps; the loop
+// runs nsteps + 2 iterations with wave-uniform guards.
+struct Gru64EpiArgs {
+    Gru64Args g;            // g.out unused
+    const float* fc_frag;   // [part][wave 4][16][lane 64]: part 0 = W_fc columns fed by h' (inter: the only part;
+                            //                               intra: the bwd half), part 1 = the fwd half (EPI 2)
+    const float* fc_bias;   // [64]
+    const float* ln_g; const float* ln_b;   // [64]
+    const float* extra;     // EPI 2: hf tensor, addressed like x
+    float* y;               // output, addressed like x
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, EPI == 1 ? 3 : 2) void gru64_epi_kernel(Gru64EpiArgs ea) {
+    const Gru64Args& a = ea.g;
+    __shared__ __attribute__((aligned(16))) float Hs[2][16][68];
+    __shared__ __attribute__((aligned(16))) float Xs[4][16][68];      // ring: x(s-2) must outlive x(s+1)'s staging
+    __shared__ __attribute__((aligned(16))) float Ys[2][16][68];
+    __shared__ __attribute__((aligned(16))) float Es[EPI == 2 ? 3 : 1][EPI == 2 ? 16 : 1][EPI == 2 ? 68 : 4];   // hf ring (3 slots)
+    __shared__ float Wf[EPI == 1 ? 4 : 1][16][64];                    // EPI 1: fc B fragments in LDS (keeps 3 WG/CU)
+    __shared__ __attribute__((aligned(16))) float Lp[3][64];          // fc bias | ln gamma | ln beta
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dir = EPI == 2 ? 1 : 0;                                   // EPI 2 is the backward direction
+    const int row0 = blockIdx.x * 16;
+    const int cl = lane & 15, q = lane >> 4;
+
+    float wih[3][16], whh[3][16];
+    {
+        const float* wp = a.wfrag + ((size_t)(dir * 4 + w) * 2) * 3 * 16 * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                wih[g][j] = wp[(size_t)((0 * 3 + g) * 16 + j) * 64];
+                whh[g][j] = wp[(size_t)((1 * 3 + g) * 16 + j) * 64];
+            }
+    }
+    const float* bp = a.bias + (size_t)dir * 256 + 16 * w + cl;
+    const float b_r = bp[0], b_z = bp[64], b_in = bp[128], b_hn = bp[192];
+    float wfc[EPI == 2 ? 2 : 1][EPI == 2 ? 16 : 1];                   // EPI 2: fc B fragments in registers (2 WG/CU anyway)
+    if (EPI == 1) {
+        for (int i = tid; i < 4 * 16 * 64; i += 256) (&Wf[0][0][0])[i] = ea.fc_frag[i];
+    } else {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wfc[pt][j] = ea.fc_frag[((size_t)(pt * 4 + w) * 16 + j) * 64 + lane];
+    }
+    if (tid < 64) { Lp[0][tid] = ea.fc_bias[tid]; Lp[1][tid] = ea.ln_g[tid]; Lp[2][tid] = ea.ln_b[tid]; }
+
+    const int hi0 = row0 / a.rdiv, lo0 = row0 - hi0 * a.rdiv;
+    const float* xbase = a.x + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
+    const float* ebase = EPI == 2 ? ea.extra + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo : nullptr;
+    float* ybase = ea.y + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
+    const int srow = 4 * w + q, scol = 4 * cl;
+    int sx_off; bool so_ok;
+    {
+        int rs = row0 + srow;
+        so_ok = rs < a.nrows;
+        if (rs >= a.nrows) rs = a.nrows - 1;
+        sx_off = (int)((long)(rs / a.rdiv - hi0) * a.x_hi + (long)(rs % a.rdiv - lo0) * a.x_lo) + scol;
+    }
+    float h_own[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int rc = row0 + q * 4 + i;
+        if (rc >= a.nrows) rc = a.nrows - 1;
+        float hv = a.hstate ? a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] : 0.f;
+        h_own[i] = hv;
+        Hs[1][q * 4 + i][16 * w + cl] = hv;
+    }
+    const int n = a.nsteps;
+    auto pos_of = [&](int s) { return dir ? n - 1 - s : s; };
+    {
+        *(float4*)&Xs[0][srow][scol] = *(const float4*)(xbase + sx_off + (long)pos_of(0) * a.x_step);
+        if (EPI == 2) *(float4*)&Es[0][srow][scol] = *(const float4*)(ebase + sx_off + (long)pos_of(0) * a.x_step);   // Es(s) lives in slot s % 3
+    }
+    __syncthreads();
+
+    for (int s = 0; s < n + 2; ++s) {
+        const int hb = s & 1;                 // Hs/Ys/Es slot written this step
+        // ---- finalize step s-2: LayerNorm + residual on the row-contiguous pieces, one store per lane
+        if (s >= 2) {
+            const float4 yv = *(const float4*)&Ys[hb][srow][scol];            // fc(s-2) + bias, written during step s-1
+            const float4 rv = *(const float4*)&Xs[(s - 2) & 3][srow][scol];   // residual x(s-2)
+            float s1 = yv.x + yv.y + yv.z + yv.w;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) s1 += __shfl_xor(s1, off, 64);
+            const float mean = s1 * (1.0f / 64.0f);
+            const float d0 = yv.x - mean, d1 = yv.y - mean, d2 = yv.z - mean, d3 = yv.w - mean;
+            float s2 = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) s2 += __shfl_xor(s2, off, 64);
+            const float inv = rsqrtf(s2 * (1.0f / 64.0f) + 1e-5f);
+            const float4 gg = *(const float4*)&Lp[1][scol], bb = *(const float4*)&Lp[2][scol];
+            float4 o;
+            o.x = rv.x + d0 * inv * gg.x + bb.x; o.y = rv.y + d1 * inv * gg.y + bb.y;
+            o.z = rv.z + d2 * inv * gg.z + bb.z; o.w = rv.w + d3 * inv * gg.w + bb.w;
+            if (so_ok) *(float4*)(ybase + sx_off + (long)pos_of(s - 2) * a.x_step) = o;
+        }
+        // ---- loads for step s+1
+        float4 xnext = make_float4(0.f, 0.f, 0.f, 0.f), enext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s + 1 < n) {
+            xnext = *(const float4*)(xbase + sx_off + (long)pos_of(s + 1) * a.x_step);
+            if (EPI == 2) enext = *(const float4*)(ebase + sx_off + (long)pos_of(s + 1) * a.x_step);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 ar = {b_r, b_r, b_r, b_r}, az = {b_z, b_z, b_z, b_z};
+        f32x4 axn = {b_in, b_in, b_in, b_in}, ahn = {b_hn, b_hn, b_hn, b_hn};
+        f32x4 ay = {0.f, 0.f, 0.f, 0.f};
+        if (s < n) {
+            const float* xrow = &Xs[s & 3][cl][4 * q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 x4 = *(const float4*)(xrow + 16 * c);
+                const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    ar = mfma16(xv[kb], wih[0][c * 4 + kb], ar);
+                    az = mfma16(xv[kb], wih[1][c * 4 + kb], az);
+                    axn = mfma16(xv[kb], wih[2][c * 4 + kb], axn);
+                }
+            }
+        }
+        if (s <= n) {
+            // h-part of step s and fc of step s-1 share the A fragments of h'(s-1)
+            const float* hrow = &Hs[hb ^ 1][cl][4 * q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 h4 = *(const float4*)(hrow + 16 * c);
+                const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    ar = mfma16(hv[kb], whh[0][c * 4 + kb], ar);
+                    az = mfma16(hv[kb], whh[1][c * 4 + kb], az);
+                    ahn = mfma16(hv[kb], whh[2][c * 4 + kb], ahn);
+                    ay = mfma16(hv[kb], EPI == 1 ? Wf[w][c * 4 + kb][lane] : wfc[0][c * 4 + kb], ay);
+                }
+            }
+            if (EPI == 2) {
+                const float* erow = &Es[(s + 2) % 3][cl][4 * q];             // slot (s-1) % 3: hf at the position of step s-1
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 e4 = *(const float4*)(erow + 16 * c);
+                    const float ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) ay = mfma16(ev[kb], wfc[EPI == 2 ? 1 : 0][c * 4 + kb], ay);
+                }
+            }
+        }
+        if (s < n) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float r = sigmoid_f(ar[i]);
+                float z = sigmoid_f(az[i]);
+                float nn = tanh_f(axn[i] + r * ahn[i]);
+                float h = (1.0f - z) * nn + z * h_own[i];
+                h_own[i] = h;
+                Hs[hb][q * 4 + i][16 * w + cl] = h;
+            }
+        }
+        if (s >= 1 && s <= n) {
+            const float fb = Lp[0][16 * w + cl];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Ys[hb ^ 1][q * 4 + i][16 * w + cl] = ay[i] + fb;    // fc(s-1): read at step s+1 from Ys[(s+1)&1]
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < n) {
+            *(float4*)&Xs[(s + 1) & 3][srow][scol] = xnext;
+            if (EPI == 2) *(float4*)&Es[(s + 1) % 3][srow][scol] = enext;  // read during step s+2; slot (s-1)%3 is the one in use now
+        }
+        __syncthreads();
+    }
+    if (a.hstate) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int rc = row0 + q * 4 + i;
+            if (rc < a.nrows)
+                a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] = h_own[i];
+        }
+    }
+}

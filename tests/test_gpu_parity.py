@@ -100,6 +100,22 @@ def test_time_chunking_and_state_carry_invariance(case, chunk):
     np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5)
 
 
+def test_fused_and_unfused_dprnn_paths_agree(case):
+    """fc + LayerNorm + residual inside the GRU-64 scans (default) vs as separate GEMM kernels."""
+    g, meta, o, m = case
+    spec = o.stft(g["wav"])[:30]
+    ref, st_ref = o.run_frames(spec)
+    outs = []
+    for fuse in (True, False):
+        m.set_fuse_dprnn(fuse)
+        out, st = m.run_frames(spec, m.initial_state())
+        assert np.abs(out - ref).max() < STAGE_REL_TOL * float(np.abs(ref).max())
+        assert np.abs(st - st_ref).max() < 2e-4
+        outs.append(out)
+    m.set_fuse_dprnn(True)
+    assert np.abs(outs[0] - outs[1]).max() < 2e-5 * float(np.abs(ref).max())
+
+
 def test_single_frame_chunks_are_race_free_under_stream_overlap(case):
     """Regression: with one frame per launch the 4-workgroup GRU-256 cluster has no inter-step
     hand-off, and a fast workgroup used to overwrite the carried state before a late peer had read
