@@ -115,6 +115,7 @@ def main() -> None:
     ap.add_argument("--no-fuse", action="store_true", help="run fc+LN of the DPRNN blocks as separate kernels")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the extra serial profiling step")
     ap.add_argument("--cpu-clip-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-clips-per-thread", type=int, default=5)
     args = ap.parse_args()
@@ -193,40 +194,89 @@ def main() -> None:
         dt = float(tmax.item())
     prof = model.profile_report()
     model.profile(False)
+    fused = not args.no_fuse
+    # one extra serial step (not timed into `value`) to time the kernels without co-running streams
+    iso_prof, iso_ms, kernel_stats_iso = None, None, None
+    if rank == 0 and not args.no_isolated:
+        model.set_overlap(0)
+        model.profile(True)
+        sync(); t1 = time.perf_counter(); step(); sync(); iso_ms = 1e3 * (time.perf_counter() - t1)
+        iso_prof = model.profile_report()
+        model.profile(False)
+        model.set_overlap(args.overlap if args.overlap >= 0 else 3)
 
     if rank == 0:
         finite = bool(torch.isfinite(out).all().item())
         total_frames = world * B * T * args.steps
         value = total_frames / dt
-        # dominant kernel: gru64_scan_kernel (all its launches: intra-band bi-GRU over F' and
-        # inter-band GRU over T, DF branch F'=48 and ERB branch F'=8).  rocprofv3 --kernel-trace
-        # aggregates exactly these launches under one kernel name (profiles/).
-        gru = {k: v for k, v in prof.items() if k.startswith("gru64_")}
-        ms = sum(v[0] for v in gru.values())
-        calls = sum(v[1] for v in gru.values())
-        # per frame and DPRNN block: intra = 2 directions x F' steps, inter = F' rows x 1 step
-        flops_total = args.steps * NB * (B * T) * (48 + 8) * 3 * GRU64_FLOP_PER_ROW_STEP
-        achieved = flops_total / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # Dominant kernel family: the GRU-64 scans of the DPRNN blocks (reference layers.py:159-196).  With the
+        # fused epilogues they are three kernels; rocprofv3 --kernel-trace reports the same three names:
+        #   gru64_scan_kernel      intra-band forward direction            49 152 FLOP per (row, step)
+        #   gru64_epi_kernel<2>    intra-band backward + fc_intra + LN     49 152 + 2*64*128 FLOP
+        #   gru64_epi_kernel<1>    inter-band + fc_inter + LN              49 152 + 2*64*64 FLOP
+        # rows*steps per step of the bench: NB blocks x B*T frames x (48 DF + 8 ERB) band positions.
+        rs = NB * (B * T) * (48 + 8)
+        fam = {
+            "gru64_scan_kernel": GRU64_FLOP_PER_ROW_STEP * (1 if fused else 3),
+            "gru64_epi_kernel<2>": GRU64_FLOP_PER_ROW_STEP + 2 * 64 * 128,
+            "gru64_epi_kernel<1>": GRU64_FLOP_PER_ROW_STEP + 2 * 64 * 64,
+        }
+
+        def kernel_stats(p):
+            out = {}
+            for kname, flop_rs in fam.items():
+                sel = {k: v for k, v in p.items() if k.split("/")[0] == kname}
+                ms_ = sum(v[0] for v in sel.values()); n_ = sum(v[1] for v in sel.values())
+                if n_:
+                    fl = flop_rs * rs * args.steps
+                    out[kname] = {"ms_total": ms_, "launches": n_, "avg_launch_ms": ms_ / n_,
+                                  "flop_per_launch": fl / n_, "tflops": fl / (ms_ * 1e-3) / 1e12}
+            return out
+
+        ks = kernel_stats(prof)
+        if iso_prof is not None:
+            steps_saved = args.steps; args.steps = 1
+            kernel_stats_iso = kernel_stats(iso_prof)
+            args.steps = steps_saved
+        dom = "gru64_epi_kernel<2>" if "gru64_epi_kernel<2>" in ks else "gru64_scan_kernel"
+        ms, calls = ks[dom]["ms_total"], ks[dom]["launches"]
+        achieved = ks[dom]["tflops"]
+        fam_ms = sum(v["ms_total"] for v in ks.values())
+        fam_flop = sum(v["flop_per_launch"] * v["launches"] for v in ks.values())
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
         # separate --pmc runs of this same command, gfx950 x2 read correction applied; profiles/README.md)
-        traffic, traffic_note = None, "no PMC summary in profiles/"
+        traffic, traffic_note = None, "no PMC summary in profiles/ for this kernel"
         try:
-            pmc = json.loads((ROOT / "profiles" / "r1_final_pmc_summary.json").read_text())["gru64_scan_kernel"]
+            pmc_all = json.loads((ROOT / "profiles" / "pmc_summary.json").read_text())
+            pmc = next(v for k, v in pmc_all.items() if k.replace("void ", "") == dom)
             traffic = pmc["hbm_bytes_per_dispatch_corrected"]
-            traffic_note = "bytes/launch, profiles/r1_final_pmc_summary.json (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            traffic_note = "bytes/launch, profiles/pmc_summary.json (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         except Exception:
             pass
+        # algorithmic bytes: x row in, (hf row in,) y row out = 256 B each per (row, step)
+        alg_bytes = {"gru64_scan_kernel": 2 * 256, "gru64_epi_kernel<2>": 3 * 256, "gru64_epi_kernel<1>": 2 * 256}[dom]
         roofline = {
-            "bound": "mfma", "kernel": "gru64_scan_kernel (all launches: intra/inter x DF/ERB)",
+            "bound": "mfma", "kernel": dom + " (all launches, DF + ERB branch)",
             "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-            "algorithmic_bytes_per_launch": NB * (B * T) * (48 + 8) * 64 * 4 * (1 + 2 + 1 + 1) * args.steps / calls if calls else None,
-            "avg_launch_ms": ms / calls if calls else None, "launches": calls,
-            "flop_per_launch": flops_total / calls if calls else None,
+            "algorithmic_bytes_per_launch": alg_bytes * rs * args.steps / calls,
+            "avg_launch_ms": ms / calls, "launches": calls, "flop_per_launch": ks[dom]["flop_per_launch"],
+            "timing": "HIP events on the launching stream inside the timed region; launches overlap with the other "
+                      "streams of the pipeline there (see roofline_isolated for the same kernels run back to back)",
+            "gru64_family": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "launches": v["launches"],
+                                 "tflops": round(v["tflops"], 1)} for k, v in ks.items()},
+            "gru64_family_tflops": fam_flop / (fam_ms * 1e-3) / 1e12 if fam_ms else None,
             "whole_path_frac": value * FLOP_PER_FRAME / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
             "per_class_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
-            "gru64_share_of_step": ms / (dt * 1e3) if dt > 0 else None,
         }
+        if iso_prof is not None:
+            ki = kernel_stats_iso
+            roofline["roofline_isolated"] = {
+                "note": "one extra step AFTER the timed region with the stream pipeline switched off (kernels back to back)",
+                "ms_per_step": iso_ms,
+                "kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "tflops": round(v["tflops"], 1),
+                                "frac": round(v["tflops"] / FP32_MFMA_PEAK_TFLOPS, 3)} for k, v in ki.items()},
+            }
         line = {
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,

@@ -535,16 +535,18 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
         ae.h_hi = S; ae.h_lo = 64;
         if (fused) {
             {   // forward direction: plain scan, hf -> `hin` scratch [rows][Fp][64]
-                ProfScope ps(m, Fp >= 48 ? "gru64_intra_df" : "gru64_intra_erb");
+                ProfScope ps(m, Fp >= 48 ? "gru64_scan_kernel/intra_fwd_df" : "gru64_scan_kernel/intra_fwd_erb");
                 ai.out = hin; ai.ndirs = 1; ai.o_hi = (long)Fp * 64; ai.o_lo = 0; ai.o_step = 64; ai.o_dir_off = 0;
                 hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ai);
-                // backward direction + fc_intra + ln_intra + residual
+            }
+            {   // backward direction + fc_intra + ln_intra + residual
+                ProfScope ps(m, Fp >= 48 ? "gru64_epi_kernel<2>/intra_bwd_df" : "gru64_epi_kernel<2>/intra_bwd_erb");
                 Gru64EpiArgs ea{ai, m->C(w.fci_epi), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b), hin, y};
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<2>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
             }
             std::swap(x, y);
             {   // inter scan + fc_inter + ln_inter + residual
-                ProfScope ps(m, Fp >= 48 ? "gru64_inter_df" : "gru64_inter_erb");
+                ProfScope ps(m, Fp >= 48 ? "gru64_epi_kernel<1>/inter_df" : "gru64_epi_kernel<1>/inter_erb");
                 ae.x = x; ae.out = nullptr;
                 Gru64EpiArgs ea{ae, m->C(w.fce_epi), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<1>), dim3((ae.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
@@ -553,7 +555,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
             continue;
         }
         {
-            ProfScope ps(m, Fp >= 48 ? "gru64_intra_df" : "gru64_intra_erb");
+            ProfScope ps(m, Fp >= 48 ? "gru64_scan_kernel/intra_df" : "gru64_scan_kernel/intra_erb");
             ai.out = hcat; ai.ndirs = 2;
             ai.o_hi = (long)Fp * 128; ai.o_lo = 0; ai.o_step = 128; ai.o_dir_off = 64;
             hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai);
@@ -566,7 +568,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
         }
         std::swap(x, y);
         {
-            ProfScope ps(m, Fp >= 48 ? "gru64_inter_df" : "gru64_inter_erb");
+            ProfScope ps(m, Fp >= 48 ? "gru64_scan_kernel/inter_df" : "gru64_scan_kernel/inter_erb");
             ae.x = x; ae.out = hin;
             hipLaunchKernelGGL(gru64_scan_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae);
         }
