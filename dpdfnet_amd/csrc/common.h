@@ -33,3 +33,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_SIGMOID) return sigmoid_f(v);
     return v;
 }
+
+// all-reduce (sum) inside each 16-lane DPP row: four row-rotate adds on the VALU, no LDS crossbar.
+// (A 64-channel row of the row-contiguous tile layout is exactly one DPP row x 4 values per lane.)
+__device__ __forceinline__ float row16_allreduce_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v;
+}

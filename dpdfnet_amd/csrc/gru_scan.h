@@ -407,14 +407,18 @@ struct Gru64EpiArgs {
     float* y;               // output, addressed like x
 };
 
+#ifndef EPI1_WF_LDS
+#define EPI1_WF_LDS 1     // 1: inter-band fc fragments in LDS, 3 WG/CU; 0: in registers, 2 WG/CU
+#endif
 template <int EPI>
-__global__ __launch_bounds__(256, EPI == 1 ? 3 : 2) void gru64_epi_kernel(Gru64EpiArgs ea) {
+__global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_epi_kernel(Gru64EpiArgs ea) {
     const Gru64Args& a = ea.g;
     __shared__ __attribute__((aligned(16))) float Hs[2][16][68];
     __shared__ __attribute__((aligned(16))) float Xs[4][16][68];      // ring: x(s-2) must outlive x(s+1)'s staging
     __shared__ __attribute__((aligned(16))) float Ys[2][16][68];
     __shared__ __attribute__((aligned(16))) float Es[EPI == 2 ? 3 : 1][EPI == 2 ? 16 : 1][EPI == 2 ? 68 : 4];   // hf ring (3 slots)
-    __shared__ float Wf[EPI == 1 ? 4 : 1][16][64];                    // EPI 1: fc B fragments in LDS (keeps 3 WG/CU)
+    constexpr bool WF_LDS = EPI == 1 && EPI1_WF_LDS;
+    __shared__ float Wf[WF_LDS ? 4 : 1][16][64];                      // EPI 1: fc B fragments in LDS (keeps 3 WG/CU)
     __shared__ __attribute__((aligned(16))) float Lp[3][64];          // fc bias | ln gamma | ln beta
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int dir = EPI == 2 ? 1 : 0;                                   // EPI 2 is the backward direction
@@ -434,12 +438,12 @@ __global__ __launch_bounds__(256, EPI == 1 ? 3 : 2) void gru64_epi_kernel(Gru64E
     }
     const float* bp = a.bias + (size_t)dir * 256 + 16 * w + cl;
     const float b_r = bp[0], b_z = bp[64], b_in = bp[128], b_hn = bp[192];
-    float wfc[EPI == 2 ? 2 : 1][EPI == 2 ? 16 : 1];                   // EPI 2: fc B fragments in registers (2 WG/CU anyway)
-    if (EPI == 1) {
+    float wfc[EPI == 2 ? 2 : 1][WF_LDS ? 1 : 16];                     // otherwise in registers (2 WG/CU anyway)
+    if (WF_LDS) {
         for (int i = tid; i < 4 * 16 * 64; i += 256) (&Wf[0][0][0])[i] = ea.fc_frag[i];
     } else {
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+        for (int pt = 0; pt < (EPI == 2 ? 2 : 1); ++pt)
 #pragma unroll
             for (int j = 0; j < 16; ++j) wfc[pt][j] = ea.fc_frag[((size_t)(pt * 4 + w) * 16 + j) * 64 + lane];
     }
@@ -477,24 +481,22 @@ __global__ __launch_bounds__(256, EPI == 1 ? 3 : 2) void gru64_epi_kernel(Gru64E
     for (int s = 0; s < n + 2; ++s) {
         const int hb = s & 1;                 // Hs/Ys/Es slot written this step
         // ---- finalize step s-2: LayerNorm + residual on the row-contiguous pieces, one store per lane
+        auto finalize = [&]() __attribute__((always_inline)) {
         if (s >= 2) {
-            const float4 yv = *(const float4*)&Ys[hb][srow][scol];            // fc(s-2) + bias, written during step s-1
-            const float4 rv = *(const float4*)&Xs[(s - 2) & 3][srow][scol];   // residual x(s-2)
-            float s1 = yv.x + yv.y + yv.z + yv.w;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) s1 += __shfl_xor(s1, off, 64);
-            const float mean = s1 * (1.0f / 64.0f);
-            const float d0 = yv.x - mean, d1 = yv.y - mean, d2 = yv.z - mean, d3 = yv.w - mean;
-            float s2 = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) s2 += __shfl_xor(s2, off, 64);
-            const float inv = rsqrtf(s2 * (1.0f / 64.0f) + 1e-5f);
-            const float4 gg = *(const float4*)&Lp[1][scol], bb = *(const float4*)&Lp[2][scol];
-            float4 o;
-            o.x = rv.x + d0 * inv * gg.x + bb.x; o.y = rv.y + d1 * inv * gg.y + bb.y;
-            o.z = rv.z + d2 * inv * gg.z + bb.z; o.w = rv.w + d3 * inv * gg.w + bb.w;
-            if (so_ok) *(float4*)(ybase + sx_off + (long)pos_of(s - 2) * a.x_step) = o;
-        }
+                const float4 yv = *(const float4*)&Ys[hb][srow][scol];            // fc(s-2) + bias, written during step s-1
+                const float4 rv = *(const float4*)&Xs[(s - 2) & 3][srow][scol];   // residual x(s-2)
+                const float mean = row16_allreduce_sum(yv.x + yv.y + yv.z + yv.w) * (1.0f / 64.0f);
+                const float d0 = yv.x - mean, d1 = yv.y - mean, d2 = yv.z - mean, d3 = yv.w - mean;
+                const float s2 = row16_allreduce_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+                const float inv = rsqrtf(s2 * (1.0f / 64.0f) + 1e-5f);
+                const float4 gg = *(const float4*)&Lp[1][scol], bb = *(const float4*)&Lp[2][scol];
+                float4 o;
+                o.x = rv.x + d0 * inv * gg.x + bb.x; o.y = rv.y + d1 * inv * gg.y + bb.y;
+                o.z = rv.z + d2 * inv * gg.z + bb.z; o.w = rv.w + d3 * inv * gg.w + bb.w;
+                if (so_ok) *(float4*)(ybase + sx_off + (long)pos_of(s - 2) * a.x_step) = o;
+            }
+        };
+        if (EPI == 1) finalize();
         // ---- loads for step s+1
         float4 xnext = make_float4(0.f, 0.f, 0.f, 0.f), enext = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s + 1 < n) {
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(256, EPI == 1 ? 3 : 2) void gru64_epi_kernel(Gru64E
                     ar = mfma16(hv[kb], whh[0][c * 4 + kb], ar);
                     az = mfma16(hv[kb], whh[1][c * 4 + kb], az);
                     ahn = mfma16(hv[kb], whh[2][c * 4 + kb], ahn);
-                    ay = mfma16(hv[kb], EPI == 1 ? Wf[w][c * 4 + kb][lane] : wfc[0][c * 4 + kb], ay);
+                    ay = mfma16(hv[kb], WF_LDS ? Wf[w][c * 4 + kb][lane] : wfc[0][WF_LDS ? 0 : c * 4 + kb], ay);
                 }
             }
             if (EPI == 2) {
@@ -545,6 +547,7 @@ __global__ __launch_bounds__(256, EPI == 1 ? 3 : 2) void gru64_epi_kernel(Gru64E
                 }
             }
         }
+        if (EPI == 2) finalize();          // behind the MFMA block: its latency hides under it (registers allow it at 2 WG/CU)
         if (s < n) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
