@@ -981,7 +981,11 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
     for (int g = 0; g < 2; ++g) {
         Lane& L = m->lanes[g];
         HIP_TRY(hipStreamCreateWithFlags(&L.sA, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&L.sB, hipStreamNonBlocking));
+        {   // stage 2 is latency-bound (GRU-256 cluster scans): give its workgroups dispatch priority
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&L.sB, hipStreamNonBlocking, hi));
+        }
         HIP_TRY(hipStreamCreateWithFlags(&L.sC, hipStreamNonBlocking));
         for (int p = 0; p < 2; ++p) {
             HIP_TRY(hipEventCreateWithFlags(&L.ev_s1[p], hipEventDisableTiming));
