@@ -236,8 +236,11 @@ class HipModel:
     def set_overlap(self, mask: int) -> None:
         _check(self._L.dpdf_set_overlap(self._h, int(mask)))
 
-    def set_fuse_dprnn(self, on: bool) -> None:
-        _check(self._L.dpdf_set_fuse_dprnn(self._h, 1 if on else 0))
+    def set_fuse_dprnn(self, mode) -> None:
+        """True/"always": fused GRU-64 epilogues for every chunk; False/"never": separate GEMM
+        kernels; "auto" (engine default): fused only when the chunk fills the chip."""
+        code = {"never": 0, "auto": 1, "always": 2, False: 0, True: 2}[mode]
+        _check(self._L.dpdf_set_fuse_dprnn(self._h, code))
 
     def debug_fetch(self, name: str) -> np.ndarray:
         n = self._L.dpdf_debug_fetch(self._h, name.encode(), None, 0)

@@ -203,7 +203,8 @@ struct dpdf_model {
     // bit 0: stage 2 on its own stream; bit 1: ERB encoder branch on its own stream (single-lane runs);
     // bit 2: split the batch over two lanes.  0 = everything serial on the main stream (A/B timing).
     int overlap = 3;
-    int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans (0: separate GEMM kernels)
+    int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
+                                       // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
     bool two_lanes_active = false;
     std::mutex mu;
     float* consts = nullptr;           // device arena
@@ -519,7 +520,10 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
                  float* state, long S, int soff, int B, int Tc) {
     const int M = B * Tc * Fp;
     float* x = xa; float* y = xb;
-    const bool fused = m->fuse_dprnn && (Fp % 4 == 0);
+    // the fused form runs the two intra directions back to back (half the workgroups each) and carries the fc/LN
+    // latency inside the scan step, so it only pays once B*Tc/16 tiles oversubscribe the 256 CUs; below that
+    // (streaming hops, tiny batches) the direction-parallel scan + wide GEMM wins (tools/sweep2.sh, profiles/README)
+    const bool fused = (Fp % 4 == 0) && (m->fuse_dprnn == 2 || (m->fuse_dprnn == 1 && (long)B * Tc >= 3072));
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         const DprnnW& w = blocks[bi];
         Gru64Args ai{};     // intra-band bi-GRU over frequency, h0 = 0: rows = frames, steps = band positions
@@ -1111,7 +1115,7 @@ extern "C" int dpdf_set_overlap(dpdf_model* m, int on) {
 extern "C" int dpdf_set_fuse_dprnn(dpdf_model* m, int on) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
     std::lock_guard<std::mutex> lk(m->mu);
-    m->fuse_dprnn = on != 0;
+    m->fuse_dprnn = on < 0 ? 0 : (on > 2 ? 2 : on);
     return DPDF_OK;
 }
 extern "C" int dpdf_sync(dpdf_model* m) {

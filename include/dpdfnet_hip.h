@@ -101,9 +101,10 @@ int dpdf_set_chunk_frames(dpdf_model* m, int frames);
 /* 1 (default): stage 2 of chunk i (GRU-256 scans, decoders) and the ERB encoder branch run on their own
  * HIP streams underneath stage 1 of chunk i+1; 0: everything serial on one stream (A/B timing). */
 int dpdf_set_overlap(dpdf_model* m, int on);
-/* 1 (default): fc + LayerNorm + residual of every DPRNN block run inside the GRU-64 scan kernels;
- * 0: as separate GEMM kernels (A/B timing and cross-check). */
-int dpdf_set_fuse_dprnn(dpdf_model* m, int on);
+/* Where fc + LayerNorm + residual of every DPRNN block run: 2 always inside the GRU-64 scan kernels;
+ * 0 always as separate GEMM kernels; 1 (default) picks per chunk -- fused once streams x frames fills the
+ * chip (>= 3072 frame rows), separate below that (single-hop streaming, small batches). */
+int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
 
 /* Debug/test hook: copy an intermediate tensor of the last processed chunk to the host
  * ("e0","e1","e2","e3","e3_dprnn","c0","c1","c1_dprnn","emb","m","coefs","xm","feat_erb",

@@ -8,8 +8,10 @@ ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
 from dpdfnet_amd import backend as be
 from dpdfnet_amd.weights import synth_blob
 
-def run(sr, nb, S, hops_per_call, calls, warm=20):
+def run(sr, nb, S, hops_per_call, calls, warm=20, overlap=None, fuse=None):
     m = be.HipModel(sr, nb, synth_blob(be.manifest(sr, nb), 20260417), 0)
+    if overlap is not None: m.set_overlap(overlap)
+    if fuse is not None: m.set_fuse_dprnn(fuse)
     st = be.HipStreams(m, S)
     rng = np.random.default_rng(0)
     hop = m.hop
@@ -22,13 +24,15 @@ def run(sr, nb, S, hops_per_call, calls, warm=20):
     us = 1e6 * dt / calls
     fps = S * hops_per_call * calls / dt
     audio_per_call = hops_per_call * hop / sr
-    print(json.dumps({"sr": sr, "nb": nb, "streams": S, "hops_per_call": hops_per_call, "us_per_call": round(us, 1),
+    print(json.dumps({"overlap": overlap, "fuse": fuse, "sr": sr, "nb": nb, "streams": S, "hops_per_call": hops_per_call, "us_per_call": round(us, 1),
                       "frames_per_s": round(fps), "rtf": round((dt / calls) / audio_per_call, 4)}))
     st.close(); m.close()
 
 if __name__ == "__main__":
-    run(48000, 8, 64, 1, 200)
-    run(48000, 8, 64, 4, 100)
-    run(48000, 8, 64, 16, 50)
+    for hops in (1, 4, 16):
+        run(48000, 8, 64, hops, 200 if hops == 1 else 50)
     run(16000, 2, 1, 1, 200)
-    run(16000, 4, 64, 1, 200)
+    if "--ablate" in sys.argv:
+        for ov in (0, 1, 3):
+            for fu in ("always", "never"):
+                run(48000, 8, 64, 1, 200, overlap=ov, fuse=fu)
