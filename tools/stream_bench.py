@@ -29,6 +29,8 @@ def run(sr, nb, S, hops_per_call, calls, warm=20, overlap=None, fuse=None):
     st.close(); m.close()
 
 if __name__ == "__main__":
+    if "--one" in sys.argv:
+        run(48000, 8, 64, 1, 200, warm=20); sys.exit(0)
     for hops in (1, 4, 16):
         run(48000, 8, 64, hops, 200 if hops == 1 else 50)
     run(16000, 2, 1, 1, 200)
