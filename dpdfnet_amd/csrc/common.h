@@ -22,6 +22,12 @@ __device__ __forceinline__ float tanh_f(float x) {
     return copysignf(t, x);
 }
 
+// GRU cell tail (reference onnx_model/layers.py:1235-1259: n = tanh(x_n + r * h_n), h' = (1-z) n + z h) with the FMA
+// contraction pinned, so that every row a lane holds -- and every kernel variant -- rounds identically (identical
+// clips in different batch slots must come out bit-identical; left to the compiler, unrolled copies may differ).
+__device__ __forceinline__ float gru_candidate(float r, float hn, float xn) { return tanh_f(__builtin_fmaf(r, hn, xn)); }
+__device__ __forceinline__ float gru_blend(float z, float n, float h) { return __builtin_fmaf(z, h - n, n); }
+
 // K index supplied by lane-quad q (= lane>>4) for MFMA kb (0..3) of 16-wide K chunk c.
 // All A fragments (4 contiguous floats per lane per chunk) and all packed B fragments use it.
 __host__ __device__ inline int kperm(int c, int q, int kb) { return 16 * c + 4 * q + kb; }

@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
 #else
             float r = sigmoid_f(ar[i]);
             float z = sigmoid_f(az[i]);
-            float n = tanh_f(axn[i] + r * ahn[i]);
-            float h = (1.0f - z) * n + z * h_own[i];
+            float n = gru_candidate(r, ahn[i], axn[i]);
+            float h = gru_blend(z, n, h_own[i]);
 #endif
             h_own[i] = h;
             Hs[buf][q * 4 + i][16 * w + cl] = h;
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(1024) void gru256_scan_kernel(Gru256Args a) {
         for (int i = 0; i < 4; ++i) {
             float r = sigmoid_f(ar[i]);
             float z = sigmoid_f(az[i]);
-            float n = tanh_f(axn[i] + r * ahn[i]);
-            float h = (1.0f - z) * n + z * h_own[i];
+            float n = gru_candidate(r, ahn[i], axn[i]);
+            float h = gru_blend(z, n, h_own[i]);
             h_own[i] = h;
             Hs[buf ^ 1][q * 4 + i][16 * w + cl] = h;
             if (ok[i]) a.out[((size_t)rc[i] * a.Tc + t) * 256 + 16 * w + cl] = h;
@@ -347,32 +347,47 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
         for (int i = 0; i < 4; ++i) {
             float r = sigmoid_f(ar[i]);
             float z = sigmoid_f(az[i]);
-            float n = tanh_f(axn[i] + r * ahn[i]);
-            float h = (1.0f - z) * n + z * h_own[i];
-            h_own[i] = h;
-            Hs[nxt][q * 4 + i][u0 + cl] = h;
-            __hip_atomic_store(slot + (q * 4 + i) * 256 + u0 + cl,
-                               ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(h),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ok[i]) a.out[((size_t)rc[i] * a.Tc + t) * 256 + u0 + cl] = h;
+            float n = gru_candidate(r, ahn[i], axn[i]);
+            h_own[i] = gru_blend(z, n, h_own[i]);
         }
-        // sweep the three peers' slices (3 x 16 rows x 64 units = 12 granules per thread).  Also after the
-        // LAST step: a workgroup may overwrite the carried state (below) only once every peer has
-        // provably consumed the old one, i.e. has published its own last step.
+        // publish first (the peers' next step waits on these), then the local copies
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __hip_atomic_store(slot + (q * 4 + i) * 256 + u0 + cl,
+                               ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(h_own[i]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Hs[nxt][q * 4 + i][u0 + cl] = h_own[i];
+            if (ok[i]) a.out[((size_t)rc[i] * a.Tc + t) * 256 + u0 + cl] = h_own[i];
+        }
+        // sweep the three peers' slices (3 x 16 rows x 64 units = 12 granules per thread): all 12 loads go
+        // out back to back and are checked together -- one L2 round trip per sweep instead of twelve
+        // dependent ones; a sweep that finds a stale granule is simply repeated.  Also after the LAST
+        // step: a workgroup may overwrite the carried state (below) only once every peer has provably
+        // consumed the old one, i.e. has published its own last step.
         {
+            unsigned long long xv[12];
+            unsigned spins = 0;
+            for (;;) {
+                bool all_in = true;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    const int idx = tid + 256 * k;
+                    const int s = idx >> 10, r = (idx >> 6) & 15, u = 64 * ((j + 1 + s) & 3) + (idx & 63);
+                    xv[k] = __hip_atomic_load(slot + r * 256 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < 12; ++k) all_in &= (unsigned)(xv[k] >> 32) == epoch;
+                if (all_in) break;
+                if (++spins > (1u << 22)) { *a.err = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
                 const int idx = tid + 256 * k;
                 const int s = idx >> 10, r = (idx >> 6) & 15, u = 64 * ((j + 1 + s) & 3) + (idx & 63);
-                const unsigned long long* gp = slot + r * 256 + u;
-                unsigned long long x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while ((unsigned)(x >> 32) != epoch) {
-                    __builtin_amdgcn_s_sleep(1);
-                    x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (++spins > (1u << 22)) { *a.err = 1; break; }
-                }
-                Hs[nxt][r][u] = __uint_as_float((unsigned)x);
+                Hs[nxt][r][u] = __uint_as_float((unsigned)xv[k]);
             }
         }
         __syncthreads();
@@ -553,8 +568,8 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
             for (int i = 0; i < 4; ++i) {
                 float r = sigmoid_f(ar[i]);
                 float z = sigmoid_f(az[i]);
-                float nn = tanh_f(axn[i] + r * ahn[i]);
-                float h = (1.0f - z) * nn + z * h_own[i];
+                float nn = gru_candidate(r, ahn[i], axn[i]);
+                float h = gru_blend(z, nn, h_own[i]);
                 h_own[i] = h;
                 Hs[hb][q * 4 + i][16 * w + cl] = h;
             }
