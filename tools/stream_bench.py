@@ -29,6 +29,11 @@ def run(sr, nb, S, hops_per_call, calls, warm=20, overlap=None, fuse=None):
     st.close(); m.close()
 
 if __name__ == "__main__":
+    if "--scale" in sys.argv:
+        for S in (64, 256, 1024, 4096):
+            run(48000, 8, S, 1, 60, warm=10)
+            run(16000, 4, S, 1, 60, warm=10)
+        sys.exit(0)
     if "--one" in sys.argv:
         run(48000, 8, 64, 1, 200, warm=20); sys.exit(0)
     for hops in (1, 4, 16):
