@@ -5,7 +5,6 @@ The STFT / iSTFT / attenuation-limit of the OFFLINE path run on the GPU inside
 from __future__ import annotations
 
 from dataclasses import dataclass
-from fractions import Fraction
 from typing import Optional
 
 import numpy as np
@@ -23,18 +22,22 @@ def to_mono(audio: np.ndarray) -> np.ndarray:
     return np.mean(x, axis=1, dtype=np.float32)
 
 
-def ensure_sample_rate(audio: np.ndarray, sample_rate: int, target_sample_rate: int) -> np.ndarray:
-    """Identity when the rates match (the on-path case, reference audio.py:20-22).  Otherwise a
-    polyphase (Kaiser-windowed sinc) resampler -- the reference delegates to librosa/soxr_hq,
-    whose source is not in the repository: parity for mismatched rates is UNPINNED."""
+def ensure_sample_rate(audio: np.ndarray, sample_rate: int, target_sample_rate: int, device: Optional[int] = None) -> np.ndarray:
+    """Identity when the rates match (the on-path case, reference audio.py:20-22).  Otherwise the
+    device polyphase resampler `dpdf_resample` (Kaiser-windowed sinc, the scheme of
+    scipy.signal.resample_poly) -- the reference delegates to librosa/soxr_hq, whose source is not
+    in the repository: parity for mismatched rates is UNPINNED.  No host fallback:
+    without the HIP extension / a GPU this raises like every other engine call."""
     x = np.asarray(audio, dtype=np.float32)
     if int(sample_rate) == int(target_sample_rate):
         return x
-    from scipy.signal import resample_poly
-    frac = Fraction(int(target_sample_rate), int(sample_rate))
     if x.size == 0:
         return x
-    return resample_poly(x.astype(np.float64), frac.numerator, frac.denominator).astype(np.float32)
+    from . import backend
+    if device is None:
+        import os
+        device = int(os.environ.get("DPDFNET_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    return backend.resample(x, int(sample_rate), int(target_sample_rate), device)
 
 
 def fit_length(audio: np.ndarray, target_len: int) -> np.ndarray:

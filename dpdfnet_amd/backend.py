@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = (
     "dpdf_streams_destroy", "dpdf_streams_reset", "dpdf_streams_prime", "dpdf_streams_process",
     "dpdf_streams_get_state", "dpdf_sync", "dpdf_profile_enable", "dpdf_profile_report",
     "dpdf_set_chunk_frames", "dpdf_set_overlap", "dpdf_set_fuse_dprnn", "dpdf_debug_fetch",
+    "dpdf_resample_len", "dpdf_resample",
 )
 
 
@@ -106,6 +107,9 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_set_fuse_dprnn.argtypes = [vp, ctypes.c_int]
         L.dpdf_debug_fetch.restype = ctypes.c_long
         L.dpdf_debug_fetch.argtypes = [vp, ctypes.c_char_p, fp, ctypes.c_long]
+        L.dpdf_resample_len.restype = ctypes.c_long
+        L.dpdf_resample_len.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
+        L.dpdf_resample.argtypes = [ctypes.c_int, vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
         _lib = L
         return L
 
@@ -144,6 +148,24 @@ def query_dims(sample_rate: int, nb: int) -> DpdfDims:
 
 def device_count() -> int:
     return int(load_library().dpdf_device_count())
+
+
+def resample(x: np.ndarray, sr_in: int, sr_out: int, device: int = 0) -> np.ndarray:
+    """Device polyphase resampler (`dpdf_resample`): [n] or [B, n] float32 at sr_in -> same rank at sr_out."""
+    L = load_library()
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    one = a.ndim == 1
+    a2 = a[None, :] if one else a
+    if a2.ndim != 2:
+        raise ValueError(f"Expected [n] or [B, n] audio, got shape {a.shape}")
+    B, n = a2.shape
+    n_out = int(L.dpdf_resample_len(n, int(sr_in), int(sr_out)))
+    if n_out < 0:
+        raise ValueError(f"bad resample arguments n={n} {sr_in}->{sr_out}")
+    out = np.empty((B, n_out), dtype=np.float32)
+    if B and n:
+        _check(L.dpdf_resample(int(device), a2.ctypes.data, B, n, int(sr_in), int(sr_out), out.ctypes.data, DPDF_HOST_PTRS))
+    return out[0] if one else out
 
 
 class HipModel:

@@ -25,6 +25,7 @@
 #include "gemm_rows.h"
 #include "gru_scan.h"
 #include "misc_kernels.h"
+#include "resample.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -48,6 +49,59 @@ extern "C" int dpdf_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+// ------------------------------------------------------------------------------------------------
+// N3: device resampler (model-independent; one tap table per (device, up, down), one stream per device)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ResampleDev { hipStream_t stream = nullptr; std::map<std::pair<int, int>, std::pair<float*, ResampleDesign>> taps;
+                     float* in = nullptr; float* out = nullptr; size_t in_cap = 0, out_cap = 0; };
+std::mutex g_rs_mu;
+std::map<int, ResampleDev> g_rs;
+}
+extern "C" long dpdf_resample_len(long n_in, int sr_in, int sr_out) {
+    if (n_in < 0 || sr_in <= 0 || sr_out <= 0) return -1;
+    long g = resample_gcd(sr_in, sr_out);
+    return resample_out_len(n_in, (int)(sr_out / g), (int)(sr_in / g));
+}
+extern "C" int dpdf_resample(int device, const float* in, int B, long n_in, int sr_in, int sr_out, float* out, int flags) {
+    if (!in || !out) return set_err(DPDF_E_INVALID, "null argument");
+    if (B <= 0 || n_in < 0 || sr_in <= 0 || sr_out <= 0) return set_err(DPDF_E_INVALID, "bad resample geometry B=%d n=%ld %d->%d", B, n_in, sr_in, sr_out);
+    if (n_in == 0) return DPDF_OK;
+    std::lock_guard<std::mutex> lk(g_rs_mu);
+    HIP_TRY(hipSetDevice(device));
+    ResampleDev& R = g_rs[device];
+    if (!R.stream) HIP_TRY(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+    long g = resample_gcd(sr_in, sr_out);
+    const std::pair<int, int> key((int)(sr_out / g), (int)(sr_in / g));
+    auto it = R.taps.find(key);
+    if (it == R.taps.end()) {
+        ResampleDesign d = design_resampler(sr_in, sr_out);
+        std::vector<float> hf(d.hp.begin(), d.hp.end());
+        float* dp = nullptr;
+        HIP_TRY(hipMalloc((void**)&dp, hf.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(dp, hf.data(), hf.size() * sizeof(float), hipMemcpyHostToDevice));
+        it = R.taps.emplace(key, std::make_pair(dp, std::move(d))).first;
+    }
+    const ResampleDesign& d = it->second.second;
+    const long n_out = resample_out_len(n_in, d.up, d.down);
+    const bool host = !(flags & DPDF_DEVICE_PTRS);
+    const float* d_in = in; float* d_out = out;
+    if (host) {
+        const size_t ni = (size_t)B * n_in, no = (size_t)B * n_out;
+        if (ni > R.in_cap) { if (R.in) (void)hipFree(R.in); R.in = nullptr; R.in_cap = 0; HIP_TRY(hipMalloc((void**)&R.in, ni * sizeof(float))); R.in_cap = ni; }
+        if (no > R.out_cap) { if (R.out) (void)hipFree(R.out); R.out = nullptr; R.out_cap = 0; HIP_TRY(hipMalloc((void**)&R.out, no * sizeof(float))); R.out_cap = no; }
+        HIP_TRY(hipMemcpyAsync(R.in, in, ni * sizeof(float), hipMemcpyHostToDevice, R.stream));
+        d_in = R.in; d_out = R.out;
+    }
+    ResampleArgs a{d_in, d_out, it->second.first, n_in, n_out, d.pre, d.up, d.down, (int)d.hp.size()};
+    hipLaunchKernelGGL(resample_poly_kernel, dim3((unsigned)((n_out + 255) / 256), (unsigned)B), dim3(256), 0, R.stream, a);
+    HIP_TRY(hipGetLastError());
+    if (host) HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)B * n_out * sizeof(float), hipMemcpyDeviceToHost, R.stream));
+    HIP_TRY(hipStreamSynchronize(R.stream));
+    return DPDF_OK;
+}
+
 extern "C" size_t dpdf_weight_count(const dpdf_cfg* cfg) { return dpdf_manifest(cfg, nullptr, nullptr); }
 extern "C" int dpdf_query_dims(const dpdf_cfg* cfg, dpdf_dims* out) {
     if (!out || dpdf_get_dims(cfg, out) != 0) return set_err(DPDF_E_INVALID, "unsupported model config");

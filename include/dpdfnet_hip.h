@@ -106,6 +106,14 @@ int dpdf_set_overlap(dpdf_model* m, int on);
  * chip (>= 3072 frame rows), separate below that (single-hop streaming, small batches). */
 int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
 
+/* Rational polyphase resampler on the device, for `ensure_sample_rate` when the caller's rate differs from the
+ * model's (reference package/src/dpdfnet/audio.py:20-27 -> librosa.resample(res_type="soxr_hq"); stream.py:112,
+ * 163-165 per chunk).  Kaiser(5.0)-windowed-sinc polyphase filter of scipy.signal.resample_poly; parity with soxr
+ * is unpinned (its source is not part of the reference).  in [B][n_in] -> out [B][dpdf_resample_len(n_in, ...)].
+ * Model-independent; synchronous (returns after the result is complete, also for device pointers). */
+long dpdf_resample_len(long n_in, int sr_in, int sr_out);      /* ceil(n_in * sr_out / sr_in); -1 on bad arguments */
+int dpdf_resample(int device, const float* in, int B, long n_in, int sr_in, int sr_out, float* out, int flags);
+
 /* Debug/test hook: copy an intermediate tensor of the last processed chunk to the host
  * ("e0","e1","e2","e3","e3_dprnn","c0","c1","c1_dprnn","emb","m","coefs","xm","feat_erb",
  * "feat_spec"; engine-native channels-last layouts).  Returns the element count, -1 if unknown. */

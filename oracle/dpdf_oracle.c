@@ -859,3 +859,50 @@ size_t dpdf_oracle_manifest_text(const dpdf_cfg* cfg, char* buf, size_t cap) {
     if (buf && t.len < cap) buf[t.len] = 0;
     return t.len;
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * ensure_sample_rate for mismatched rates (package/src/dpdfnet/audio.py:20-27): see the header for why this
+ * follows scipy.signal.resample_poly rather than soxr.  Steps of resample_poly restated:
+ *   up, down reduced by gcd;  n_out = ceil(n_in*up/down);  half_len = 10*max(up,down)
+ *   h = firwin(2*half_len+1, 1/max(up,down), window=('kaiser',5.0)) * up     (unit DC gain before *up)
+ *   n_pre_pad = down - half_len % down;  n_pre_remove = (half_len + n_pre_pad) / down
+ *   y = upfirdn([0]*n_pre_pad + h, x, up, down)[n_pre_remove : n_pre_remove + n_out]
+ * and upfirdn is y[m] = sum_i x[i] * hp[m*down - i*up].
+ * ------------------------------------------------------------------------------------------- */
+static double oracle_i0(double x) {
+    double sum = 1.0, term = 1.0, q = x * x / 4.0;
+    for (int k = 1; k < 500; ++k) { term *= q / ((double)k * k); sum += term; if (term < 1e-18 * sum) break; }
+    return sum;
+}
+long dpdf_oracle_resample(const float* x, long n_in, int sr_in, int sr_out, float* out, long cap) {
+    long a = sr_in, b = sr_out;
+    while (b) { long t = a % b; a = b; b = t; }
+    const long up = sr_out / a, down = sr_in / a;
+    const long n_out = (n_in * up) / down + ((n_in * up) % down ? 1 : 0);
+    if (n_in <= 0) return 0;
+    const long max_rate = up > down ? up : down, half_len = 10 * max_rate, M = 2 * half_len + 1;
+    const double fc = 1.0 / (double)max_rate, beta = 5.0, pi = 3.14159265358979323846;
+    const long n_pre_pad = down - half_len % down, n_pre_remove = (half_len + n_pre_pad) / down;
+    const long lh = n_pre_pad + M;
+    double* hp = (double*)calloc((size_t)lh, sizeof(double));
+    double sum = 0.0;
+    for (long n = 0; n < M; ++n) {
+        const double m = (double)n - (double)half_len, xa = fc * m, r = m / (double)half_len;
+        const double sinc = xa == 0.0 ? 1.0 : sin(pi * xa) / (pi * xa);
+        double rad = 1.0 - r * r; if (rad < 0.0) rad = 0.0;
+        hp[n_pre_pad + n] = fc * sinc * oracle_i0(beta * sqrt(rad)) / oracle_i0(beta);
+        sum += hp[n_pre_pad + n];
+    }
+    for (long n = 0; n < M; ++n) hp[n_pre_pad + n] = hp[n_pre_pad + n] / sum * (double)up;
+    for (long n = 0; n < n_out && n < cap; ++n) {
+        const long t = (n + n_pre_remove) * down;
+        long i_hi = t / up; if (i_hi > n_in - 1) i_hi = n_in - 1;
+        long i_lo = t - lh + 1 <= 0 ? 0 : (t - lh + 1 + up - 1) / up;
+        double acc = 0.0;
+        for (long i = i_lo; i <= i_hi; ++i) acc += (double)x[i] * hp[t - i * up];
+        out[n] = (float)acc;
+    }
+    free(hp);
+    return n_out;
+}

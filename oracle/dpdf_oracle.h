@@ -57,6 +57,14 @@ void dpdf_oracle_attn_limit(const float* spec_noisy, float* spec_e, int T, int F
 /* whole `enhance()` (package/src/dpdfnet/api.py:51-113) for one mono clip at the model rate. */
 void dpdf_oracle_enhance(dpdf_oracle* o, const float* wav, int n, float attn_limit_db, float* out);
 
+/* Sample-rate conversion for ensure_sample_rate (package/src/dpdfnet/audio.py:20-27).  The reference calls
+ * librosa.resample(res_type="soxr_hq"), a third-party dependency (librosa==0.11.0, soxr unpinned) that is absent from
+ * /root/reference and from this image: PARITY UNPINNED against it.  Restated here is the published algorithm of
+ * scipy.signal.resample_poly (Kaiser beta=5 windowed sinc, 20*max(up,down)+1 taps, centred), float64 taps and
+ * accumulation; tests/test_resample.py pins it against scipy itself.  Returns the output length
+ * ceil(n_in*sr_out/sr_in); writes min(len, cap) samples. */
+long dpdf_oracle_resample(const float* x, long n_in, int sr_in, int sr_out, float* out, long cap);
+
 /* ERB band widths (model/utils.py:265-324) for goldens; returns number of bands. */
 int dpdf_oracle_erb_widths(const dpdf_oracle* o, int* widths, int cap);
 void dpdf_oracle_window(const dpdf_oracle* o, float* w);

@@ -62,6 +62,8 @@ def lib() -> ctypes.CDLL:
         L.dpdf_oracle_stft.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, fp]
         L.dpdf_oracle_istft.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, fp, ctypes.c_int]
         L.dpdf_oracle_attn_limit.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+        L.dpdf_oracle_resample.argtypes = [fp, ctypes.c_long, ctypes.c_int, ctypes.c_int, fp, ctypes.c_long]
+        L.dpdf_oracle_resample.restype = ctypes.c_long
         L.dpdf_oracle_enhance.argtypes = [ctypes.c_void_p, fp, ctypes.c_int, ctypes.c_float, fp]
         L.dpdf_oracle_erb_widths.restype = ctypes.c_int
         L.dpdf_oracle_erb_widths.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
@@ -158,6 +160,18 @@ class Oracle:
         enh = np.array(enh, dtype=np.float32)
         lib().dpdf_oracle_attn_limit(_fp(noisy), _fp(enh), enh.shape[0], enh.shape[1], float(db))
         return enh
+
+    @staticmethod
+    def resample(x: np.ndarray, sr_in: int, sr_out: int) -> np.ndarray:
+        """ensure_sample_rate for mismatched rates (resample_poly restatement; see dpdf_oracle.h)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if int(sr_in) == int(sr_out) or x.size == 0:
+            return x
+        n_out = -(-x.size * int(sr_out) // int(sr_in))
+        out = np.empty(n_out, dtype=np.float32)
+        got = lib().dpdf_oracle_resample(_fp(x), x.size, int(sr_in), int(sr_out), _fp(out), n_out)
+        assert got == n_out, (got, n_out)
+        return out
 
     def enhance(self, wav: np.ndarray, attn_limit_db: Optional[float] = None) -> np.ndarray:
         wav = np.ascontiguousarray(wav, dtype=np.float32)

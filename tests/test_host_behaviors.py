@@ -199,7 +199,24 @@ def test_vorbis_window_cola_and_stft_config():
     x = np.arange(10, dtype=np.float32)
     assert audio.ensure_sample_rate(x, 16000, 16000) is not None
     np.testing.assert_array_equal(audio.ensure_sample_rate(x, 16000, 16000), x)
-    assert abs(len(audio.ensure_sample_rate(np.zeros(4800, np.float32), 48000, 16000)) - 1600) <= 1
+
+
+def test_ensure_sample_rate_routes_mismatched_rates_to_the_device_resampler(monkeypatch):
+    """Identity when rates match (reference audio.py:20-22); otherwise the engine's `dpdf_resample` -- no host DSP."""
+    from dpdfnet_amd import audio, backend
+    from oracle.oracle import Oracle
+    calls = []
+
+    def fake(x, sr_in, sr_out, device=0):
+        calls.append((len(x), sr_in, sr_out, device))
+        return Oracle.resample(x, sr_in, sr_out)
+
+    monkeypatch.setattr(backend, "resample", fake)
+    x = np.linspace(-0.5, 0.5, 4800, dtype=np.float32)
+    assert audio.ensure_sample_rate(x, 16000, 16000) is not None and not calls
+    y = audio.ensure_sample_rate(x, 48000, 16000, device=3)
+    assert calls == [(4800, 48000, 16000, 3)] and y.shape == (1600,) and y.dtype == np.float32
+    assert audio.ensure_sample_rate(np.zeros(0, np.float32), 48000, 16000).size == 0 and len(calls) == 1
 
 
 def test_model_registry_and_resolution(tmp_path, monkeypatch):
