@@ -10,18 +10,19 @@ __all__ = [
     "enhance",
     "enhance_batch",
     "enhance_file",
+    "enhance_dir",
     "available_models",
     "download",
     "StreamEnhancer",
 ]
 
 if TYPE_CHECKING:  # pragma: no cover
-    from .api import available_models, download, enhance, enhance_batch, enhance_file
+    from .api import available_models, download, enhance, enhance_batch, enhance_dir, enhance_file
     from .stream import StreamEnhancer
 
 
 def __getattr__(name: str):
-    if name in {"enhance", "enhance_batch", "enhance_file", "available_models", "download"}:
+    if name in {"enhance", "enhance_batch", "enhance_file", "enhance_dir", "available_models", "download"}:
         from . import api
 
         return getattr(api, name)

@@ -183,3 +183,89 @@ def enhance_file(
     out_path = in_path.with_name(f"{in_path.stem}_enhanced.wav") if output_path is None else Path(output_path).expanduser().resolve()
     _write_pcm16(out_path, enhanced, int(sr))
     return out_path
+
+
+# directory batch (reference cli.py:222-311 `_run_enhance_dir`): the reference fans files out over a CPU thread pool,
+# one ORT session per thread; here the files are read, grouped by (input rate, length) and each group goes through
+# the GPU as ONE batched call.  Same discovery rules, output naming and error aggregation.
+SUPPORTED_EXTENSIONS = frozenset({".wav"})            # stdlib reader; soundfile (optional) widens this at run time
+MAX_BATCH_SAMPLES = 64 * 1024 * 1024                   # per engine call (model-rate samples); keeps spectra < 1 GB
+
+
+def _supported_extensions() -> frozenset:
+    try:
+        import soundfile as sf  # type: ignore
+        return frozenset("." + k.lower() for k in sf.available_formats()) | SUPPORTED_EXTENSIONS
+    except ImportError:
+        return SUPPORTED_EXTENSIONS
+
+
+def enhance_dir(
+    input_dir: Union[str, Path],
+    output_dir: Union[str, Path],
+    *,
+    model: str = DEFAULT_MODEL,
+    onnx_path: Optional[Union[str, Path]] = None,
+    attn_limit_db: Optional[float] = None,
+    verbose: bool = False,
+    file_callback: Optional[Callable[[Path, Path], None]] = None,
+) -> List[Path]:
+    """Enhance every supported audio file of `input_dir` into `output_dir/<stem>_enhanced.wav`.
+    Returns the written paths in the sorted order of the inputs."""
+    from .audio import ensure_sample_rate, fit_length, to_mono, validate_attn_limit_db
+
+    in_dir, out_dir = Path(input_dir).expanduser().resolve(), Path(output_dir).expanduser().resolve()
+    if not in_dir.is_dir():
+        raise FileNotFoundError(f"Input directory not found: {in_dir}")
+    exts = _supported_extensions()
+    files = sorted(p for p in in_dir.iterdir() if p.is_file() and p.suffix.lower() in exts)
+    if not files:
+        raise FileNotFoundError(f"No supported audio files found in {in_dir}\nSupported extensions: {', '.join(sorted(exts))}")
+    attn = validate_attn_limit_db(attn_limit_db)
+    resolved = resolve_model(model=model, onnx_path=onnx_path, auto_download=True, verbose=verbose)
+    runtime = build_runtime_model(resolved.onnx_path, resolved.info, _device_from_env())
+    msr = resolved.info.sample_rate
+    out_dir.mkdir(parents=True, exist_ok=True)
+
+    errors: List = []
+    clips: Dict[Path, tuple] = {}
+    groups: Dict[tuple, List[Path]] = {}
+    for p in files:
+        try:
+            audio, sr = _read_audio(p)
+            mono = to_mono(audio)
+            clips[p] = (mono, int(sr))
+            groups.setdefault((int(sr), int(mono.shape[0])), []).append(p)
+        except Exception as exc:  # one bad file must not stop the directory (cli.py:296-305)
+            errors.append((p, exc))
+
+    written: Dict[Path, Path] = {}
+
+    def _emit(p: Path, enhanced_model_sr: np.ndarray) -> None:
+        mono, sr = clips[p]
+        y = fit_length(ensure_sample_rate(enhanced_model_sr, msr, sr), mono.shape[0])
+        dst = out_dir / f"{p.stem}_enhanced.wav"
+        _write_pcm16(dst, y, sr)
+        written[p] = dst
+        if file_callback is not None:
+            file_callback(p, dst)
+
+    for (sr, n), paths in groups.items():
+        try:
+            if n == 0:
+                for p in paths:
+                    _emit(p, clips[p][0].copy())
+                continue
+            batch = np.stack([clips[p][0] for p in paths])
+            batch = batch if sr == msr else ensure_sample_rate(batch, sr, msr)      # [B, n] in one device call
+            per_call = max(1, MAX_BATCH_SAMPLES // max(1, batch.shape[1]))
+            for lo in range(0, len(paths), per_call):
+                res = runtime.session.enhance_batch(batch[lo: lo + per_call], attn)
+                for j, p in enumerate(paths[lo: lo + per_call]):
+                    _emit(p, res[j])
+        except Exception as exc:
+            errors.extend((p, exc) for p in paths if p not in written)
+    if errors:
+        msgs = "\n".join(f"  {p}: {e}" for p, e in errors)
+        raise RuntimeError(f"Errors during processing:\n{msgs}")
+    return [written[p] for p in files]

@@ -26,7 +26,7 @@ def _patch(monkeypatch, win=320, sr=16000, zero=False):
 
 def test_import_surface():
     import dpdfnet_amd
-    for name in ("enhance", "enhance_file", "StreamEnhancer", "available_models", "download", "enhance_batch"):
+    for name in ("enhance", "enhance_file", "enhance_dir", "StreamEnhancer", "available_models", "download", "enhance_batch"):
         assert hasattr(dpdfnet_amd, name)
     with pytest.raises(AttributeError):
         dpdfnet_amd.nope
@@ -252,6 +252,40 @@ def test_enhance_file_wav_roundtrip(tmp_path, monkeypatch):
     assert sr == 16000 and y.shape == x.shape
     with pytest.raises(FileNotFoundError):
         api.enhance_file(tmp_path / "missing.wav")
+
+
+def test_enhance_dir_batches_files_by_rate_and_length(tmp_path, monkeypatch):
+    """Directory mode (reference cli.py:222-311): sorted discovery, `<stem>_enhanced.wav`, one engine call per
+    (rate, length) group instead of one thread per file, per-file errors aggregated into one RuntimeError."""
+    from dpdfnet_amd import api
+    sess = _patch(monkeypatch)
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    rng = np.random.default_rng(3)
+    lens = {"a": 3200, "b": 1600, "c": 3200, "d": 0}
+    for k, n in lens.items():
+        api._write_pcm16(src / f"{k}.wav", (0.1 * rng.standard_normal(n)).astype(np.float32), 16000)
+    (src / "notes.txt").write_text("skip me")
+    seen = []
+    outs = api.enhance_dir(src, dst, file_callback=lambda i, o: seen.append(i.name))
+    assert [o.name for o in outs] == ["a_enhanced.wav", "b_enhanced.wav", "c_enhanced.wav", "d_enhanced.wav"]
+    assert sorted(seen) == ["a.wav", "b.wav", "c.wav", "d.wav"]
+    assert sorted(shape for shape, _ in sess.calls) == [(1, 1600), (2, 3200)]       # a+c share one call
+    for k, n in lens.items():
+        y, sr = api._read_audio(dst / f"{k}_enhanced.wav")
+        assert sr == 16000 and y.shape == (n,)
+    single = api.enhance_file(src / "a.wav", tmp_path / "single.wav")
+    np.testing.assert_array_equal(api._read_audio(single)[0], api._read_audio(dst / "a_enhanced.wav")[0])
+    with pytest.raises(FileNotFoundError, match="Input directory not found"):
+        api.enhance_dir(tmp_path / "nope", dst)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    with pytest.raises(FileNotFoundError, match="No supported audio files"):
+        api.enhance_dir(empty, dst)
+    (src / "broken.wav").write_bytes(b"not a wav file")
+    with pytest.raises(RuntimeError, match="Errors during processing:\\n.*broken.wav"):
+        api.enhance_dir(src, tmp_path / "out2")
+    assert (tmp_path / "out2" / "a_enhanced.wav").is_file()                         # the good files were still written
 
 
 def test_evalkit_si_snr_and_alignment():
