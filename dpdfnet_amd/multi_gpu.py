@@ -37,15 +37,18 @@ def gather_to_root(local, world_size: int, rank: int, out=None):
 
     if world_size == 1:
         return local.unsqueeze(0)
+    # one grouped launch (ncclGroupStart/End under batch_isend_irecv): the root's world-1 receives progress
+    # concurrently instead of one peer after the other
     if rank == 0:
         if out is None:
             out = torch.empty((world_size,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         out[0].copy_(local)
-        reqs = [dist.irecv(out[r], src=r) for r in range(1, world_size)]
-        for q in reqs:
+        ops = [dist.P2POp(dist.irecv, out[r], r) for r in range(1, world_size)]
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
         return out
-    dist.send(local.contiguous(), dst=0)
+    for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), 0)]):
+        q.wait()
     return None
 
 
