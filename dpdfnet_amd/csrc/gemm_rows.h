@@ -487,7 +487,12 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(AProd ap, const float* _
 #pragma unroll
         for (int i = 0; i < PB; ++i) breg[i] = wf[(size_t)i * 64];
     }
+    // XCD-aware tile order: the hardware deals consecutive workgroups round-robin onto the 8 XCDs (block b -> XCD
+    // b % 8), each with a private L2.  Row tiles that are neighbours in (clip, frame, band) order share input rows
+    // through the time/frequency halos of the conv producers (up to 5x for the DF pathway conv), so each sweep of
+    // gridDim.x tiles is cut into 8 contiguous slabs, one per XCD, instead of being interleaved across all of them.
     int tile = blockIdx.x, panel = 0, cur = 0;
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (tile >= ntiles) return;
     typename AProd::Regs R;
     ap.load(R, tile * GEMM_BM, 0, grp, M);
