@@ -28,6 +28,16 @@ __device__ __forceinline__ float tanh_f(float x) {
 __device__ __forceinline__ float gru_candidate(float r, float hn, float xn) { return tanh_f(__builtin_fmaf(r, hn, xn)); }
 __device__ __forceinline__ float gru_blend(float z, float n, float h) { return __builtin_fmaf(z, h - n, n); }
 
+// GRU(64) cell tail on PRE-SCALED pre-activations (build_gru64 folds -log2 e into the r/z rows and -2 log2 e into the
+// candidate rows of W_ih, W_hh and the biases): r, z = 1/(1 + 2^a); n = tanh(.) = 2/(1 + 2^t) - 1 with t = xn + r hn;
+// h' = n + z (h - n).  6 transcendentals + 7 plain VALU per hidden unit; exp2 -> inf / 0 saturates to -1 / +1 cleanly.
+__device__ __forceinline__ float sigmoid_pre(float a) { return fast_rcp(1.0f + __builtin_amdgcn_exp2f(a)); }
+__device__ __forceinline__ float gru64_cell(float ar, float az, float axn, float ahn, float h) {
+    const float r = sigmoid_pre(ar), z = sigmoid_pre(az);
+    const float n = __builtin_fmaf(2.0f, sigmoid_pre(__builtin_fmaf(r, ahn, axn)), -1.0f);
+    return __builtin_fmaf(z, h - n, n);
+}
+
 // K index supplied by lane-quad q (= lane>>4) for MFMA kb (0..3) of 16-wide K chunk c.
 // All A fragments (4 contiguous floats per lane per chunk) and all packed B fragments use it.
 __host__ __device__ inline int kperm(int c, int q, int kb) { return 16 * c + 4 * q + kb; }

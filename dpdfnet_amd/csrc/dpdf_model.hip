@@ -346,6 +346,11 @@ PathW build_path(Arena& A, const Blob& B, const std::string& p) {
 // [dir][wave][part][gate][chunk*4+kb][lane] + bias [dir][4][64]
 GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::string, std::string>>& dirs) {
     GruW64 g; g.ndirs = (int)dirs.size();
+    // The exponent scales of the gate non-linearities are folded into the packed weights, so that the accumulators
+    // come out of the MFMAs ready for v_exp_f32 (2^x): sigma(a) = 1/(1 + 2^(-a log2 e)) for r and z, and
+    // tanh(t) = 2/(1 + 2^(-2 t log2 e)) - 1 for the candidate (common.h gru64_cell).  VALU instructions and fp32 MFMAs
+    // share the SIMD datapath, so the four multiplies per hidden unit this removes are MFMA time.
+    const float gate_scale[3] = {-1.4426950408889634f, -1.4426950408889634f, -2.8853900817779268f};
     std::vector<float> frag((size_t)g.ndirs * 4 * 2 * 3 * 16 * 64), bias((size_t)g.ndirs * 256);
     for (int d = 0; d < g.ndirs; ++d) {
         const std::string &p = dirs[d].first, &sfx = dirs[d].second;
@@ -360,13 +365,13 @@ GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::str
                                 int k = kperm(c, lane >> 4, kb);
                                 int j = gate * 64 + 16 * w + (lane & 15);
                                 const float* W = part == 0 ? wih : whh;
-                                frag[(((((size_t)(d * 4 + w) * 2 + part) * 3 + gate) * 16) + c * 4 + kb) * 64 + lane] = W[j * 64 + k];
+                                frag[(((((size_t)(d * 4 + w) * 2 + part) * 3 + gate) * 16) + c * 4 + kb) * 64 + lane] = W[j * 64 + k] * gate_scale[gate];
                             }
         for (int j = 0; j < 64; ++j) {
-            bias[d * 256 + j] = bih[j] + bhh[j];
-            bias[d * 256 + 64 + j] = bih[64 + j] + bhh[64 + j];
-            bias[d * 256 + 128 + j] = bih[128 + j];
-            bias[d * 256 + 192 + j] = bhh[128 + j];
+            bias[d * 256 + j] = (bih[j] + bhh[j]) * gate_scale[0];
+            bias[d * 256 + 64 + j] = (bih[64 + j] + bhh[64 + j]) * gate_scale[1];
+            bias[d * 256 + 128 + j] = bih[128 + j] * gate_scale[2];
+            bias[d * 256 + 192 + j] = bhh[128 + j] * gate_scale[2];
         }
     }
     g.wfrag = A.add(frag); g.bias = A.add(bias);

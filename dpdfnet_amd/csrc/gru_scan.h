@@ -148,10 +148,7 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
 #if GRU64_VARIANT & 1
             float h = 0.01f * (ar[i] + az[i] + axn[i] + ahn[i]) + 0.5f * h_own[i];
 #else
-            float r = sigmoid_f(ar[i]);
-            float z = sigmoid_f(az[i]);
-            float n = gru_candidate(r, ahn[i], axn[i]);
-            float h = gru_blend(z, n, h_own[i]);
+            float h = gru64_cell(ar[i], az[i], axn[i], ahn[i], h_own[i]);
 #endif
             h_own[i] = h;
             Hs[buf][q * 4 + i][16 * w + cl] = h;
@@ -431,7 +428,7 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
     __shared__ __attribute__((aligned(16))) float Hs[2][16][68];
     __shared__ __attribute__((aligned(16))) float Xs[4][16][68];      // ring: x(s-2) must outlive x(s+1)'s staging
     __shared__ __attribute__((aligned(16))) float Ys[2][16][68];
-    __shared__ __attribute__((aligned(16))) float Es[EPI == 2 ? 3 : 1][EPI == 2 ? 16 : 1][EPI == 2 ? 68 : 4];   // hf ring (3 slots)
+    __shared__ __attribute__((aligned(16))) float Es[EPI == 2 ? 4 : 1][EPI == 2 ? 16 : 1][EPI == 2 ? 68 : 4];   // hf ring (3 live slots; 4 so that every ring index is s & const)
     constexpr bool WF_LDS = EPI == 1 && EPI1_WF_LDS;
     __shared__ float Wf[WF_LDS ? 4 : 1][16][64];                      // EPI 1: fc B fragments in LDS (keeps 3 WG/CU)
     __shared__ __attribute__((aligned(16))) float Lp[3][64];          // fc bias | ln gamma | ln beta
@@ -469,12 +466,14 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
     const float* ebase = EPI == 2 ? ea.extra + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo : nullptr;
     float* ybase = ea.y + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
     const int srow = 4 * w + q, scol = 4 * cl;
-    int sx_off; bool so_ok;
+    // non-negative 32-bit lane offset: every global address is (wave-uniform base advanced on the scalar unit) + sx_off,
+    // so the step costs no 64-bit VALU address arithmetic -- VALU cycles come straight out of the MFMA budget
+    unsigned sx_off; bool so_ok;
     {
         int rs = row0 + srow;
         so_ok = rs < a.nrows;
         if (rs >= a.nrows) rs = a.nrows - 1;
-        sx_off = (int)((long)(rs / a.rdiv - hi0) * a.x_hi + (long)(rs % a.rdiv - lo0) * a.x_lo) + scol;
+        sx_off = (unsigned)((long)(rs / a.rdiv - hi0) * a.x_hi + (long)(rs % a.rdiv - lo0) * a.x_lo) + scol;
     }
     float h_own[4];
 #pragma unroll
@@ -486,14 +485,15 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
         Hs[1][q * 4 + i][16 * w + cl] = hv;
     }
     const int n = a.nsteps;
-    auto pos_of = [&](int s) { return dir ? n - 1 - s : s; };
+    auto pos_of = [&](int s) { s = s < n ? s : n - 1; return dir ? n - 1 - s : s; };    // clamped: the tail re-reads the last tile instead of branching
     {
-        *(float4*)&Xs[0][srow][scol] = *(const float4*)(xbase + sx_off + (long)pos_of(0) * a.x_step);
-        if (EPI == 2) *(float4*)&Es[0][srow][scol] = *(const float4*)(ebase + sx_off + (long)pos_of(0) * a.x_step);   // Es(s) lives in slot s % 3
+        *(float4*)&Xs[0][srow][scol] = *(const float4*)((xbase + (long)pos_of(0) * a.x_step) + sx_off);
+        if (EPI == 2) *(float4*)&Es[0][srow][scol] = *(const float4*)((ebase + (long)pos_of(0) * a.x_step) + sx_off);   // Es(s) lives in slot s & 3
     }
     __syncthreads();
 
-    for (int s = 0; s < n + 2; ++s) {
+#pragma unroll 4
+    for (int s = 0; s < n + 2; ++s) {         // unrolled by the ring period: every LDS slot offset becomes an immediate
         const int hb = s & 1;                 // Hs/Ys/Es slot written this step
         // ---- finalize step s-2: LayerNorm + residual on the row-contiguous pieces, one store per lane
         auto finalize = [&]() __attribute__((always_inline)) {
@@ -508,16 +508,14 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
                 float4 o;
                 o.x = rv.x + d0 * inv * gg.x + bb.x; o.y = rv.y + d1 * inv * gg.y + bb.y;
                 o.z = rv.z + d2 * inv * gg.z + bb.z; o.w = rv.w + d3 * inv * gg.w + bb.w;
-                if (so_ok) *(float4*)(ybase + sx_off + (long)pos_of(s - 2) * a.x_step) = o;
+                if (so_ok) *(float4*)((ybase + (long)pos_of(s - 2) * a.x_step) + sx_off) = o;
             }
         };
         if (EPI == 1) finalize();
         // ---- loads for step s+1
-        float4 xnext = make_float4(0.f, 0.f, 0.f, 0.f), enext = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s + 1 < n) {
-            xnext = *(const float4*)(xbase + sx_off + (long)pos_of(s + 1) * a.x_step);
-            if (EPI == 2) enext = *(const float4*)(ebase + sx_off + (long)pos_of(s + 1) * a.x_step);
-        }
+        const float4 xnext = *(const float4*)((xbase + (long)pos_of(s + 1) * a.x_step) + sx_off);
+        float4 enext = xnext;
+        if (EPI == 2) enext = *(const float4*)((ebase + (long)pos_of(s + 1) * a.x_step) + sx_off);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 ar = {b_r, b_r, b_r, b_r}, az = {b_z, b_z, b_z, b_z};
         f32x4 axn = {b_in, b_in, b_in, b_in}, ahn = {b_hn, b_hn, b_hn, b_hn};
@@ -552,7 +550,7 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
                 }
             }
             if (EPI == 2) {
-                const float* erow = &Es[(s + 2) % 3][cl][4 * q];             // slot (s-1) % 3: hf at the position of step s-1
+                const float* erow = &Es[(s + 3) & 3][cl][4 * q];             // slot (s-1) & 3: hf at the position of step s-1
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float4 e4 = *(const float4*)(erow + 16 * c);
@@ -566,10 +564,7 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
         if (s < n) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float r = sigmoid_f(ar[i]);
-                float z = sigmoid_f(az[i]);
-                float nn = gru_candidate(r, ahn[i], axn[i]);
-                float h = gru_blend(z, nn, h_own[i]);
+                float h = gru64_cell(ar[i], az[i], axn[i], ahn[i], h_own[i]);
                 h_own[i] = h;
                 Hs[hb][q * 4 + i][16 * w + cl] = h;
             }
@@ -582,7 +577,7 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < n) {
             *(float4*)&Xs[(s + 1) & 3][srow][scol] = xnext;
-            if (EPI == 2) *(float4*)&Es[(s + 1) % 3][srow][scol] = enext;  // read during step s+2; slot (s-1)%3 is the one in use now
+            if (EPI == 2) *(float4*)&Es[(s + 1) & 3][srow][scol] = enext;  // read during step s+2; slot (s-1)&3 is the one in use now
         }
         __syncthreads();
     }
