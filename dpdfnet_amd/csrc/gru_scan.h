@@ -71,14 +71,14 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
     const float* xbase = a.x + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
     float* obase = a.out + (long)hi0 * a.o_hi + (long)lo0 * a.o_lo + dir * a.o_dir_off;
     const int srow = 4 * w + q, scol = 4 * cl;
-    int sx_off, so_off; bool so_ok;
+    unsigned sx_off, so_off; bool so_ok;     // non-negative lane offsets: address = scalar per-step base + VGPR offset
     {
         int rs = row0 + srow;
         so_ok = rs < a.nrows;
         if (rs >= a.nrows) rs = a.nrows - 1;
         const int dh = rs / a.rdiv - hi0, dl = rs % a.rdiv - lo0;
-        sx_off = (int)((long)dh * a.x_hi + (long)dl * a.x_lo) + scol;
-        so_off = (int)((long)dh * a.o_hi + (long)dl * a.o_lo) + scol;
+        sx_off = (unsigned)((long)dh * a.x_hi + (long)dl * a.x_lo) + scol;
+        so_off = (unsigned)((long)dh * a.o_hi + (long)dl * a.o_lo) + scol;
     }
     float h_own[4];
 #pragma unroll
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
     }
     {
         const int p0 = dir ? a.nsteps - 1 : 0;
-        *(float4*)&Xs[0][srow][scol] = *(const float4*)(xbase + sx_off + (long)p0 * a.x_step);
+        *(float4*)&Xs[0][srow][scol] = *(const float4*)((xbase + (long)p0 * a.x_step) + sx_off);
     }
     __syncthreads();
 
@@ -104,13 +104,13 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
         if (s > 0 && !(GRU64_VARIANT & 2)) {
             const int pp = dir ? a.nsteps - s : s - 1;
             const float4 hv4 = *(const float4*)&Hs[buf ^ 1][srow][scol];
-            if (so_ok) *(float4*)(obase + so_off + (long)pp * a.o_step) = hv4;
+            if (so_ok) *(float4*)((obase + (long)pp * a.o_step) + so_off) = hv4;
         }
         float4 xnext = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!(GRU64_VARIANT & 8)) {
             const int sn = s + 1 < a.nsteps ? s + 1 : s;
             const int pn = dir ? a.nsteps - 1 - sn : sn;
-            xnext = *(const float4*)(xbase + sx_off + (long)pn * a.x_step);
+            xnext = *(const float4*)((xbase + (long)pn * a.x_step) + sx_off);
         }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 ar = {b_r, b_r, b_r, b_r}, az = {b_z, b_z, b_z, b_z};
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
     if (a.nsteps > 0 && !(GRU64_VARIANT & 2)) {
         const int pp = dir ? 0 : a.nsteps - 1;
         const float4 hv4 = *(const float4*)&Hs[buf ^ 1][srow][scol];
-        if (so_ok) *(float4*)(obase + so_off + (long)pp * a.o_step) = hv4;
+        if (so_ok) *(float4*)((obase + (long)pp * a.o_step) + so_off) = hv4;
     }
     if (a.hstate) {
 #pragma unroll
@@ -492,8 +492,7 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
     }
     __syncthreads();
 
-#pragma unroll 4
-    for (int s = 0; s < n + 2; ++s) {         // unrolled by the ring period: every LDS slot offset becomes an immediate
+    for (int s = 0; s < n + 2; ++s) {
         const int hb = s & 1;                 // Hs/Ys/Es slot written this step
         // ---- finalize step s-2: LayerNorm + residual on the row-contiguous pieces, one store per lane
         auto finalize = [&]() __attribute__((always_inline)) {
