@@ -63,6 +63,45 @@ def test_baseline_batch_configs_full_size(be, nb, B, check_oracle):
     m.close()
 
 
+def test_whole_config3_batch_on_one_gpu(be):
+    """configs[2] unsharded: all 2048 clips x 10 s (2.05 M frames) through ONE engine call -- what a single 288 GB
+    GPU is sized for; guards the 64-bit indexing of spectra / frame buffers (B*T*win = 657 M floats) and the
+    auto chunking at large B (16-frame chunks)."""
+    from oracle import oracle as orc
+    sr, n, nb, B = 16000, 160000, 2, 2048
+    m, blob = _model(be, sr, nb)
+    base = [synth_clip(n, sr, 9100 + i) for i in range(4)]
+    wav = np.empty((B, n), np.float32)
+    for b in range(B):
+        wav[b] = base[b % 4]
+    wav[B - 1, :] = base[1][::-1]                        # the very last slot holds something unique
+    out = m.enhance_batch(wav, None)
+    assert out.shape == wav.shape and np.isfinite(out).all()
+    np.testing.assert_array_equal(out[0], out[2044])
+    np.testing.assert_array_equal(out[1], out[1025])
+    o = orc.Oracle(sr, nb, blob)
+    for b in (2, B - 1):
+        err = rms(out[b] - o.enhance(wav[b]))
+        assert err < WAVE_TOL, (b, err)
+    m.close()
+
+
+def test_one_long_clip(be):
+    """A single 60 s utterance (6001 frames): the whole clip is ONE time chunk at B=1 (scans of 6001 dependent steps,
+    GRU-256 granule epochs far past one launch), against the oracle and against a 1000-frame chunking."""
+    from oracle import oracle as orc
+    sr, nb, n = 16000, 2, 60 * 16000
+    m, blob = _model(be, sr, nb)
+    wav = synth_clip(n, sr, 4242)[None, :]
+    out = m.enhance_batch(wav, 12.0)
+    assert m.num_frames(n) == 6003 and np.isfinite(out).all()
+    ref = orc.Oracle(sr, nb, blob).enhance(wav[0], 12.0)
+    assert rms(out[0] - ref) < WAVE_TOL
+    m.set_chunk_frames(1000)
+    assert rms(m.enhance_batch(wav, 12.0) - out) < 1e-6
+    m.close()
+
+
 def test_config5_64_streams_48khz_dpdfnet8(be):
     """configs[4]: 64 concurrent StreamEnhancer states on dpdfnet8_48khz_hr, 10 ms hops."""
     from oracle import oracle as orc

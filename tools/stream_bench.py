@@ -26,6 +26,13 @@ def run(sr, nb, S, hops_per_call, calls, warm=20, overlap=None, fuse=None):
     audio_per_call = hops_per_call * hop / sr
     print(json.dumps({"overlap": overlap, "fuse": fuse, "sr": sr, "nb": nb, "streams": S, "hops_per_call": hops_per_call, "us_per_call": round(us, 1),
                       "frames_per_s": round(fps), "rtf": round((dt / calls) / audio_per_call, 4)}))
+    if "--breakdown" in sys.argv:
+        m.set_overlap(0); m.profile(True)
+        for _ in range(20): st.process(pcm)
+        m.sync()
+        rep = m.profile_report(); m.profile(False)
+        print("  serial us/call:", {k: round(1e3 * v[0] / 20, 1) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])})
+        print("  launches/call:", sum(v[1] for v in rep.values()) / 20)
     st.close(); m.close()
 
 if __name__ == "__main__":
