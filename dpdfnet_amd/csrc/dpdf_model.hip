@@ -181,7 +181,8 @@ BnFold fold_bn(const Blob& B, const std::string& p, int ch) {
 
 struct SepConvW { size_t dw, pwfrag, bias; int nsub; };        // arena offsets
 struct PathW { size_t ps, pb; };
-struct GruW64 { size_t wfrag, bias; int ndirs; };
+struct GruW64 { size_t wfrag, bias; int ndirs;
+                size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
 struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
 struct Gru256W { size_t ih_frag, ih_bias, hh_frag, b_hn; };   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
@@ -222,11 +223,12 @@ struct Workspace {
     XSet x[2];
     // stage-1 temporaries (DF branch on the main stream, ERB branch on its own stream)
     DevBuf feat_erb, feat_spec, hcat, hin, hcat_e, hin_e;
+    DevBuf gi64, gi64_e;               // input-side GRU-64 pre-activations of the small-batch scans (grown on first use)
     // stage-2 temporaries
     DevBuf embin, g256a, g256b, g256c, gi, emb, demb, demb2, d3, d2, d1, m, dfo, coefs, xm;
     void release() {
         x[0].release(); x[1].release();
-        DevBuf* all[] = {&feat_erb, &feat_spec, &hcat, &hin, &hcat_e, &hin_e,
+        DevBuf* all[] = {&feat_erb, &feat_spec, &hcat, &hin, &hcat_e, &hin_e, &gi64, &gi64_e,
                          &embin, &g256a, &g256b, &g256c, &gi, &emb, &demb, &demb2, &d3, &d2, &d1, &m, &dfo, &coefs, &xm};
         for (DevBuf* b : all) b->release();
         Bcap = Tcap = 0;
@@ -257,6 +259,7 @@ struct dpdf_model {
     // bit 0: stage 2 on its own stream; bit 1: ERB encoder branch on its own stream (single-lane runs);
     // bit 2: split the batch over two lanes.  0 = everything serial on the main stream (A/B timing).
     int overlap = 3;
+    int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
     bool two_lanes_active = false;
@@ -375,6 +378,21 @@ GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::str
         }
     }
     g.wfrag = A.add(frag); g.bias = A.add(bias);
+    {   // the same W_ih (and input-side biases), scaled alike, as an ordinary GEMM operand for gru64_scan_gi_kernel
+        std::vector<float> gfrag, gbias;
+        for (int d = 0; d < g.ndirs; ++d) {
+            const std::string &p = dirs[d].first, &sfx = dirs[d].second;
+            const float* wih = B.get(p + ".weight_ih" + sfx);
+            const float* bih = B.get(p + ".bias_ih" + sfx); const float* bhh = B.get(p + ".bias_hh" + sfx);
+            for (int gate = 0; gate < 3; ++gate) {
+                auto f = pack_frag(64, 64, 4, [&](int k, int n) { return wih[(gate * 64 + n) * 64 + k] * gate_scale[gate]; });
+                gfrag.insert(gfrag.end(), f.begin(), f.end());
+                for (int j = 0; j < 64; ++j)
+                    gbias.push_back((gate < 2 ? bih[gate * 64 + j] + bhh[gate * 64 + j] : bih[128 + j]) * gate_scale[gate]);
+            }
+        }
+        g.ih_frag = A.add(gfrag); g.ih_bias = A.add(gbias);
+    }
     return g;
 }
 GlW build_gl(Arena& A, const Blob& B, const std::string& p, int G, int Og, int Ig) {
@@ -485,6 +503,19 @@ void erb_bands(int nfft, int fs, std::vector<int>& start, std::vector<int>& band
 
 int ensure_ws(dpdf_model* m, int B, int Tc) {
     Workspace& w = m->ln->ws;
+    {   // hoisted input-side GRU-64 pre-activations (run_dprnn): intra form (2 dirs x 192 per band row) only below 3072
+        // frame rows, inter form (192 per band row) whenever B*F' is too small to fill the chip.  Not monotone in B,
+        // so checked on every call; growing waits for the streams like the rest of the workspace.
+        const dpdf_dims& d = m->d;
+        const size_t BT = (size_t)B * Tc, bt_small = std::min(BT, (size_t)3071);
+        const size_t need_d = std::max(bt_small * d.Fd * 384, (size_t)B * d.Fd < 64 * 16 ? BT * d.Fd * 192 : (size_t)0);
+        const size_t need_e = std::max(bt_small * d.F3 * 384, (size_t)B * d.F3 < 64 * 16 ? BT * d.F3 * 192 : (size_t)0);
+        if (need_d > w.gi64.n || need_e > w.gi64_e.n) {
+            (void)hipStreamSynchronize(m->ln->sA); (void)hipStreamSynchronize(m->ln->sB); (void)hipStreamSynchronize(m->ln->sC);
+            int rc = w.gi64.ensure(need_d); if (rc) return rc;
+            rc = w.gi64_e.ensure(need_e); if (rc) return rc;
+        }
+    }
     if (B <= w.Bcap && Tc <= w.Tcap) return DPDF_OK;    // every size below is monotone in B and Tc
     // growing: make sure nothing in flight still uses the old buffers
     (void)hipStreamSynchronize(m->ln->sA); (void)hipStreamSynchronize(m->ln->sB); (void)hipStreamSynchronize(m->ln->sC);
@@ -575,71 +606,94 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
 }
 
 // DPRNN (reference onnx_model/layers.py:159-196, 278-302): x [B*Tc][Fp][64] -> same, in xa (uses xb as scratch)
-float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, float* xb, float* hcat, float* hin, int Fp,
+//
+// Each of the two recurrences of a block picks its form from the parallelism it actually has (tiles of 16 rows):
+//   intra-band: B*Tc/16 tiles x 2 directions, Fp steps;   inter-band: B*Fp/16 tiles, Tc steps.
+//   * enough tiles to oversubscribe the 256 CUs  -> fused scans (fc + LayerNorm + residual inside the scan step):
+//     the MFMA count is what matters and the fc rides along;
+//   * fewer                                       -> a scan step is pure latency: W_ih x is hoisted into one GEMM over
+//     all (row, step) pairs (gru64_scan_gi_kernel keeps the 48 h-part MFMAs), fc + LN run as a wide GEMM afterwards.
+// Measured (tools/sweep2.sh, tools/latency_bench.py): intra crossover at 192 tiles (3072 frame rows).  Inter: the
+// hoisted form wins below ~100 tiles when run alone (8 clips x 10 s: 8.7 -> 6.6 ms) but costs throughput inside the
+// stream pipeline of a big batch (256 clips, ERB branch, 128 tiles: 125.6 -> 128.7 ms/step), so it is used below 64.
+float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, float* xb, float* hcat, float* hin, DevBuf& gibuf, int Fp,
                  float* state, long S, int soff, int B, int Tc) {
     const int M = B * Tc * Fp;
     float* x = xa; float* y = xb;
-    // the fused form runs the two intra directions back to back (half the workgroups each) and carries the fc/LN
-    // latency inside the scan step, so it only pays once B*Tc/16 tiles oversubscribe the 256 CUs; below that
-    // (streaming hops, tiny batches) the direction-parallel scan + wide GEMM wins (tools/sweep2.sh, profiles/README)
-    const bool fused = (Fp % 4 == 0) && (m->fuse_dprnn == 2 || (m->fuse_dprnn == 1 && (long)B * Tc >= 3072));
+    const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0;
+    const bool fuse_intra = can_fuse && (m->fuse_dprnn == 2 || (long)B * Tc >= 3072);
+    const bool fuse_inter = can_fuse && (m->fuse_dprnn == 2 || (long)B * Fp >= 64 * 16);
+    const bool gi_intra = !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
+    const bool gi_inter = !fuse_inter && m->hoist_gi && Tc >= 4 && (size_t)M * 192 <= gibuf.n;
+    const bool df = Fp >= 48;
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         const DprnnW& w = blocks[bi];
         Gru64Args ai{};     // intra-band bi-GRU over frequency, h0 = 0: rows = frames, steps = band positions
         ai.x = x; ai.wfrag = m->C(w.intra.wfrag); ai.bias = m->C(w.intra.bias); ai.hstate = nullptr;
         ai.nrows = B * Tc; ai.nsteps = Fp; ai.rdiv = 1;
         ai.x_hi = (long)Fp * 64; ai.x_lo = 0; ai.x_step = 64;
+        if (fuse_intra) {
+            {   // forward direction: plain scan, hf -> `hin` scratch [rows][Fp][64]
+                ProfScope ps(m, df ? "gru64_scan_kernel/intra_fwd_df" : "gru64_scan_kernel/intra_fwd_erb");
+                ai.out = hin; ai.ndirs = 1; ai.o_hi = (long)Fp * 64; ai.o_lo = 0; ai.o_step = 64; ai.o_dir_off = 0;
+                hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ai);
+            }
+            {   // backward direction + fc_intra + ln_intra + residual
+                ProfScope ps(m, df ? "gru64_epi_kernel<2>/intra_bwd_df" : "gru64_epi_kernel<2>/intra_bwd_erb");
+                Gru64EpiArgs ea{ai, m->C(w.fci_epi), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b), hin, y};
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<2>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
+            }
+        } else {
+            ai.out = hcat; ai.ndirs = 2;
+            ai.o_hi = (long)Fp * 128; ai.o_lo = 0; ai.o_step = 128; ai.o_dir_off = 64;
+            if (gi_intra) {     // W_ih x for every (frame, band) in one GEMM, then the h-only scan
+                ProfScope ps(m, df ? "gru64_scan_gi_kernel/intra_df" : "gru64_scan_gi_kernel/intra_erb");
+                PlainA<64> ap{x, 64, 0, 64};
+                BiasActStore<4> ep{gibuf.p, 384, 64, m->C(w.intra.ih_bias), 64, 64, ACT_NONE};
+                launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.intra.ih_frag), ep, M, 64, 6);
+                hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const float*)gibuf.p, 384);
+            } else {
+                ProfScope ps(m, df ? "gru64_scan_kernel/intra_df" : "gru64_scan_kernel/intra_erb");
+                hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai);
+            }
+            {   // fc_intra + ln_intra + residual
+                ProfScope ps(m, "dprnn_fc_ln");
+                PlainA<128> ap{hcat, 128, 0, 128};
+                LnResStore ep{y, x, m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b)};
+                launch_gemm_rows<4, 128, true>(m->cur, ap, m->C(w.fci_frag), ep, M, 128, 1);
+            }
+        }
+        std::swap(x, y);
         Gru64Args ae{};     // inter-band GRUCell over time, one hidden state per band position
-        ae.wfrag = m->C(w.inter.wfrag); ae.bias = m->C(w.inter.bias);
+        ae.x = x; ae.wfrag = m->C(w.inter.wfrag); ae.bias = m->C(w.inter.bias);
         ae.hstate = state + soff + (long)bi * Fp * 64;
         ae.nrows = B * Fp; ae.nsteps = Tc; ae.ndirs = 1; ae.rdiv = Fp;
         ae.x_hi = (long)Tc * Fp * 64; ae.x_lo = 64; ae.x_step = (long)Fp * 64;
         ae.o_hi = ae.x_hi; ae.o_lo = 64; ae.o_step = ae.x_step; ae.o_dir_off = 0;
         ae.h_hi = S; ae.h_lo = 64;
-        if (fused) {
-            {   // forward direction: plain scan, hf -> `hin` scratch [rows][Fp][64]
-                ProfScope ps(m, Fp >= 48 ? "gru64_scan_kernel/intra_fwd_df" : "gru64_scan_kernel/intra_fwd_erb");
-                ai.out = hin; ai.ndirs = 1; ai.o_hi = (long)Fp * 64; ai.o_lo = 0; ai.o_step = 64; ai.o_dir_off = 0;
-                hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ai);
+        if (fuse_inter) {   // inter scan + fc_inter + ln_inter + residual
+            ProfScope ps(m, df ? "gru64_epi_kernel<1>/inter_df" : "gru64_epi_kernel<1>/inter_erb");
+            ae.out = nullptr;
+            Gru64EpiArgs ea{ae, m->C(w.fce_epi), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<1>), dim3((ae.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
+        } else {
+            ae.out = hin;
+            if (gi_inter) {
+                ProfScope ps(m, df ? "gru64_scan_gi_kernel/inter_df" : "gru64_scan_gi_kernel/inter_erb");
+                PlainA<64> ap{x, 64, 0, 64};
+                BiasActStore<4> ep{gibuf.p, 192, 64, m->C(w.inter.ih_bias), 64, 64, ACT_NONE};
+                launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.inter.ih_frag), ep, M, 64, 3);
+                hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const float*)gibuf.p, 192);
+            } else {
+                ProfScope ps(m, df ? "gru64_scan_kernel/inter_df" : "gru64_scan_kernel/inter_erb");
+                hipLaunchKernelGGL(gru64_scan_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae);
             }
-            {   // backward direction + fc_intra + ln_intra + residual
-                ProfScope ps(m, Fp >= 48 ? "gru64_epi_kernel<2>/intra_bwd_df" : "gru64_epi_kernel<2>/intra_bwd_erb");
-                Gru64EpiArgs ea{ai, m->C(w.fci_epi), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b), hin, y};
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<2>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
+            {
+                ProfScope ps(m, "dprnn_fc_ln");
+                PlainA<64> ap{hin, 64, 0, 64};
+                LnResStore ep{y, x, m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b)};
+                launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.fce_frag), ep, M, 64, 1);
             }
-            std::swap(x, y);
-            {   // inter scan + fc_inter + ln_inter + residual
-                ProfScope ps(m, Fp >= 48 ? "gru64_epi_kernel<1>/inter_df" : "gru64_epi_kernel<1>/inter_erb");
-                ae.x = x; ae.out = nullptr;
-                Gru64EpiArgs ea{ae, m->C(w.fce_epi), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<1>), dim3((ae.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
-            }
-            std::swap(x, y);
-            continue;
-        }
-        {
-            ProfScope ps(m, Fp >= 48 ? "gru64_scan_kernel/intra_df" : "gru64_scan_kernel/intra_erb");
-            ai.out = hcat; ai.ndirs = 2;
-            ai.o_hi = (long)Fp * 128; ai.o_lo = 0; ai.o_step = 128; ai.o_dir_off = 64;
-            hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai);
-        }
-        {   // fc_intra + ln_intra + residual
-            ProfScope ps(m, "dprnn_fc_ln");
-            PlainA<128> ap{hcat, 128, 0, 128};
-            LnResStore ep{y, x, m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b)};
-            launch_gemm_rows<4, 128, true>(m->cur, ap, m->C(w.fci_frag), ep, M, 128, 1);
-        }
-        std::swap(x, y);
-        {
-            ProfScope ps(m, Fp >= 48 ? "gru64_scan_kernel/inter_df" : "gru64_scan_kernel/inter_erb");
-            ae.x = x; ae.out = hin;
-            hipLaunchKernelGGL(gru64_scan_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae);
-        }
-        {
-            ProfScope ps(m, "dprnn_fc_ln");
-            PlainA<64> ap{hin, 64, 0, 64};
-            LnResStore ep{y, x, m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b)};
-            launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.fce_frag), ep, M, 64, 1);
         }
         std::swap(x, y);
     }
@@ -737,7 +791,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     x.e3d = x.e3.p;
     if (d.nb > 0) {
         HIP_TRY(hipMemcpyAsync(x.xe_a.p, x.e3.p, (size_t)BT * d.F3 * 64 * sizeof(float), hipMemcpyDeviceToDevice, sC));
-        x.e3d = run_dprnn(m, m->dprnn_erb, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, d.F3, state, S, L.dprnn_erb, B, Tc);
+        x.e3d = run_dprnn(m, m->dprnn_erb, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
     }
     // ---- encoder, DF branch (dpdfnet.py:221-234) on the main stream ----
     m->cur = sA;
@@ -753,7 +807,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     x.c1d = x.c1.p;
     if (d.nb > 0) {
         HIP_TRY(hipMemcpyAsync(x.xd_a.p, x.c1.p, (size_t)BT * d.Fd * 64 * sizeof(float), hipMemcpyDeviceToDevice, sA));
-        x.c1d = run_dprnn(m, m->dprnn_df, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, d.Fd, state, S, L.dprnn_df, B, Tc);
+        x.c1d = run_dprnn(m, m->dprnn_df, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
     }
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_jn[c.parity], sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_jn[c.parity], 0)); }
     {

@@ -176,6 +176,112 @@ __global__ __launch_bounds__(256, 3) void gru64_scan_kernel(Gru64Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gru64_scan_gi_kernel: the small-batch form of the scan.  When streams x frames is too small to put several
+// workgroups on every CU (single-hop streaming, one clip through enhance()), a scan step is pure latency: 96
+// dependent-issue MFMAs per wave, nothing to overlap them with.  Half of them (W_ih x) do not depend on the
+// recurrence, so they are hoisted into one gemm_rows launch over ALL (row, step) pairs -- which spreads over the idle
+// CUs -- and the scan keeps only the 48 h-part MFMAs per step: 1.9 -> 1.3 us per step.  gi holds, per memory row of x,
+// [dir][gate r,z,n][64] pre-activations incl. the input-side biases, already in the exponent scaling of gru64_cell.
+// At large batch the plain / fused kernels are used instead: there the MFMA count is what matters, not its latency,
+// and gi would only add HBM traffic.
+__global__ __launch_bounds__(256, 3) void gru64_scan_gi_kernel(Gru64Args a, const float* gi, int gw) {
+    __shared__ __attribute__((aligned(16))) float Hs[2][16][68];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dir = blockIdx.y;
+    const int row0 = blockIdx.x * 16;
+    const int cl = lane & 15, q = lane >> 4;
+    float whh[3][16];
+    {
+        const float* wp = a.wfrag + ((size_t)(dir * 4 + w) * 2) * 3 * 16 * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) whh[g][j] = wp[(size_t)((1 * 3 + g) * 16 + j) * 64];
+    }
+    const float b_hn = a.bias[(size_t)dir * 256 + 192 + 16 * w + cl];
+    const int hi0 = row0 / a.rdiv, lo0 = row0 - hi0 * a.rdiv;
+    float* obase = a.out + (long)hi0 * a.o_hi + (long)lo0 * a.o_lo + dir * a.o_dir_off;
+    // gi is addressed like x: memory row of x = x offset / 64, gw floats per row
+    const float* gbase = gi + ((long)hi0 * a.x_hi + (long)lo0 * a.x_lo) / 64 * gw + dir * 192 + 16 * w + cl;
+    const long gstep = a.x_step / 64 * gw;
+    const int srow = 4 * w + q, scol = 4 * cl;
+    unsigned so_off; bool so_ok;
+    {
+        int rs = row0 + srow;
+        so_ok = rs < a.nrows;
+        if (rs >= a.nrows) rs = a.nrows - 1;
+        so_off = (unsigned)((long)(rs / a.rdiv - hi0) * a.o_hi + (long)(rs % a.rdiv - lo0) * a.o_lo) + scol;
+    }
+    unsigned g_off[4];
+    float h_own[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int rc = row0 + q * 4 + i;
+        if (rc >= a.nrows) rc = a.nrows - 1;
+        g_off[i] = (unsigned)(((long)(rc / a.rdiv - hi0) * a.x_hi + (long)(rc % a.rdiv - lo0) * a.x_lo) / 64 * gw);
+        float hv = a.hstate ? a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] : 0.f;
+        h_own[i] = hv;
+        Hs[1][q * 4 + i][16 * w + cl] = hv;
+    }
+    float gr[4], gz[4], gn[4];
+    {
+        const float* gp = gbase + (long)(dir ? a.nsteps - 1 : 0) * gstep;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gr[i] = gp[g_off[i]]; gz[i] = gp[g_off[i] + 64]; gn[i] = gp[g_off[i] + 128]; }
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int s = 0; s < a.nsteps; ++s) {
+        if (s > 0) {
+            const int pp = dir ? a.nsteps - s : s - 1;
+            const float4 hv4 = *(const float4*)&Hs[buf ^ 1][srow][scol];
+            if (so_ok) *(float4*)((obase + (long)pp * a.o_step) + so_off) = hv4;
+        }
+        f32x4 ar = {gr[0], gr[1], gr[2], gr[3]}, az = {gz[0], gz[1], gz[2], gz[3]};
+        f32x4 axn = {gn[0], gn[1], gn[2], gn[3]}, ahn = {b_hn, b_hn, b_hn, b_hn};
+        {   // next step's input-side pre-activations (independent of h)
+            const int sn = s + 1 < a.nsteps ? s + 1 : s;
+            const float* gp = gbase + (long)(dir ? a.nsteps - 1 - sn : sn) * gstep;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { gr[i] = gp[g_off[i]]; gz[i] = gp[g_off[i] + 64]; gn[i] = gp[g_off[i] + 128]; }
+        }
+        const float* hrow = &Hs[buf ^ 1][cl][4 * q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 h4 = *(const float4*)(hrow + 16 * c);
+            const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                ar = mfma16(hv[kb], whh[0][c * 4 + kb], ar);
+                az = mfma16(hv[kb], whh[1][c * 4 + kb], az);
+                ahn = mfma16(hv[kb], whh[2][c * 4 + kb], ahn);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float h = gru64_cell(ar[i], az[i], axn[i], ahn[i], h_own[i]);
+            h_own[i] = h;
+            Hs[buf][q * 4 + i][16 * w + cl] = h;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (a.nsteps > 0) {
+        const int pp = dir ? 0 : a.nsteps - 1;
+        const float4 hv4 = *(const float4*)&Hs[buf ^ 1][srow][scol];
+        if (so_ok) *(float4*)((obase + (long)pp * a.o_step) + so_off) = hv4;
+    }
+    if (a.hstate) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int rc = row0 + q * 4 + i;
+            if (rc < a.nrows)
+                a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] = h_own[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 struct Gru256Args {
     const float* gi;       // [B*Tc][768]: W_ih x + (b_ir+b_hr | b_iz+b_hz | b_in)
     float* out;            // [B*Tc][256]
