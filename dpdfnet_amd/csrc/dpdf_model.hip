@@ -184,7 +184,7 @@ struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs;
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
 struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
-struct Gru256W { size_t ih_frag, ih_bias, hh_frag, b_hn; };   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
+struct Gru256W { size_t ih_frag, ih_frag_s, ih_bias, hh_frag, b_hn; };   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
                 size_t fci_epi, fce_epi; };   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
 
@@ -281,8 +281,8 @@ struct dpdf_model {
     PathW conv3p, conv2p, conv1p, conv0p;
     size_t c0out_w; float c0out_bias;
     size_t convp_frag, convp_bias;
-    size_t window, stft_frag, istft_frag;
-    int stft_groups, istft_groups, istft_K;
+    size_t window, stft_frag, stft_frag_s, istft_frag;
+    int stft_groups, stft_groups_s, istft_groups, istft_K;
     DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state;
     // profiling
     bool prof_on = false;
@@ -418,6 +418,15 @@ Gru256W build_gru256(Arena& A, const Blob& B, const std::string& p) {
         frag.insert(frag.end(), f.begin(), f.end());
     }
     g.ih_frag = A.add(frag);
+    {   // few rows (streaming hops, single clips): 24 blocks of 32 columns -> 4x the workgroups, a quarter of the
+        // dependent panel work each; the launch is latency-bound there
+        std::vector<float> fs;
+        for (int g24 = 0; g24 < 24; ++g24) {
+            auto f = pack_frag(256, 32, 2, [&](int k, int n) { return wih[(size_t)(g24 * 32 + n) * 256 + k]; });
+            fs.insert(fs.end(), f.begin(), f.end());
+        }
+        g.ih_frag_s = A.add(fs);
+    }
     std::vector<float> bias(768), bhn(256);
     for (int j = 0; j < 256; ++j) {
         bias[j] = bih[j] + bhh[j]; bias[256 + j] = bih[256 + j] + bhh[256 + j]; bias[512 + j] = bih[512 + j];
@@ -579,13 +588,21 @@ void run_gl_auto(dpdf_model* m, const GlW& g, const float* in, size_t lda, float
 }
 
 // SqueezedGRU_S cell: gi = W_ih x + b (all frames, one GEMM) then the recurrent scan
+// Row count below which the wide-N GEMMs switch to their narrow-column packing: with <= 8 row tiles the launch is a
+// handful of workgroups walking all K panels one after the other; narrower column blocks multiply the workgroups.
+constexpr int SMALL_M_ROWS = 512;
 void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int Tc) {
     const int M = B * Tc;
     {
         ProfScope ps(m, "gru256_proj");
         PlainA<64> ap{x, 256, 0, 256};
-        BiasActStore<8> ep{m->ln->ws.gi.p, 768, 128, m->C(g.ih_bias), 128, 128, ACT_NONE};
-        launch_gemm_rows<8, 64, false>(m->cur, ap, m->C(g.ih_frag), ep, M, 256, 6);
+        if (M <= SMALL_M_ROWS) {
+            BiasActStore<2> ep{m->ln->ws.gi.p, 768, 32, m->C(g.ih_bias), 32, 32, ACT_NONE};
+            launch_gemm_rows<2, 64, false>(m->cur, ap, m->C(g.ih_frag_s), ep, M, 256, 24);
+        } else {
+            BiasActStore<8> ep{m->ln->ws.gi.p, 768, 128, m->C(g.ih_bias), 128, 128, ACT_NONE};
+            launch_gemm_rows<8, 64, false>(m->cur, ap, m->C(g.ih_frag), ep, M, 256, 6);
+        }
     }
     {
         ProfScope ps(m, "gru256_scan");
@@ -765,7 +782,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     sio.seg_lo = 0; sio.seg_hi = 4;                    // erb_conv0 / df_conv0 / mask(spec) / df_convp FIFOs
     {
         ProfScope ps(m, "state_io");
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 4), dim3(256), 0, sA, sio);
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 4, 5), dim3(256), 0, sA, sio);
     }
     {
         ProfScope ps(m, "features");
@@ -813,7 +830,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 4), dim3(256), 0, sA, sio);
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 4, 5), dim3(256), 0, sA, sio);
     }
     m->ln->dbg_e3d = x.e3d; m->ln->dbg_c1d = x.c1d; m->ln->dbg_B = B; m->ln->dbg_Tc = Tc; m->ln->dbg_parity = c.parity;
     HIP_TRY(hipEventRecord(m->ln->ev_s1[c.parity], sA));
@@ -834,7 +851,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     sio.seg_lo = 4; sio.seg_hi = 6;                    // DF coefs delay / masked-spec FIFOs
     {
         ProfScope ps(m, "state_io");
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2), dim3(256), 0, st, sio);
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, st, sio);
     }
     const float* e3d = x.e3d; const float* c1d = x.c1d;
     TView e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
@@ -908,7 +925,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2), dim3(256), 0, st, sio);
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, st, sio);
     }
     if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_s2[c.parity], st)); m->ln->s2_pending[c.parity] = true; }
     HIP_TRY(hipGetLastError());
@@ -1072,6 +1089,21 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
             frag.insert(frag.end(), f.begin(), f.end());
         }
         m->stft_frag = A.add(frag);
+        // few frames (streaming hops): 32-column blocks, see SMALL_M_ROWS
+        const int NTs = 2;
+        m->stft_groups_s = ((N2 + 15) / 16 + NTs - 1) / NTs;
+        std::vector<float> fs;
+        for (int g = 0; g < m->stft_groups_s; ++g) {
+            auto f = pack_frag(d.win, NTs * 16, NTs, [&](int k, int n) -> float {
+                int ng = g * NTs * 16 + n;
+                if (ng >= N2) return 0.f;
+                int fb = ng / 2; long idx = ((long)fb * k) % d.win;
+                double ang = 2.0 * M_PI * (double)idx / d.win;
+                return (ng & 1) ? (float)(-std::sin(ang)) : (float)std::cos(ang);
+            });
+            fs.insert(fs.end(), f.begin(), f.end());
+        }
+        m->stft_frag_s = A.add(fs);
     }
     {
         const int NT = 5;
@@ -1440,9 +1472,15 @@ extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_
     hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, s->in_tail.p, xbuf, S, T, d.hop);
     {   // causal analysis (stream.py:119-126): frame j = xbuf[j*hop : j*hop+win] * window -> rfft.
                 StftA<64> ap{xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
-        BiasActStore<7> ep{s->spec.p, (size_t)2 * d.F, 112, nullptr, 0, 112, ACT_NONE};
-        ep.ncol_total = 2 * d.F;
-        launch_gemm_rows<7, 64, false>(m->stream, ap, m->C(m->stft_frag), ep, S * T, d.win, m->stft_groups);
+        if (S * T <= SMALL_M_ROWS) {
+            BiasActStore<2> ep{s->spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
+            ep.ncol_total = 2 * d.F;
+            launch_gemm_rows<2, 64, false>(m->stream, ap, m->C(m->stft_frag_s), ep, S * T, d.win, m->stft_groups_s);
+        } else {
+            BiasActStore<7> ep{s->spec.p, (size_t)2 * d.F, 112, nullptr, 0, 112, ACT_NONE};
+            ep.ncol_total = 2 * d.F;
+            launch_gemm_rows<7, 64, false>(m->stream, ap, m->C(m->stft_frag), ep, S * T, d.win, m->stft_groups);
+        }
     }
     rc = run_chunks(m, s->spec.p, (size_t)T * d.F * 2, S, T, s->state.p, s->spec_e.p, nullptr, 0.f);
     if (rc) return rc;

@@ -292,9 +292,9 @@ struct StateIoArgs {
     int seg_lo, seg_hi;    // this launch handles segments [seg_lo, seg_hi): 0 erb_conv0, 1 df_conv0, 2 mask spec, 3 df_convp | 4 coefs, 5 masked spec
 };
 __device__ __forceinline__ void fifo_io(float* st, float* tensor_frame0 /* frame t=0 of clip */, long frame_sz,
-                                        int cap, int Tc, int do_export, int tid, int nthreads) {
-    // plain layout: state frame j <-> tensor frame (export: Tc-cap+j, import: j-cap, j>=1)
-    for (int j = do_export ? 0 : 1; j < cap; ++j) {
+                                        int cap, int Tc, int do_export, int tid, int nthreads, int j) {
+    // plain layout: state frame j <-> tensor frame (export: Tc-cap+j, import: j-cap, j>=1); one FIFO frame per blockIdx.z
+    if (j >= (do_export ? 0 : 1) && j < cap) {
         long tf = do_export ? (long)Tc - cap + j : (long)j - cap;
         float* tp = tensor_frame0 + tf * frame_sz;
         float* sp = st + (long)j * frame_sz;
@@ -305,22 +305,24 @@ __device__ __forceinline__ void fifo_io(float* st, float* tensor_frame0 /* frame
 }
 __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
     const int b = blockIdx.x, seg = a.seg_lo + blockIdx.y, tid = threadIdx.x;
+    const int jz = blockIdx.z;         // FIFO frame handled by this workgroup (grid.z = 5 = deepest FIFO)
     if (seg >= a.seg_hi) return;
     float* st = a.state + (long)b * a.S;
     const int Tc = a.Tc;
     if (seg == 0) {
-        fifo_io(st + a.off_erb_buf, a.feat_erb + ((size_t)b * (Tc + 2) + 2) * a.E, a.E, 3, Tc, a.do_export, tid, 256);
+        fifo_io(st + a.off_erb_buf, a.feat_erb + ((size_t)b * (Tc + 2) + 2) * a.E, a.E, 3, Tc, a.do_export, tid, 256, jz);
     } else if (seg == 1) {
-        fifo_io(st + a.off_df_buf, a.feat_spec + ((size_t)b * (Tc + 2) + 2) * 2 * a.D, 2 * a.D, 3, Tc, a.do_export, tid, 256);
+        fifo_io(st + a.off_df_buf, a.feat_spec + ((size_t)b * (Tc + 2) + 2) * 2 * a.D, 2 * a.D, 3, Tc, a.do_export, tid, 256, jz);
     } else if (seg == 2) {
-        fifo_io(st + a.off_mask, a.xs + ((size_t)b * (Tc + 2) + 2) * a.F * 2, a.F * 2, 3, Tc, a.do_export, tid, 256);
+        fifo_io(st + a.off_mask, a.xs + ((size_t)b * (Tc + 2) + 2) * a.F * 2, a.F * 2, 3, Tc, a.do_export, tid, 256, jz);
     } else if (seg == 5) {
-        fifo_io(st + a.off_spec, a.xm + ((size_t)b * (Tc + 4) + 4) * a.F * 2, a.F * 2, 5, Tc, a.do_export, tid, 256);
+        fifo_io(st + a.off_spec, a.xm + ((size_t)b * (Tc + 4) + 4) * a.F * 2, a.F * 2, 5, Tc, a.do_export, tid, 256, jz);
     } else if (seg == 3) {
         // df_convp_buf [5][64][D] (channel-first) <-> c0 [B][4+Tc][D][64]
         const long fsz = 64L * a.D;
         float* t0 = a.c0 + ((size_t)b * (Tc + 4) + 4) * fsz;
-        for (int j = a.do_export ? 0 : 1; j < 5; ++j) {
+        const int j = jz;
+        if (j >= (a.do_export ? 0 : 1) && j < 5) {
             long tf = a.do_export ? (long)Tc - 5 + j : (long)j - 5;
             float* tp = t0 + tf * fsz;
             float* sp = st + a.off_convp + (long)j * fsz;
@@ -333,7 +335,8 @@ __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
         // coefs_buf [3][5][D][2] <-> coefs [B][2+Tc][D][10]
         const long fsz = 10L * a.D;
         float* t0 = a.coefs + ((size_t)b * (Tc + 2) + 2) * fsz;
-        for (int j = a.do_export ? 0 : 1; j < 3; ++j) {
+        const int j = jz;
+        if (j >= (a.do_export ? 0 : 1) && j < 3) {
             long tf = a.do_export ? (long)Tc - 3 + j : (long)j - 3;
             float* tp = t0 + tf * fsz;
             float* sp = st + a.off_coefs + (long)j * fsz;
