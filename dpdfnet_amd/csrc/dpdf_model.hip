@@ -226,10 +226,11 @@ struct Workspace {
     DevBuf gi64, gi64_e;               // input-side GRU-64 pre-activations of the small-batch scans (grown on first use)
     // stage-2 temporaries
     DevBuf embin, g256a, g256b, g256c, gi, emb, demb, demb2, d3, d2, d1, m, dfo, coefs, xm;
+    DevBuf g256d, g256e, g256f, gi2;   // DF-decoder chain's own scratch (runs beside the ERB decoder)
     void release() {
         x[0].release(); x[1].release();
         DevBuf* all[] = {&feat_erb, &feat_spec, &hcat, &hin, &hcat_e, &hin_e, &gi64, &gi64_e,
-                         &embin, &g256a, &g256b, &g256c, &gi, &emb, &demb, &demb2, &d3, &d2, &d1, &m, &dfo, &coefs, &xm};
+                         &embin, &g256a, &g256b, &g256c, &gi, &g256d, &g256e, &g256f, &gi2, &emb, &demb, &demb2, &d3, &d2, &d1, &m, &dfo, &coefs, &xm};
         for (DevBuf* b : all) b->release();
         Bcap = Tcap = 0;
     }
@@ -239,12 +240,14 @@ struct Workspace {
 // Clips are independent, so a batch is split over two lanes whose kernels the GPU interleaves:
 // HBM-bound phases of one lane run under MFMA-bound scans of the other.
 struct Lane {
-    hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
+    hipStream_t sA = nullptr, sB = nullptr, sC = nullptr, sD = nullptr;   // sD: DF-decoder half of stage 2
     hipEvent_t ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
     hipEvent_t ev_fk[2] = {nullptr, nullptr}, ev_jn[2] = {nullptr, nullptr};   // ERB-branch fork/join, per chunk parity
+    hipEvent_t ev_dfk[2] = {nullptr, nullptr}, ev_djn[2] = {nullptr, nullptr}; // decoder fork/join inside stage 2
     bool s2_pending[2] = {false, false};
     Workspace ws;
-    unsigned long long* gru_xbuf = nullptr; int gru_xbuf_tiles = 0; unsigned gru_epoch = 0;
+    // GRU-256 cluster exchange granules: [0] embedding + ERB-decoder cells, [1] DF-decoder cells (they may run concurrently)
+    unsigned long long* gru_xbuf[2] = {nullptr, nullptr}; int gru_xbuf_tiles[2] = {0, 0}; unsigned gru_epoch[2] = {0, 0};
     const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
 };
 
@@ -257,8 +260,9 @@ struct dpdf_model {
     hipStream_t cur = nullptr;         // stream the helper launchers enqueue on
     Lane lanes[2]; Lane* ln = nullptr; // current lane of the host-side enqueue loop
     // bit 0: stage 2 on its own stream; bit 1: ERB encoder branch on its own stream (single-lane runs);
-    // bit 2: split the batch over two lanes.  0 = everything serial on the main stream (A/B timing).
-    int overlap = 3;
+    // bit 2: split the batch over two lanes; bit 3: DF decoder beside the ERB decoder inside stage 2 (needs bit 0).
+    // 0 = everything serial on the main stream (A/B timing).
+    int overlap = 11;
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
@@ -520,14 +524,14 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
         const size_t need_d = std::max(bt_small * d.Fd * 384, (size_t)B * d.Fd < 64 * 16 ? BT * d.Fd * 192 : (size_t)0);
         const size_t need_e = std::max(bt_small * d.F3 * 384, (size_t)B * d.F3 < 64 * 16 ? BT * d.F3 * 192 : (size_t)0);
         if (need_d > w.gi64.n || need_e > w.gi64_e.n) {
-            (void)hipStreamSynchronize(m->ln->sA); (void)hipStreamSynchronize(m->ln->sB); (void)hipStreamSynchronize(m->ln->sC);
+            (void)hipStreamSynchronize(m->ln->sA); (void)hipStreamSynchronize(m->ln->sB); (void)hipStreamSynchronize(m->ln->sC); (void)hipStreamSynchronize(m->ln->sD);
             int rc = w.gi64.ensure(need_d); if (rc) return rc;
             rc = w.gi64_e.ensure(need_e); if (rc) return rc;
         }
     }
     if (B <= w.Bcap && Tc <= w.Tcap) return DPDF_OK;    // every size below is monotone in B and Tc
     // growing: make sure nothing in flight still uses the old buffers
-    (void)hipStreamSynchronize(m->ln->sA); (void)hipStreamSynchronize(m->ln->sB); (void)hipStreamSynchronize(m->ln->sC);
+    (void)hipStreamSynchronize(m->ln->sA); (void)hipStreamSynchronize(m->ln->sB); (void)hipStreamSynchronize(m->ln->sC); (void)hipStreamSynchronize(m->ln->sD);
     B = std::max(B, w.Bcap); Tc = std::max(Tc, w.Tcap);
     const dpdf_dims& d = m->d;
     const size_t BT = (size_t)B * Tc;
@@ -547,6 +551,7 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
     ENS(w.hcat_e, BT * d.F3 * 128); ENS(w.hin_e, BT * d.F3 * 64);
     ENS(w.embin, BT * 1024); ENS(w.g256a, BT * 256); ENS(w.g256b, BT * 256); ENS(w.g256c, BT * 256);
     ENS(w.gi, BT * 768); ENS(w.emb, BT * 512); ENS(w.demb, BT * 512);
+    ENS(w.g256d, BT * 256); ENS(w.g256e, BT * 256); ENS(w.g256f, BT * 256); ENS(w.gi2, BT * 768);
     ENS(w.demb2, BT * (size_t)d.F3 * 64);
     ENS(w.d3, BT * d.F2 * 64); ENS(w.d2, BT * d.F1 * 64); ENS(w.d1, BT * d.Ec * 64);
     ENS(w.m, BT * d.E); ENS(w.dfo, BT * d.D * 10);
@@ -556,21 +561,24 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
     return DPDF_OK;
 }
 
-int ensure_gru_xbuf(dpdf_model* m, int ntiles) {
-    if (ntiles <= m->ln->gru_xbuf_tiles && m->ln->gru_xbuf && m->d_err) return DPDF_OK;
-    if (m->ln->gru_xbuf) { (void)hipStreamSynchronize(m->ln->sA); (void)hipFree(m->ln->gru_xbuf); m->ln->gru_xbuf = nullptr; }
+int ensure_gru_xbuf(dpdf_model* m, int ntiles, int which) {
+    Lane& L = *m->ln;
+    if (ntiles <= L.gru_xbuf_tiles[which] && L.gru_xbuf[which] && m->d_err) return DPDF_OK;
+    if (L.gru_xbuf[which]) {
+        (void)hipStreamSynchronize(L.sA); (void)hipStreamSynchronize(L.sB); (void)hipStreamSynchronize(L.sD);
+        (void)hipFree(L.gru_xbuf[which]); L.gru_xbuf[which] = nullptr;
+    }
     const size_t bytes = (size_t)ntiles * 2 * 16 * 256 * 8;
-    if (hipMalloc((void**)&m->ln->gru_xbuf, bytes) != hipSuccess) { m->ln->gru_xbuf_tiles = 0; return DPDF_E_RUNTIME; }
-    (void)hipMemsetAsync(m->ln->gru_xbuf, 0, bytes, m->ln->sA);
-    m->ln->gru_epoch = 0;
-    m->ln->gru_xbuf_tiles = ntiles;
+    if (hipMalloc((void**)&L.gru_xbuf[which], bytes) != hipSuccess) { L.gru_xbuf_tiles[which] = 0; return DPDF_E_RUNTIME; }
+    (void)hipMemsetAsync(L.gru_xbuf[which], 0, bytes, m->cur);
+    L.gru_epoch[which] = 0;
+    L.gru_xbuf_tiles[which] = ntiles;
     if (!m->d_err) {
         if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return DPDF_E_RUNTIME;
-        (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->ln->sA);
+        (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->cur);
     }
     return DPDF_OK;
 }
-
 template <int NT, int KP>
 void run_gl(dpdf_model* m, const GlW& g, const float* in, size_t lda, float* out, size_t ldo, int M, int act) {
     PlainA<KP> ap{in, lda, g.Ig, g.Ig};
@@ -591,32 +599,35 @@ void run_gl_auto(dpdf_model* m, const GlW& g, const float* in, size_t lda, float
 // Row count below which the wide-N GEMMs switch to their narrow-column packing: with <= 8 row tiles the launch is a
 // handful of workgroups walking all K panels one after the other; narrower column blocks multiply the workgroups.
 constexpr int SMALL_M_ROWS = 512;
-void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int Tc) {
+// which: 0 = embedding / ERB-decoder cells (scratch ws.gi, granules [0]); 1 = DF-decoder cells (ws.gi2, granules [1])
+void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int Tc, int which = 0) {
     const int M = B * Tc;
+    float* gi = which ? m->ln->ws.gi2.p : m->ln->ws.gi.p;
     {
         ProfScope ps(m, "gru256_proj");
         PlainA<64> ap{x, 256, 0, 256};
         if (M <= SMALL_M_ROWS) {
-            BiasActStore<2> ep{m->ln->ws.gi.p, 768, 32, m->C(g.ih_bias), 32, 32, ACT_NONE};
+            BiasActStore<2> ep{gi, 768, 32, m->C(g.ih_bias), 32, 32, ACT_NONE};
             launch_gemm_rows<2, 64, false>(m->cur, ap, m->C(g.ih_frag_s), ep, M, 256, 24);
         } else {
-            BiasActStore<8> ep{m->ln->ws.gi.p, 768, 128, m->C(g.ih_bias), 128, 128, ACT_NONE};
+            BiasActStore<8> ep{gi, 768, 128, m->C(g.ih_bias), 128, 128, ACT_NONE};
             launch_gemm_rows<8, 64, false>(m->cur, ap, m->C(g.ih_frag), ep, M, 256, 6);
         }
     }
     {
         ProfScope ps(m, "gru256_scan");
         const int ntiles = (B + 15) / 16;
-        if (m->use_gru256_cluster && ensure_gru_xbuf(m, ntiles) == DPDF_OK) {
-            if (m->ln->gru_epoch > 0xF0000000u) {     // epoch wrap: re-zero the granules (once per ~4e9 steps)
-                (void)hipMemsetAsync(m->ln->gru_xbuf, 0, (size_t)m->ln->gru_xbuf_tiles * 2 * 16 * 256 * 8, m->cur);
-                m->ln->gru_epoch = 0;
+        if (m->use_gru256_cluster && ensure_gru_xbuf(m, ntiles, which) == DPDF_OK) {
+            Lane& L = *m->ln;
+            if (L.gru_epoch[which] > 0xF0000000u) {     // epoch wrap: re-zero the granules (once per ~4e9 steps)
+                (void)hipMemsetAsync(L.gru_xbuf[which], 0, (size_t)L.gru_xbuf_tiles[which] * 2 * 16 * 256 * 8, m->cur);
+                L.gru_epoch[which] = 0;
             }
-            Gru256CArgs a{m->ln->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc, m->ln->gru_xbuf, m->ln->gru_epoch, m->d_err};
-            m->ln->gru_epoch += (unsigned)Tc;
+            Gru256CArgs a{gi, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc, L.gru_xbuf[which], L.gru_epoch[which], m->d_err};
+            L.gru_epoch[which] += (unsigned)Tc;
             hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->cur, a);
         } else {
-            Gru256Args a{m->ln->ws.gi.p, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
+            Gru256Args a{gi, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
             hipLaunchKernelGGL(gru256_scan_kernel, dim3(ntiles), dim3(1024), 0, m->cur, a);
         }
     }
@@ -869,9 +880,44 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->enc_lin_out, w.g256b.p, 256, w.emb.p, 512, BT, ACT_RELU);
-        run_gl_auto(m, m->ed_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
+    }
+    // The two decoders only share `emb`: the DF decoder (2 GRU-256 cells, df_out, pathway conv) runs on its own stream
+    // beside the ERB decoder (2 cells, transposed convs, mask) -- the five latency-bound cell scans become three deep.
+    const bool fork = (m->overlap & 8) && st != m->ln->sA;
+    hipStream_t sd = fork ? m->ln->sD : st;
+    if (fork) { HIP_TRY(hipEventRecord(m->ln->ev_dfk[c.parity], st)); HIP_TRY(hipStreamWaitEvent(sd, m->ln->ev_dfk[c.parity], 0)); }
+    // ---- DF decoder (dpdfnet.py:486-519) ----
+    {
+        m->cur = sd;
+        float* ga = fork ? w.g256d.p : w.g256a.p; float* gb = fork ? w.g256e.p : w.g256b.p; float* gc = fork ? w.g256f.p : w.g256c.p;
+        const int which = fork ? 1 : 0;
+        {
+            ProfScope ps(m, "grouped_linear");
+            run_gl_auto(m, m->df_lin_in, w.emb.p, 512, ga, 256, BT, ACT_RELU);
+        }
+        run_gru256(m, m->df_gru0, ga, gb, state, S, L.df_dec_gru, B, Tc, which);
+        run_gru256(m, m->df_gru1, gb, gc, state, S, L.df_dec_gru + 256, B, Tc, which);
+        {
+            ProfScope ps(m, "grouped_linear");
+            run_gl_auto(m, m->df_skip, w.emb.p, 512, ga, 256, BT, ACT_NONE);   // c = df_gru(emb) + df_skip(emb)
+        }
+        {
+            ProfScope ps(m, "df_coefs");
+            size_t n = (size_t)BT * 256;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(axpy_kernel), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, sd, gc, ga, n);
+            run_gl_auto(m, m->df_out, gc, 256, w.dfo.p, (size_t)d.D * 10, BT, ACT_TANH);
+            RowMap rm = RowMap::make(Tc, d.D);
+            ConvpA ap{c0v, rm};
+            ConvpEpi ep{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
+            launch_gemm_rows<1, 64, false>(sd, ap, m->C(m->convp_frag), ep, BT * d.D, 320, 1);
+        }
+        m->cur = st;
     }
     // ---- ERB decoder (dpdfnet.py:343-368; 48k hr.py:405-432) ----
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->ed_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
+    }
     run_gru256(m, m->ed_gru0, w.g256a.p, w.g256b.p, state, S, L.erb_dec_gru, B, Tc);
     run_gru256(m, m->ed_gru1, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc);
     float* dembp = w.demb.p;
@@ -891,27 +937,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
                        BT * d.Ec, d.Ec, d.E, d.is48};
         hipLaunchKernelGGL(mask_out_kernel, dim3((BT * d.Ec + 3) / 4), dim3(256), 0, st, ma);
     }
-    // ---- DF decoder (dpdfnet.py:486-519) ----
-    {
-        ProfScope ps(m, "grouped_linear");
-        run_gl_auto(m, m->df_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
-    }
-    run_gru256(m, m->df_gru0, w.g256a.p, w.g256b.p, state, S, L.df_dec_gru, B, Tc);
-    run_gru256(m, m->df_gru1, w.g256b.p, w.g256c.p, state, S, L.df_dec_gru + 256, B, Tc);
-    {
-        ProfScope ps(m, "grouped_linear");
-        run_gl_auto(m, m->df_skip, w.emb.p, 512, w.g256a.p, 256, BT, ACT_NONE);   // c = df_gru(emb) + df_skip(emb)
-    }
-    {
-        ProfScope ps(m, "df_coefs");
-        size_t n = (size_t)BT * 256;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(axpy_kernel), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, w.g256c.p, w.g256a.p, n);
-        run_gl_auto(m, m->df_out, w.g256c.p, 256, w.dfo.p, (size_t)d.D * 10, BT, ACT_TANH);
-        RowMap rm = RowMap::make(Tc, d.D);
-        ConvpA ap{c0v, rm};
-        ConvpEpi ep{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
-        launch_gemm_rows<1, 64, false>(st, ap, m->C(m->convp_frag), ep, BT * d.D, 320, 1);
-    }
+    if (fork) { HIP_TRY(hipEventRecord(m->ln->ev_djn[c.parity], sd)); HIP_TRY(hipStreamWaitEvent(st, m->ln->ev_djn[c.parity], 0)); }
     // ---- mask + deep filter (layers.py:414-445, multiframe.py:200-232) ----
     {
         ProfScope ps(m, "mask_df");
@@ -1136,11 +1162,18 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
             HIP_TRY(hipStreamCreateWithPriority(&L.sB, hipStreamNonBlocking, hi));
         }
         HIP_TRY(hipStreamCreateWithFlags(&L.sC, hipStreamNonBlocking));
+        {
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&L.sD, hipStreamNonBlocking, hi));
+        }
         for (int p = 0; p < 2; ++p) {
             HIP_TRY(hipEventCreateWithFlags(&L.ev_s1[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_s2[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_fk[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_jn[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_dfk[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_djn[p], hipEventDisableTiming));
         }
         HIP_TRY(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
@@ -1191,7 +1224,8 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
         if (L.sB) (void)hipStreamSynchronize(L.sB);
         if (L.sC) (void)hipStreamSynchronize(L.sC);
         L.ws.release();
-        if (L.gru_xbuf) (void)hipFree(L.gru_xbuf);
+        if (L.sD) (void)hipStreamSynchronize(L.sD);
+        for (int k = 0; k < 2; ++k) if (L.gru_xbuf[k]) (void)hipFree(L.gru_xbuf[k]);
     }
     DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state};
     for (DevBuf* b : bufs) b->release();
@@ -1204,12 +1238,13 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     for (int g = 0; g < 2; ++g) {
         Lane& L = m->lanes[g];
-        for (int p = 0; p < 2; ++p) { if (L.ev_s1[p]) (void)hipEventDestroy(L.ev_s1[p]); if (L.ev_s2[p]) (void)hipEventDestroy(L.ev_s2[p]); if (L.ev_fk[p]) (void)hipEventDestroy(L.ev_fk[p]); if (L.ev_jn[p]) (void)hipEventDestroy(L.ev_jn[p]); }
+        for (int p = 0; p < 2; ++p) { if (L.ev_s1[p]) (void)hipEventDestroy(L.ev_s1[p]); if (L.ev_s2[p]) (void)hipEventDestroy(L.ev_s2[p]); if (L.ev_fk[p]) (void)hipEventDestroy(L.ev_fk[p]); if (L.ev_jn[p]) (void)hipEventDestroy(L.ev_jn[p]); if (L.ev_dfk[p]) (void)hipEventDestroy(L.ev_dfk[p]); if (L.ev_djn[p]) (void)hipEventDestroy(L.ev_djn[p]); }
         if (L.ev_fork) (void)hipEventDestroy(L.ev_fork);
         if (L.ev_join) (void)hipEventDestroy(L.ev_join);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
         if (L.sB) (void)hipStreamDestroy(L.sB);
         if (L.sC) (void)hipStreamDestroy(L.sC);
+        if (L.sD) (void)hipStreamDestroy(L.sD);
         if (L.sA) (void)hipStreamDestroy(L.sA);
     }
     delete m;
@@ -1253,7 +1288,7 @@ extern "C" int dpdf_set_overlap(dpdf_model* m, int on) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
     std::lock_guard<std::mutex> lk(m->mu);
     (void)hipSetDevice(m->device);
-    for (int g = 0; g < 2; ++g) { (void)hipStreamSynchronize(m->lanes[g].sA); (void)hipStreamSynchronize(m->lanes[g].sB); (void)hipStreamSynchronize(m->lanes[g].sC); }
+    for (int g = 0; g < 2; ++g) { (void)hipStreamSynchronize(m->lanes[g].sA); (void)hipStreamSynchronize(m->lanes[g].sB); (void)hipStreamSynchronize(m->lanes[g].sC); (void)hipStreamSynchronize(m->lanes[g].sD); }
     m->overlap = on;
     return DPDF_OK;
 }
