@@ -203,7 +203,7 @@ def main() -> None:
         sync(); t1 = time.perf_counter(); step(); sync(); iso_ms = 1e3 * (time.perf_counter() - t1)
         iso_prof = model.profile_report()
         model.profile(False)
-        model.set_overlap(args.overlap if args.overlap >= 0 else 11)
+        model.set_overlap(args.overlap if args.overlap >= 0 else 27)
 
     if rank == 0:
         finite = bool(torch.isfinite(out).all().item())

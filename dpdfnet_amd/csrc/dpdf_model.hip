@@ -260,9 +260,10 @@ struct dpdf_model {
     hipStream_t cur = nullptr;         // stream the helper launchers enqueue on
     Lane lanes[2]; Lane* ln = nullptr; // current lane of the host-side enqueue loop
     // bit 0: stage 2 on its own stream; bit 1: ERB encoder branch on its own stream (single-lane runs);
-    // bit 2: split the batch over two lanes; bit 3: DF decoder beside the ERB decoder inside stage 2 (needs bit 0).
+    // bit 2: split the batch over two lanes; bit 3: DF decoder beside the ERB decoder inside stage 2 (needs bit 0);
+    // bit 4: GRU-256 scans on 8 workgroups per tile when the launch has <= 4 tiles.
     // 0 = everything serial on the main stream (A/B timing).
-    int overlap = 11;
+    int overlap = 27;
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
@@ -625,7 +626,9 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
             }
             Gru256CArgs a{gi, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc, L.gru_xbuf[which], L.gru_epoch[which], m->d_err};
             L.gru_epoch[which] += (unsigned)Tc;
-            hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->cur, a);
+            // eight workgroups per tile: measured better up to 64 clips, worse from 128 (tools/sweep2.sh)
+            if ((m->overlap & 16) && ntiles <= 4) hipLaunchKernelGGL(gru256_cluster8_kernel, dim3(ntiles * 8), dim3(256), 0, m->cur, a);
+            else hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->cur, a);
         } else {
             Gru256Args a{gi, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
             hipLaunchKernelGGL(gru256_scan_kernel, dim3(ntiles), dim3(1024), 0, m->cur, a);

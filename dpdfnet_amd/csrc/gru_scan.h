@@ -502,6 +502,152 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gru256_cluster8_kernel: the same cluster scan on EIGHT workgroups per 16-row tile, for launches that leave most of
+// the chip idle anyway (<= 4 tiles = 64 streams; beyond that the doubled CU footprint costs more than it buys).  A step of the 4-workgroup form is 2.6 us of dependent MFMAs (192 per wave) plus
+// one L2 exchange; here workgroup j owns 32 hidden units and its four waves split them 2 (unit halves) x 2 (K
+// halves): 96 MFMAs per wave per step, the two K-halves are summed through LDS, and each wave finishes two of the four
+// C-layout rows of its 16x16 block.  Same granule protocol, same exchange buffer layout, same W_hh fragment packing.
+__global__ __launch_bounds__(256, 1) void gru256_cluster8_kernel(Gru256CArgs a) {
+    __shared__ __attribute__((aligned(16))) float Hs[2][16][260];
+    __shared__ float Ps[4][3][4][64];            // per wave: partial pre-activations [gate][C-layout row i][lane]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int cl = lane & 15, q = lane >> 4;
+    const int uh = w & 1, kh = w >> 1;
+    const int ntiles = gridDim.x >> 3;
+    int rt, j;
+    if ((ntiles & 7) == 0) {       // keep a cluster on one XCD (block b -> XCD b % 8): speed only
+        rt = (blockIdx.x & 7) + 8 * (blockIdx.x >> 6);
+        j = (blockIdx.x >> 3) & 7;
+    } else {
+        rt = blockIdx.x >> 3; j = blockIdx.x & 7;
+    }
+    const int row0 = rt * 16;
+    const int u0 = 32 * j + 16 * uh;           // first hidden unit of this wave's column block
+
+    float wr[32], wz[32], wn[32];              // K half kh: chunks [8 kh, 8 kh + 8)
+    {
+        const float* wf = a.whh_frag + ((size_t)(2 * j + uh) * 3) * 64 * 64 + (size_t)(32 * kh) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            wr[k] = wf[(size_t)(0 * 64 + k) * 64];
+            wz[k] = wf[(size_t)(1 * 64 + k) * 64];
+            wn[k] = wf[(size_t)(2 * 64 + k) * 64];
+        }
+    }
+    const float bhn = a.b_hn[u0 + cl];
+    // this wave finalises C-layout rows i = 2 kh + {0, 1} of its block: tile rows q*4 + 2 kh + e
+    int rc[2]; bool ok[2]; float h_own[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        int r = row0 + q * 4 + 2 * kh + e;
+        ok[e] = r < a.B;
+        rc[e] = ok[e] ? r : a.B - 1;
+        h_own[e] = a.hstate[(long)rc[e] * a.h_stride + u0 + cl];
+    }
+    for (int idx = tid; idx < 16 * 256; idx += 256) {
+        int r = idx >> 8, u = idx & 255;
+        int rr = row0 + r < a.B ? row0 + r : a.B - 1;
+        Hs[0][r][u] = a.hstate[(long)rr * a.h_stride + u];
+    }
+    __syncthreads();
+
+    unsigned long long* xb = a.xbuf + (size_t)rt * 2 * 16 * 256;
+    float gr[2], gz[2], gn[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float* g = a.gi + ((size_t)rc[e] * a.Tc) * 768 + u0 + cl;
+        gr[e] = g[0]; gz[e] = g[256]; gn[e] = g[512];
+    }
+    int cur = 0;
+    for (int t = 0; t < a.Tc; ++t) {
+        f32x4 pr = {0.f, 0.f, 0.f, 0.f}, pz = pr, pn = pr;
+        const float* hrow = &Hs[cur][cl][128 * kh + 4 * q];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float4 h4 = *(const float4*)(hrow + 16 * c);
+            const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                pr = mfma16(hv[kb], wr[c * 4 + kb], pr);
+                pz = mfma16(hv[kb], wz[c * 4 + kb], pz);
+                pn = mfma16(hv[kb], wn[c * 4 + kb], pn);
+            }
+        }
+        // hand the two rows the partner wave (same units, other K half) finalises over to it
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * (1 - kh) + e;
+            Ps[w][0][i][lane] = pr[i]; Ps[w][1][i][lane] = pz[i]; Ps[w][2][i][lane] = pn[i];
+        }
+        const float xr[2] = {gr[0], gr[1]}, xz[2] = {gz[0], gz[1]}, xn[2] = {gn[0], gn[1]};
+        if (t + 1 < a.Tc) {        // prefetch next step's input projections (independent of h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float* g = a.gi + ((size_t)rc[e] * a.Tc + t + 1) * 768 + u0 + cl;
+                gr[e] = g[0]; gz[e] = g[256]; gn[e] = g[512];
+            }
+        }
+        __syncthreads();
+        const int nxt = cur ^ 1;
+        const unsigned epoch = a.epoch_base + (unsigned)t + 1u;
+        unsigned long long* slot = xb + (size_t)(t & 1) * 16 * 256;
+        const int pw = w ^ 2;                   // partner: same unit half, other K half
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * kh + e;
+            const float ar = xr[e] + (pr[i] + Ps[pw][0][i][lane]);
+            const float az = xz[e] + (pz[i] + Ps[pw][1][i][lane]);
+            const float ahn = bhn + (pn[i] + Ps[pw][2][i][lane]);
+            float r = sigmoid_f(ar);
+            float z = sigmoid_f(az);
+            float n = gru_candidate(r, ahn, xn[e]);
+            h_own[e] = gru_blend(z, n, h_own[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            __hip_atomic_store(slot + (q * 4 + 2 * kh + e) * 256 + u0 + cl,
+                               ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(h_own[e]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            Hs[nxt][q * 4 + 2 * kh + e][u0 + cl] = h_own[e];
+            if (ok[e]) a.out[((size_t)rc[e] * a.Tc + t) * 256 + u0 + cl] = h_own[e];
+        }
+        // sweep the seven peers' slices (7 x 16 rows x 32 units = 14 granules per thread), all loads in one batch;
+        // also after the LAST step (see gru256_cluster_kernel)
+        {
+            unsigned long long xv[14];
+            unsigned spins = 0;
+            for (;;) {
+                bool all_in = true;
+#pragma unroll
+                for (int k = 0; k < 14; ++k) {
+                    const int idx = tid + 256 * k;
+                    const int s = idx >> 9, r = (idx >> 5) & 15, u = 32 * ((j + 1 + s) & 7) + (idx & 31);
+                    xv[k] = __hip_atomic_load(slot + r * 256 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < 14; ++k) all_in &= (unsigned)(xv[k] >> 32) == epoch;
+                if (all_in) break;
+                if (++spins > (1u << 22)) { *a.err = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < 14; ++k) {
+                const int idx = tid + 256 * k;
+                const int s = idx >> 9, r = (idx >> 5) & 15, u = 32 * ((j + 1 + s) & 7) + (idx & 31);
+                Hs[nxt][r][u] = __uint_as_float((unsigned)xv[k]);
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        if (ok[e]) a.hstate[(long)rc[e] * a.h_stride + u0 + cl] = h_own[e];
+}
+
+// ---------------------------------------------------------------------------------------------
 // gru64_epi_kernel<EPI>: the same scan with the DPRNN block's Linear + LayerNorm + residual
 // (reference onnx_model/layers.py:178-181, 190-193) fused in, so neither the GRU outputs (h
 // sequences) of the inter-band scan nor the fwd|bwd concatenation of the intra-band scan make a

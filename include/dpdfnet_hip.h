@@ -98,9 +98,10 @@ int dpdf_profile_enable(dpdf_model* m, int on);
 size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap);
 /* Set the time-chunk length used by dpdf_enhance_batch (frames per chunk; <=0 = whole clip). */
 int dpdf_set_chunk_frames(dpdf_model* m, int frames);
-/* Stream pipeline mask (default 11 = 1|2|8): bit 0 stage 2 of chunk i (GRU-256 scans, decoders) on its own HIP stream
+/* Execution-shape mask (default 27 = 1|2|8|16): bit 0 stage 2 of chunk i (GRU-256 scans, decoders) on its own HIP stream
  * underneath stage 1 of chunk i+1; bit 1 the ERB encoder branch on its own stream; bit 2 split the batch over two lanes
- * (measured slower, off); bit 3 the DF decoder beside the ERB decoder inside stage 2.  0: everything serial on one
+ * (measured slower, off); bit 3 the DF decoder beside the ERB decoder inside stage 2; bit 4 eight (not four) workgroups per
+ * tile in the GRU-256 cluster scans of small launches.  0: everything serial on one
  * stream (A/B timing). */
 int dpdf_set_overlap(dpdf_model* m, int mask);
 /* Where fc + LayerNorm + residual of every DPRNN block run: 2 always inside the GRU-64 scan kernels;

@@ -126,7 +126,7 @@ def test_single_frame_chunks_are_race_free_under_stream_overlap(case):
     m.set_chunk_frames(0)
     ref, st_ref = m.run_frames(spec, m.initial_state())
     m.set_chunk_frames(1)
-    m.set_overlap(11)
+    m.set_overlap(27)
     try:
         for _ in range(60):
             out, st = m.run_frames(spec, m.initial_state())

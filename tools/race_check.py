@@ -14,7 +14,7 @@ segs = [("erb_norm", d.E), ("spec_norm", d.D), ("erb_conv0_buf", 3*d.E), ("dprnn
 NT = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 spec = o.stft(g["wav"])[:NT]
 m.set_chunk_frames(0); ref, st_ref = m.run_frames(spec, m.initial_state())
-m.set_overlap(11); m.set_chunk_frames(1)
+m.set_overlap(27); m.set_chunk_frames(1)
 bad = 0
 for rep in range(300):
     out, st = m.run_frames(spec, m.initial_state())
