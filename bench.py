@@ -271,6 +271,11 @@ def main() -> None:
         }
         if iso_prof is not None:
             ki = kernel_stats_iso
+            roofline["frac_isolated"] = round(ki[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if dom in ki else None
+            roofline["frac_note"] = ("`frac` divides by the launch duration seen INSIDE the 4-stream pipeline, where the kernel "
+                                     "shares the CUs with three other streams (faster pipeline => longer individual launches); "
+                                     "`frac_isolated` is the same kernel, same launches, run back to back in the extra serial "
+                                     "step; `whole_path_frac` is frames/s x FLOP/frame over the fp32 MFMA peak")
             roofline["roofline_isolated"] = {
                 "note": "one extra step AFTER the timed region with the stream pipeline switched off (kernels back to back)",
                 "ms_per_step": iso_ms,
