@@ -103,6 +103,55 @@ def cpu_baseline(blob: np.ndarray, seconds_per_clip: float, clips_per_thread: in
     }
 
 
+def other_configs() -> dict:
+    """BASELINE.json's remaining single-GPU configurations, timed briefly beside the headline (they are parity-test
+    cases in tests/test_gpu_fullsize.py; these are their speeds): dpdfnet2 / dpdfnet8 at 256 clips x 10 s, one clip
+    through the engine (what a single `enhance()` call costs), and configs[4]: 64 concurrent device-resident
+    dpdfnet8_48khz_hr streams, one 10 ms hop per call (host PCM in, host PCM out)."""
+    import torch
+    from dpdfnet_amd import backend
+    from dpdfnet_amd.weights import synth_blob
+    out: dict = {}
+    n = int(CLIP_SECONDS * SR)
+
+    def offline(nb: int, B: int, reps: int) -> float:
+        m = backend.HipModel(SR, nb, synth_blob(backend.manifest(SR, nb), WEIGHT_SEED), device=torch.cuda.current_device())
+        wav = torch.from_numpy(synth_clips(min(B, 8), n, SR, 5000)).cuda().repeat((B + 7) // 8, 1)[:B].contiguous()
+        y = torch.empty_like(wav)
+        m.enhance_batch_device(wav.data_ptr(), B, n, y.data_ptr(), None); m.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.enhance_batch_device(wav.data_ptr(), B, n, y.data_ptr(), None)
+        m.sync()
+        dt = (time.perf_counter() - t0) / reps
+        T = m.num_frames(n); m.close()
+        return B * T / dt, 1e3 * dt
+
+    for nb in (2, 8):
+        fps, ms = offline(nb, 256, 2)
+        out[f"dpdfnet{nb}_16k_256x10s"] = {"frames_per_s": round(fps), "ms_per_step": round(ms, 2)}
+    fps, ms = offline(NB, 1, 5)
+    out[f"{MODEL}_16k_1x10s"] = {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5)}
+    sr48, nb48, S = 48000, 8, 64
+    m = backend.HipModel(sr48, nb48, synth_blob(backend.manifest(sr48, nb48), WEIGHT_SEED), device=torch.cuda.current_device())
+    st = backend.HipStreams(m, S)
+    rng = np.random.default_rng(0)
+    hop = m.hop
+    st.prime((0.05 * rng.standard_normal((S, hop))).astype(np.float32))
+    pcm = (0.05 * rng.standard_normal((S, hop))).astype(np.float32)
+    for _ in range(20):
+        st.process(pcm)
+    t0 = time.perf_counter()
+    calls = 200
+    for _ in range(calls):
+        st.process(pcm)
+    dt = (time.perf_counter() - t0) / calls
+    st.close(); m.close()
+    out["dpdfnet8_48khz_hr_64_streams_1_hop"] = {"us_per_call": round(1e6 * dt, 1), "frames_per_s": round(S / dt),
+                                                  "rtf": round(dt / (hop / sr48), 4)}
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,11 +160,12 @@ def main() -> None:
     ap.add_argument("--clips", type=int, default=256, help="clips per GPU")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("DPDF_CHUNK_FRAMES", "0")),
                     help="time-chunk length in frames (0 = engine default)")
-    ap.add_argument("--overlap", type=int, default=-1, help="overlap bit mask (1 stage-2 stream, 2 ERB stream, 4 two lanes; 0 serial; -1 engine default)")
+    ap.add_argument("--overlap", type=int, default=-1, help="overlap bit mask (1 stage-2 stream, 2 ERB stream, 4 two lanes, 8 decoder fork, 16 8-WG GRU-256 clusters; 0 serial; -1 engine default)")
     ap.add_argument("--no-fuse", action="store_true", help="run fc+LN of the DPRNN blocks as separate kernels")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra serial profiling step")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the brief timings of BASELINE's other single-GPU configs")
     ap.add_argument("--cpu-clip-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-clips-per-thread", type=int, default=5)
     args = ap.parse_args()
@@ -295,6 +345,11 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blob, args.cpu_clip_seconds, args.cpu_clips_per_thread)
+        if world == 1 and not args.no_other_configs and not args.no_isolated:
+            try:
+                line["other_configs"] = other_configs()
+            except Exception as exc:  # never lose the headline line over the side measurements
+                line["other_configs"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
