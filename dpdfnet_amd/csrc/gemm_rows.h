@@ -542,6 +542,88 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(AProd ap, const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_rows_wn_kernel: the same 64-row tile, waves split over COLUMNS instead of rows.  In gemm_rows_kernel every wave
+// owns 16 rows and all NT column tiles, so the four waves each fetch the SAME B fragments of a panel (128 loads per
+// lane for NT = 8): on wide, non-persistent operands that redundant traffic through the vector-memory path takes as
+// long as the MFMAs.  Here wave w owns all 64 rows and the NTW column tiles of column group (grp*4 + w): a quarter of
+// the B loads, none of them redundant; the A fragments of the four 16-row tiles come from the shared LDS panel.
+// wfrag / epilogue are those of a gemm_rows launch with NT = NTW and 4x the groups.
+template <int NTW, int KP, class AProd, class Epi>
+__global__ __launch_bounds__(256) void gemm_rows_wn_kernel(AProd ap, const float* __restrict__ wfrag, Epi ep, int M, int K) {
+    __shared__ __attribute__((aligned(16))) float As[2][GEMM_BM][KP + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int grp = blockIdx.y, cgrp = grp * 4 + wave;
+    const int nchunks = K / 16, npanels = K / KP;
+    const float* wf = wfrag + (size_t)cgrp * nchunks * NTW * 256 + lane;
+    const int ntiles = (M + GEMM_BM - 1) / GEMM_BM;
+    constexpr int PB = (KP / 16) * NTW * 4;
+    float breg[PB];
+    int tile = blockIdx.x, panel = 0, cur = 0;
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+    typename AProd::Regs R;
+    ap.load(R, tile * GEMM_BM, 0, grp, M);
+    ap.store(As[0], R, tile * GEMM_BM, 0, grp, M);
+    __syncthreads();
+    f32x4 acc[4][NTW];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    while (true) {
+        int ntile = tile, npanel = panel + 1;
+        if (npanel == npanels) { npanel = 0; ntile = tile + gridDim.x; }
+        const bool has_next = ntile < ntiles;
+        {
+            const float* wp = wf + (size_t)panel * PB * 64;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) breg[i] = wp[(size_t)i * 64];
+        }
+        if (has_next) ap.load(R, ntile * GEMM_BM, npanel * KP, grp, M);
+        const bool last_panel = panel == npanels - 1;
+        const float* arow = &As[cur][lane & 15][(lane >> 4) * 4];
+#pragma unroll
+        for (int c = 0; c < KP / 16; ++c) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                float4 a4 = *(const float4*)(arow + rt * 16 * (KP + 4) + c * 16);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int bi = (c * NTW + nt) * 4;
+                    acc[rt][nt] = mfma16(a4.x, breg[bi + 0], acc[rt][nt]);
+                    acc[rt][nt] = mfma16(a4.y, breg[bi + 1], acc[rt][nt]);
+                    acc[rt][nt] = mfma16(a4.z, breg[bi + 2], acc[rt][nt]);
+                    acc[rt][nt] = mfma16(a4.w, breg[bi + 3], acc[rt][nt]);
+                }
+            }
+        }
+        if (last_panel) {
+            typename Epi::Pref P;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                ep.call(acc[rt], P, tile * GEMM_BM + rt * 16, lane, cgrp, M);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!has_next) break;
+        ap.store(As[cur ^ 1], R, ntile * GEMM_BM, npanel * KP, grp, M);
+        __syncthreads();
+        cur ^= 1; tile = ntile; panel = npanel;
+    }
+}
+
+// groups4 = number of 4-wave column-group quadruples (the gemm_rows launch with NT = NTW would use 4*groups4 groups)
+template <int NTW, int KP, class AProd, class Epi>
+static inline void launch_gemm_rows_wn(hipStream_t st, const AProd& ap, const float* wfrag, const Epi& ep,
+                                       int M, int K, int groups4, int max_blocks_x = 2048) {
+    int ntiles = (M + GEMM_BM - 1) / GEMM_BM;
+    if (ntiles <= 0) return;
+    int gx = ntiles < max_blocks_x ? ntiles : max_blocks_x;
+    hipLaunchKernelGGL((gemm_rows_wn_kernel<NTW, KP, AProd, Epi>), dim3(gx, groups4, 1), dim3(256), 0, st, ap, wfrag, ep, M, K);
+}
+
 template <int NT, int KP, bool PERSIST_B, class AProd, class Epi>
 static inline void launch_gemm_rows(hipStream_t st, const AProd& ap, const float* wfrag, const Epi& ep,
                                     int M, int K, int groups, int max_blocks_x = 2048) {
