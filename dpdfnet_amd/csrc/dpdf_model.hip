@@ -1407,7 +1407,8 @@ extern "C" int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N,
         ProfScope ps(m, "istft");
         PlainA<48> ap{m->enh_spec.p, (size_t)2 * d.F, 0, 2 * d.F};
         WindowStore<5> ep{m->frames.p, d.win, m->C(m->window)};
-        launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups);
+        if (B * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups / 4);
+        else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups);
         OlaArgs oa{m->frames.p, m->C(m->window), d_out, B, T, N, d.win, d.hop};
         hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, m->stream, oa);
     }
@@ -1516,7 +1517,8 @@ extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_
     {
         PlainA<48> ap{s->spec_e.p, (size_t)2 * d.F, 0, 2 * d.F};
         WindowStore<5> ep{m->frames.p, d.win, m->C(m->window)};
-        launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups);
+        if (S * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups / 4);
+        else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups);
         hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, s->ola_tail.p, dst, S, T, d.hop);
     }
     HIP_TRY(hipGetLastError());
