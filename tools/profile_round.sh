@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-rX}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
 tail -1 $OUT/bench_trace.log > $OUT/bench_line_under_trace.json
