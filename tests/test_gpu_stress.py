@@ -1,0 +1,20 @@
+"""GPU (-m gpu): a short randomised self-consistency soak (tools/stress.py): random model / stream count / frame count /
+chunk length; the default execution shape (four streams, per-launch kernel selection, GRU-256 clusters of 4 or 8
+workgroups, hoisted input GEMMs, fused epilogues) against the plain single-stream unfused form of the same engine,
+plus run-to-run bit identity.  The fixed-size parity tests pin the numbers to the oracle; this one hunts ordering bugs
+between streams and cluster workgroups at sizes nobody thought of."""
+import importlib.util
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_shapes_default_pipeline_equals_plain_form():
+    spec = importlib.util.spec_from_file_location("dpdf_stress", Path(__file__).resolve().parents[1] / "tools" / "stress.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rec = mod.run(budget=10.0, seed=20260417)
+    assert not rec.get("FAIL"), rec
+    assert rec["cases"] >= 20 and rec["worst_rel_err"] < 2e-5, rec
