@@ -17,4 +17,4 @@ def test_random_shapes_default_pipeline_equals_plain_form():
     spec.loader.exec_module(mod)
     rec = mod.run(budget=10.0, seed=20260417)
     assert not rec.get("FAIL"), rec
-    assert rec["cases"] >= 20 and rec["worst_rel_err"] < 2e-5, rec
+    assert rec["cases"] >= 20 and rec["worst_rel_err"] < 5e-5, rec

@@ -39,7 +39,7 @@ def run(budget: float = 60.0, seed: int = 1) -> dict:
         err = float(np.abs(out - ref).max()) / scale
         if err > worst: worst = err; worst_case = {"sr": sr, "nb": nb, "B": B, "T": T, "err": err}
         same = np.array_equal(out, out2) and np.array_equal(s1, s2)
-        if not np.isfinite(out).all() or err > 2e-5 or not same or np.abs(s1 - sref).max() > 5e-4 * (1 + np.abs(sref).max()):
+        if not np.isfinite(out).all() or err > 5e-5 or not same or np.abs(s1 - sref).max() > 5e-4 * (1 + np.abs(sref).max()):
             rec = {"FAIL": True, "sr": sr, "nb": nb, "B": B, "T": T, "err": err, "repeatable": bool(same),
                "state_err": float(np.abs(s1 - sref).max())}
             return rec
