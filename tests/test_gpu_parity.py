@@ -225,5 +225,9 @@ def test_package_enhance_with_synthetic_weights_matches_oracle(be):
     out = dpdfnet_amd.enhance(wav, 16000, model="dpdfnet2", onnx_path="synthetic:77", attn_limit_db=9.0)
     ref = orc.Oracle(16000, 2, synth_blob(be.manifest(16000, 2), 77)).enhance(wav, 9.0)
     assert out.shape == wav.shape and rms(out - ref) < WAVE_TOL
+    # PESQ/STOI libraries are absent: the stand-in for "PESQ delta <= 0.001" is the SI-SNR of our output
+    # against the oracle's (reference pesq_stoi_sisnr_calc.py:16-27); its eps = 1e-8 caps the figure near 93 dB here
+    from dpdfnet_amd.evalkit import si_snr
+    assert si_snr(ref, out) > 85.0
     outs = dpdfnet_amd.enhance_batch([wav, wav[:5000]], 16000, model="dpdfnet2", onnx_path="synthetic:77")
     assert rms(outs[1] - orc.Oracle(16000, 2, synth_blob(be.manifest(16000, 2), 77)).enhance(wav[:5000])) < WAVE_TOL
