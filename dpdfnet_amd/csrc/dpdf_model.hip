@@ -279,7 +279,7 @@ struct dpdf_model {
     // prepared weights (arena offsets)
     size_t conv0_w, conv0_b;
     SepConvW erb_conv1, erb_conv2, erb_conv3, df_conv1, convt3, convt2, convt1;
-    size_t dfc0_w, dfc0_pwfrag, dfc0_bias;
+    size_t dfc0_pwfrag, dfc0_bias;      // df_conv0 folded to one im2col operand [32][64] + BN shift
     std::vector<DprnnW> dprnn_erb, dprnn_df;
     GlW enc_erb_fc, df_fc_emb, enc_lin_in, enc_lin_out, ed_lin_in, ed_lin_out, ed_erb_fc, df_lin_in, df_skip, df_out;
     Gru256W enc_gru, ed_gru0, ed_gru1, df_gru0, df_gru1;
@@ -825,9 +825,9 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     {
         ProfScope ps(m, "enc_convs_df");
         RowMap rm = RowMap::make(Tc, d.D);
-        Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm, m->C(m->dfc0_w)};
+        Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm};
         BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
-        launch_gemm_rows<4, 64, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 64, 1);
+        launch_gemm_rows<4, 32, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 32, 1);
         run_dwconv_s(m, m->df_conv1, c0v, c1v, B, Tc, 2);
     }
     x.c1d = x.c1.p;
@@ -1042,13 +1042,19 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
     m->erb_conv2 = build_sepconv(A, B, "enc.erb_conv2", 1);
     m->erb_conv3 = build_sepconv(A, B, "enc.erb_conv3", 1);
     {
-        std::vector<float> w(64 * 9);
+        // grouped 3x3 conv -> pointwise -> BN is linear end to end: fold it into one [K = 32][64] im2col operand,
+        // row k = kt*8 + g*4 + kf (Conv0DfA), products accumulated in double
         const float *w0 = B.get("enc.df_conv0.1.convs.0.weight"), *w1 = B.get("enc.df_conv0.1.convs.1.weight");
-        std::copy(w0, w0 + 32 * 9, w.begin()); std::copy(w1, w1 + 32 * 9, w.begin() + 32 * 9);
-        m->dfc0_w = A.add(w);
         BnFold f = fold_bn(B, "enc.df_conv0.3", 64);
-        const float* pw = B.get("enc.df_conv0.2.weight");
-        m->dfc0_pwfrag = A.add(pack_frag(64, 64, 4, [&](int k, int n) { return pw[n * 64 + k] * f.scale[n]; }));
+        const float* pw = B.get("enc.df_conv0.2.weight");           // [out 64][in 64]
+        m->dfc0_pwfrag = A.add(pack_frag(32, 64, 4, [&](int k, int n) -> float {
+            const int kt = k >> 3, g = (k >> 2) & 1, kf = k & 3;
+            if (kt > 2 || kf > 2) return 0.f;
+            const float* wg = g ? w1 : w0;                          // [32][1][3][3]
+            double acc = 0.0;
+            for (int cl = 0; cl < 32; ++cl) acc += (double)pw[n * 64 + g * 32 + cl] * (double)wg[cl * 9 + kt * 3 + kf];
+            return (float)(acc * (double)f.scale[n]);
+        }));
         m->dfc0_bias = A.add(f.shift);
     }
     m->df_conv1 = build_sepconv(A, B, "enc.df_conv1", 1);

@@ -194,63 +194,35 @@ struct SubpixA {
     }
 };
 
-// df_conv0 front half: GroupedConv2D(2 groups, 1->32 each, k(3,3)) over the last 3 frames of
-// feat_spec (reference onnx_model/layers.py:1083-1114, dpdfnet.py:94-101); K = 64.
-// Thread = one output channel (its 9 taps live in registers) x 16 rows; the 9 feature reads per
-// row are wave-uniform (broadcast) and L1-resident, so nothing is staged through registers.
+// df_conv0 (reference onnx_model/dpdfnet.py:94-101, layers.py:761-834, 1083-1114): GroupedConv2D(2 groups, 1->32 each,
+// k(3,3)) -> pointwise 64x64 -> BatchNorm -> ReLU.  Nothing non-linear sits between the grouped and the pointwise
+// conv, so the host folds the chain into ONE [18 -> 64] matrix (+ BN shift) and the kernel is an im2col GEMM with
+// K = 32: column k = kt*8 + g*4 + kf holds feat_spec[frame t-2+kt][group g][band f+kf-1] (kf = 3 and kt = 3 are zero
+// padding).  The first version computed the grouped conv on the VALU in front of a K = 64 pointwise GEMM: 860 VALU
+// instructions per wave-tile against 64 MFMAs -- and VALU cycles are MFMA cycles on this chip.  Now: ~40 and 32.
 struct Conv0DfA {
     const float* fs;       // feat_spec [B][2+Tc][2][D]
     int Tt, D; RowMap rm;  // rm.Fp = D
-    const float* w;        // [64][9]
-    using Regs = NoRegs;
-    __device__ __forceinline__ void load(Regs&, int, int, int, int) const {}
-    // lane = output channel (its 9 taps in registers), wave = 16 consecutive rows: the 3x3 window
-    // slides along f, so each new row costs 3 (wave-uniform, L1-resident) loads instead of 9.
-    __device__ __forceinline__ void store(float (*As)[64 + 4], const Regs&, int row0, int, int, int M) const {
-        const int c = threadIdx.x & 63, g = c >> 5, wv = threadIdx.x >> 6;
-        float wk[9];
+    struct Regs { float v[8]; };
+    __device__ __forceinline__ void load(Regs& R, int row0, int, int, int M) const {
+        const int r = threadIdx.x >> 2, kt = threadIdx.x & 3, row = row0 + r;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = w[c * 9 + k];
-        int row = row0 + 16 * wv;
-        int b = 0, t = 0, f = 0;
-        if (row < M) rm.split(row, b, t, f);
-        float win[3][3];           // [kt][f-1, f, f+1]
-        const float* src = fs + (((size_t)b * Tt + t) * 2 + g) * D;      // frame t-2 (+halo 2), group g
-        auto reload = [&]() {
+        for (int j = 0; j < 8; ++j) R.v[j] = 0.f;
+        if (row < M && kt < 3) {
+            int b, t, f; rm.split(row, b, t, f);
+            const float* p = fs + (((size_t)b * Tt + t + kt) * 2) * D + f;      // frame t-2+kt (+halo 2), group 0
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) {
-                const float* p = src + (size_t)kt * 2 * D;
-                win[kt][0] = f > 0 ? p[f - 1] : 0.f;
-                win[kt][1] = p[f];
-                win[kt][2] = f + 1 < D ? p[f + 1] : 0.f;
+            for (int g = 0; g < 2; ++g) {
+                if (f > 0) R.v[4 * g + 0] = p[g * D - 1];
+                R.v[4 * g + 1] = p[g * D];
+                if (f + 1 < D) R.v[4 * g + 2] = p[g * D + 1];
             }
-        };
-        if (row < M) reload();
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            float v = 0.f;
-            if (row + i < M) {
-#pragma unroll
-                for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                    for (int kf = 0; kf < 3; ++kf) v += wk[kt * 3 + kf] * win[kt][kf];
-                // advance to the next row
-                ++f;
-                if (f == D) {                       // next frame (possibly next clip)
-                    f = 0; ++t;
-                    if (t == rm.Tc) { t = 0; ++b; }
-                    src = fs + (((size_t)b * Tt + t) * 2 + g) * D;
-                    if (row + i + 1 < M) reload();
-                } else {
-#pragma unroll
-                    for (int kt = 0; kt < 3; ++kt) {
-                        win[kt][0] = win[kt][1]; win[kt][1] = win[kt][2];
-                        win[kt][2] = f + 1 < D ? src[(size_t)kt * 2 * D + f + 1] : 0.f;
-                    }
-                }
-            }
-            As[16 * wv + i][c] = v;
         }
+    }
+    __device__ __forceinline__ void store(float (*As)[32 + 4], const Regs& R, int, int, int, int) const {
+        const int r = threadIdx.x >> 2, kt = threadIdx.x & 3;
+        *(float4*)&As[r][kt * 8] = make_float4(R.v[0], R.v[1], R.v[2], R.v[3]);
+        *(float4*)&As[r][kt * 8 + 4] = make_float4(R.v[4], R.v[5], R.v[6], R.v[7]);
     }
 };
 
