@@ -317,6 +317,9 @@ def main() -> None:
                                  "tflops": round(v["tflops"], 1)} for k, v in ks.items()},
             "gru64_family_tflops": fam_flop / (fam_ms * 1e-3) / 1e12 if fam_ms else None,
             "whole_path_frac": value * FLOP_PER_FRAME / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
+            # the three GRU-64 kernels' algorithmic FLOPs over the WALL time of the timed region: a lower bound on what
+            # they achieve while sharing the chip (unlike per-launch durations it only goes up when throughput goes up)
+            "gru64_family_wallclock_frac": fam_flop / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             "per_class_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
         }
         if iso_prof is not None:
