@@ -206,8 +206,11 @@ def main() -> None:
     do_gather = world > 1 and not args.no_gather
     gather_note = "none (single GPU)" if world == 1 else ("rccl gather to rank 0" if do_gather else "disabled")
 
-    def step() -> None:
-        model.enhance_batch_device(wav.data_ptr(), B, N, out.data_ptr(), None)
+    # two output buffers: with N > 1 the RCCL gather of step i reads one while the engine writes step i+1 into the other
+    outs = [out, torch.empty_like(out)] if do_gather else [out, out]
+
+    def step(i: int = 0) -> None:
+        model.enhance_batch_device(wav.data_ptr(), B, N, outs[i & 1].data_ptr(), None)
 
     def sync() -> None:
         model.sync()
@@ -229,11 +232,11 @@ def main() -> None:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
         if do_gather:
-            model.sync()
-            gathered = gather_to_root(out, world, rank, gathered)
+            model.sync()          # host waits for this rank's step i; the gather below is asynchronous (RCCL's stream),
+            gathered = gather_to_root(outs[i & 1], world, rank, gathered)   # so it runs under the compute of step i+1
     sync()
     if world > 1:
         dist.barrier()
