@@ -163,6 +163,7 @@ def main() -> None:
     ap.add_argument("--overlap", type=int, default=-1, help="overlap bit mask (1 stage-2 stream, 2 ERB stream, 4 two lanes, 8 decoder fork, 16 8-WG GRU-256 clusters; 0 serial; -1 engine default)")
     ap.add_argument("--no-fuse", action="store_true", help="run fc+LN of the DPRNN blocks as separate kernels")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra serial profiling step")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief timings of BASELINE's other single-GPU configs")
@@ -183,10 +184,15 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()      # functional test mode: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     blob = synth_blob(backend.manifest(SR, NB), WEIGHT_SEED)
     model = backend.HipModel(SR, NB, blob, device=local_rank)
@@ -204,7 +210,7 @@ def main() -> None:
     out = torch.empty_like(wav)
     gathered = None
     do_gather = world > 1 and not args.no_gather
-    gather_note = "none (single GPU)" if world == 1 else ("rccl gather to rank 0" if do_gather else "disabled")
+    gather_note = "none (single GPU)" if world == 1 else ((("rccl" if args.backend == "nccl" else args.backend) + " gather to rank 0") if do_gather else "disabled")
 
     # two output buffers: with N > 1 the RCCL gather of step i reads one while the engine writes step i+1 into the other
     outs = [out, torch.empty_like(out)] if do_gather else [out, out]
@@ -242,7 +248,7 @@ def main() -> None:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = model.profile_report()
@@ -273,6 +279,7 @@ def main() -> None:
             "gru64_scan_kernel": GRU64_FLOP_PER_ROW_STEP * (1 if fused else 3),
             "gru64_epi_kernel<2>": GRU64_FLOP_PER_ROW_STEP + 2 * 64 * 128,
             "gru64_epi_kernel<1>": GRU64_FLOP_PER_ROW_STEP + 2 * 64 * 64,
+            "gru64_scan_gi_kernel": GRU64_FLOP_PER_ROW_STEP,      # small --clips only: hoisted input GEMM + h-part scan
         }
 
         def kernel_stats(p):
@@ -291,7 +298,9 @@ def main() -> None:
             steps_saved = args.steps; args.steps = 1
             kernel_stats_iso = kernel_stats(iso_prof)
             args.steps = steps_saved
-        dom = "gru64_epi_kernel<2>" if "gru64_epi_kernel<2>" in ks else "gru64_scan_kernel"
+        dom = next((k for k in ("gru64_epi_kernel<2>", "gru64_scan_kernel", "gru64_scan_gi_kernel") if k in ks), None)
+        if dom is None:
+            raise SystemExit("no GRU-64 kernel launches were profiled: cannot form the roofline block")
         ms, calls = ks[dom]["ms_total"], ks[dom]["launches"]
         achieved = ks[dom]["tflops"]
         fam_ms = sum(v["ms_total"] for v in ks.values())
@@ -307,7 +316,8 @@ def main() -> None:
         except Exception:
             pass
         # algorithmic bytes: x row in, (hf row in,) y row out = 256 B each per (row, step)
-        alg_bytes = {"gru64_scan_kernel": 2 * 256, "gru64_epi_kernel<2>": 3 * 256, "gru64_epi_kernel<1>": 2 * 256}[dom]
+        alg_bytes = {"gru64_scan_kernel": 2 * 256, "gru64_epi_kernel<2>": 3 * 256, "gru64_epi_kernel<1>": 2 * 256,
+                     "gru64_scan_gi_kernel": 256 + 768 + 256}[dom]
         roofline = {
             "bound": "mfma", "kernel": dom + " (all launches, DF + ERB branch)",
             "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

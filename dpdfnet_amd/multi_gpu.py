@@ -37,6 +37,14 @@ def gather_to_root(local, world_size: int, rank: int, out=None):
 
     if world_size == 1:
         return local.unsqueeze(0)
+    if local.is_cuda and dist.get_backend() == "gloo":      # gloo moves host memory only: stage through the CPU
+        got = gather_to_root(local.cpu(), world_size, rank, None)
+        if got is None:
+            return None
+        if out is None:
+            return got.to(local.device)
+        out.copy_(got)
+        return out
     # one grouped launch (ncclGroupStart/End under batch_isend_irecv): the root's world-1 receives progress
     # concurrently instead of one peer after the other
     if rank == 0:

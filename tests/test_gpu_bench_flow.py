@@ -1,0 +1,59 @@
+"""GPU (-m gpu): bench.py's contract, exercised for real: the N=1 line and -- with two ranks sharing this box's GPU over
+gloo -- the N>1 control flow (rank env, sharding, barriers, max-over-ranks timing, gather to rank 0, one JSON line from
+rank 0 only).  RCCL itself needs >= 2 GPUs and is what the driver's scaling run exercises."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _json_lines(stdout: str):
+    return [json.loads(l) for l in stdout.splitlines() if l.startswith('{"metric"')]
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, "bench.py", "--clips", "16", "--steps", "1", "--warmup", "1", "--no-other-configs",
+                        "--cpu-clip-seconds", "0.5", "--cpu-clips-per-thread", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["unit"] == "frames/s" and d["higher_is_better"] is True and d["finite_output"] is True
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and 0.0 < rf["frac"] < 1.0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_two_ranks_control_flow_over_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                        "--clips", "8", "--no-other-configs"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1                                   # rank 0 only
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite_output"] is True
+    assert "gather to rank 0" in d["config"]["sharding"] and "cpu_baseline" not in d
+    T = d["config"]["frames_per_clip"]
+    assert abs(d["value"] - 2 * 8 * T * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
