@@ -28,7 +28,7 @@ def be():
     return backend
 
 
-@pytest.mark.parametrize("nb,B,check_oracle", [(2, 256, True), (4, 256, True), (8, 256, False)])
+@pytest.mark.parametrize("nb,B,check_oracle", [(2, 256, True), (4, 256, True), (8, 256, True)])
 def test_baseline_batch_configs_full_size(be, nb, B, check_oracle):
     """configs[1] dpdfnet2 / configs[2] per-GPU shard dpdfnet4 / configs[3] dpdfnet8: 256 x 10 s."""
     from oracle import oracle as orc
@@ -48,7 +48,7 @@ def test_baseline_batch_configs_full_size(be, nb, B, check_oracle):
     assert m.num_frames(n) == 1003
     if check_oracle:
         o = orc.Oracle(sr, nb, blob)
-        for b in (0, 7):
+        for b in ((0, 7) if nb < 8 else (7,)):               # the oracle needs ~8 s per dpdfnet8 clip
             err = rms(out[b] - o.enhance(wav[b]))
             assert err < WAVE_TOL, (b, err)
     # prefix/causality on a slice of the batch
