@@ -231,3 +231,30 @@ def test_package_enhance_with_synthetic_weights_matches_oracle(be):
     assert si_snr(ref, out) > 85.0
     outs = dpdfnet_amd.enhance_batch([wav, wav[:5000]], 16000, model="dpdfnet2", onnx_path="synthetic:77")
     assert rms(outs[1] - orc.Oracle(16000, 2, synth_blob(be.manifest(16000, 2), 77)).enhance(wav[:5000])) < WAVE_TOL
+
+
+@pytest.mark.parametrize("kind", ["silence", "full_scale_square", "dc", "impulse", "tiny"])
+def test_extreme_inputs_match_the_oracle(be, kind):
+    """Inputs at the edges of the numeric range: digital silence (log of the 1e-10 floor, zero gradients in the norms),
+    a clipped square wave, DC, a single impulse, 1e-7-amplitude noise.  Fast exp/rcp, the folded exponent scales and
+    the saturating tanh must stay finite and on the oracle."""
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import synth_blob
+    sr, nb, n = 16000, 2, 16000
+    rng = np.random.default_rng(3)
+    t = np.arange(n)
+    wav = {
+        "silence": np.zeros(n, np.float32),
+        "full_scale_square": np.where((t // 40) % 2 == 0, 1.0, -1.0).astype(np.float32),
+        "dc": np.full(n, 0.5, np.float32),
+        "impulse": np.eye(1, n, 3000, dtype=np.float32)[0],
+        "tiny": (1e-7 * rng.standard_normal(n)).astype(np.float32),
+    }[kind]
+    blob = synth_blob(be.manifest(sr, nb), 4711)
+    m = be.HipModel(sr, nb, blob, 0)
+    out = m.enhance_batch(np.stack([wav, wav[::-1].copy()]), None)
+    m.close()
+    assert np.isfinite(out).all()
+    ref = orc.Oracle(sr, nb, blob).enhance(wav)
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    assert float(np.abs(out[0] - ref).max()) < 2e-5 * scale + 1e-9, (kind, float(np.abs(out[0] - ref).max()), scale)
