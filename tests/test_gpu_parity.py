@@ -258,3 +258,45 @@ def test_extreme_inputs_match_the_oracle(be, kind):
     ref = orc.Oracle(sr, nb, blob).enhance(wav)
     scale = max(float(np.abs(ref).max()), 1e-6)
     assert float(np.abs(out[0] - ref).max()) < 2e-5 * scale + 1e-9, (kind, float(np.abs(out[0] - ref).max()), scale)
+
+
+def test_models_in_concurrent_host_threads(be):
+    """The reference runs one session per host thread (cli.py:249-259).  Here: four threads, each with its own engine
+    handle (own streams, own workspace), plus all four sharing ONE handle (calls serialise on its mutex) -- every result
+    bit-identical to the single-threaded run."""
+    import threading
+    from dpdfnet_amd.weights import synth_blob
+    sr, nb = 16000, 2
+    blob = synth_blob(be.manifest(sr, nb), 99)
+    clips = [np.stack([synth_clip(8000 + 640 * i, sr, 50 + 10 * i + j) for j in range(3)]) for i in range(4)]
+    base = be.HipModel(sr, nb, blob, 0)
+    want = [base.enhance_batch(c, None) for c in clips]
+    got_own, got_shared, errs = [None] * 4, [None] * 4, []
+
+    def own(i):
+        try:
+            m = be.HipModel(sr, nb, blob, 0)
+            for _ in range(3):
+                got_own[i] = m.enhance_batch(clips[i], None)
+            m.close()
+        except Exception as exc:   # surfaced below
+            errs.append(exc)
+
+    def shared(i):
+        try:
+            for _ in range(3):
+                got_shared[i] = base.enhance_batch(clips[i], None)
+        except Exception as exc:
+            errs.append(exc)
+
+    for fn in (own, shared):
+        ths = [threading.Thread(target=fn, args=(i,)) for i in range(4)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+    base.close()
+    assert not errs, errs
+    for i in range(4):
+        np.testing.assert_array_equal(got_own[i], want[i])
+        np.testing.assert_array_equal(got_shared[i], want[i])
