@@ -642,10 +642,12 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
 // Measured (tools/sweep2.sh, tools/latency_bench.py): intra crossover at 192 tiles (3072 frame rows).  Inter: the
 // hoisted form wins below ~100 tiles when run alone (8 clips x 10 s: 8.7 -> 6.6 ms) but costs throughput inside the
 // stream pipeline of a big batch (256 clips, ERB branch, 128 tiles: 125.6 -> 128.7 ms/step), so it is used below 64.
-float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, float* xb, float* hcat, float* hin, DevBuf& gibuf, int Fp,
+// xin is read only (it stays valid for its other consumers: e3 is the decoder's skip input); the blocks ping-pong
+// between xa and xb, so no staging copy of the input is needed.
+float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, float* xa, float* xb, float* hcat, float* hin, DevBuf& gibuf, int Fp,
                  float* state, long S, int soff, int B, int Tc) {
     const int M = B * Tc * Fp;
-    float* x = xa; float* y = xb;
+    float* x = xin; float* y = xa;
     const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0;
     const bool fuse_intra = can_fuse && (m->fuse_dprnn == 2 || (long)B * Tc >= 3072);
     const bool fuse_inter = can_fuse && (m->fuse_dprnn == 2 || (long)B * Fp >= 64 * 16);
@@ -690,6 +692,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
             }
         }
         std::swap(x, y);
+        if (y == xin) y = xb;
         Gru64Args ae{};     // inter-band GRUCell over time, one hidden state per band position
         ae.x = x; ae.wfrag = m->C(w.inter.wfrag); ae.bias = m->C(w.inter.bias);
         ae.hstate = state + soff + (long)bi * Fp * 64;
@@ -722,6 +725,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xa, fl
             }
         }
         std::swap(x, y);
+        if (y == xin) y = xb;
     }
     return x;
 }
@@ -816,8 +820,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     }
     x.e3d = x.e3.p;
     if (d.nb > 0) {
-        HIP_TRY(hipMemcpyAsync(x.xe_a.p, x.e3.p, (size_t)BT * d.F3 * 64 * sizeof(float), hipMemcpyDeviceToDevice, sC));
-        x.e3d = run_dprnn(m, m->dprnn_erb, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
+        x.e3d = run_dprnn(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
     }
     // ---- encoder, DF branch (dpdfnet.py:221-234) on the main stream ----
     m->cur = sA;
@@ -832,8 +835,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     }
     x.c1d = x.c1.p;
     if (d.nb > 0) {
-        HIP_TRY(hipMemcpyAsync(x.xd_a.p, x.c1.p, (size_t)BT * d.Fd * 64 * sizeof(float), hipMemcpyDeviceToDevice, sA));
-        x.c1d = run_dprnn(m, m->dprnn_df, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
+        x.c1d = run_dprnn(m, m->dprnn_df, x.c1.p, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
     }
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_jn[c.parity], sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_jn[c.parity], 0)); }
     {
