@@ -64,14 +64,24 @@ __global__ void feat_b_kernel(FeatBArgs a) {
     const int j = threadIdx.x;
     const float al = 0.98f, be = (float)(1.0 - 0.98);
     const int Tt = a.Tc + 2;
+    // The EMA recurrences are one dependent FMA per frame; what costs time is the load in front of each one (an L2
+    // round trip, and the compiler may not move it above the previous frame's store to the same tensor).  Frames
+    // are therefore taken eight at a time: eight independent loads, then the recurrence, then eight stores.
+    constexpr int U = 8;
     if (j < a.E) {
         float mu = a.state[b * a.S + a.off_erb + j];
         float* p = a.feat_erb + ((size_t)b * Tt + 2) * a.E + j;
-#pragma unroll 4
-        for (int t = 0; t < a.Tc; ++t) {
-            float x = p[(size_t)t * a.E];
-            mu = al * mu + be * x;
-            p[(size_t)t * a.E] = (x - mu) / 40.0f;
+        for (int t0 = 0; t0 < a.Tc; t0 += U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = t0 + u < a.Tc ? p[(size_t)(t0 + u) * a.E] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + u < a.Tc) {
+                    mu = al * mu + be * x[u];
+                    p[(size_t)(t0 + u) * a.E] = (x[u] - mu) / 40.0f;
+                }
+            }
         }
         a.state[b * a.S + a.off_erb + j] = mu;
     } else if (j < a.E + a.D) {
@@ -79,14 +89,20 @@ __global__ void feat_b_kernel(FeatBArgs a) {
         float s = a.state[b * a.S + a.off_spec + f];
         const float* xp = a.xs + ((size_t)b * Tt + 2) * a.F * 2 + 2 * f;
         float* o = a.feat_spec + ((size_t)b * Tt + 2) * 2 * a.D + f;
-#pragma unroll 4
-        for (int t = 0; t < a.Tc; ++t) {
-            float2 v = *(const float2*)(xp + (size_t)t * a.F * 2);
-            float mag = sqrtf(v.x * v.x + v.y * v.y);
-            s = al * s + be * mag;
-            float den = sqrtf(s + 1e-12f);
-            o[(size_t)t * 2 * a.D] = v.x / den;
-            o[(size_t)t * 2 * a.D + a.D] = v.y / den;
+        for (int t0 = 0; t0 < a.Tc; t0 += U) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = t0 + u < a.Tc ? *(const float2*)(xp + (size_t)(t0 + u) * a.F * 2) : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + u < a.Tc) {
+                    float mag = sqrtf(v[u].x * v[u].x + v[u].y * v[u].y);
+                    s = al * s + be * mag;
+                    float den = sqrtf(s + 1e-12f);
+                    o[(size_t)(t0 + u) * 2 * a.D] = v[u].x / den;
+                    o[(size_t)(t0 + u) * 2 * a.D + a.D] = v[u].y / den;
+                }
+            }
         }
         a.state[b * a.S + a.off_spec + f] = s;
     }
