@@ -90,6 +90,94 @@ def _enhance_with_runtime(
     return fit_length(enhanced, waveform.shape[0]).astype(np.float32, copy=False)
 
 
+# ----------------------------------------------------------------------------------------------
+# batched execution: length buckets, ragged engine calls, one handle + host thread per GPU
+# ----------------------------------------------------------------------------------------------
+RAGGED_MIN_FILL = 0.8                                  # shortest clip of a bucket >= 0.8 x its longest: <= 20 % padding frames
+MAX_BATCH_SAMPLES = 64 * 1024 * 1024                   # per engine call (model-rate samples incl. padding); spectra < 1 GB
+
+
+def _length_buckets(lengths: Sequence[int], max_samples: int = MAX_BATCH_SAMPLES) -> List[List[int]]:
+    """Indices of the non-empty clips, longest first, cut into buckets whose clips are within RAGGED_MIN_FILL of the
+    bucket's longest and whose padded size stays under `max_samples`.  A directory of arbitrary lengths becomes a handful
+    of engine calls (the reference runs one file per host thread, cli.py:249-259)."""
+    order = sorted((i for i, n in enumerate(lengths) if n > 0), key=lambda i: (-lengths[i], i))
+    buckets: List[List[int]] = []
+    cur: List[int] = []
+    for i in order:
+        if cur and (lengths[i] < RAGGED_MIN_FILL * lengths[cur[0]] or (len(cur) + 1) * lengths[cur[0]] > max_samples):
+            buckets.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+def _run_bucket(session, clips: List[np.ndarray], attn: Optional[float]) -> List[np.ndarray]:
+    n0 = clips[0].shape[0]
+    if all(c.shape[0] == n0 for c in clips):
+        res = session.enhance_batch(np.stack(clips), attn)
+        return [res[j] for j in range(len(clips))]
+    return session.enhance_batch_ragged(clips, attn)
+
+
+def _runtimes_for(resolved, devices: Optional[Sequence[int]]) -> list:
+    """One runtime (engine handle) per entry of `devices`; the same GPU listed twice gets two independent handles."""
+    devs = [_device_from_env()] if not devices else [int(d) for d in devices]
+    seen: Dict[int, int] = {}
+    rts = []
+    for d in devs:
+        k = seen.get(d, 0)
+        seen[d] = k + 1
+        rts.append(build_runtime_model(resolved.onnx_path, resolved.info, d) if k == 0
+                   else build_runtime_model(resolved.onnx_path, resolved.info, d, replica=k))
+    return rts
+
+
+def _enhance_model_rate_clips(runtimes: list, model_clips: List[np.ndarray], attn: Optional[float],
+                              on_done: Optional[Callable[[int, np.ndarray], None]] = None) -> List[Optional[np.ndarray]]:
+    """Model-rate mono clips -> enhanced clips (None for empty ones).  Buckets by length; every bucket is sharded
+    contiguously over the handles (`shard_range`, the sharding bench.py uses across ranks) and each handle's share runs
+    on its own host thread (the engine call releases the GIL), so N GPUs work concurrently with no exchange between
+    them: utterances are independent."""
+    from .multi_gpu import shard_range
+    lengths = [int(c.shape[0]) for c in model_clips]
+    out: List[Optional[np.ndarray]] = [None] * len(model_clips)
+    nd = len(runtimes)
+    work: List[List[List[int]]] = [[] for _ in range(nd)]
+    for bucket in _length_buckets(lengths):
+        for k in range(nd):
+            lo, hi = shard_range(len(bucket), nd, k)
+            if hi > lo:
+                work[k].append(bucket[lo:hi])
+    errors: List[BaseException] = []
+
+    def _worker(k: int) -> None:
+        try:
+            for idxs in work[k]:
+                res = _run_bucket(runtimes[k].session, [model_clips[i] for i in idxs], attn)
+                for i, r in zip(idxs, res):
+                    out[i] = r
+                    if on_done is not None:
+                        on_done(i, r)
+        except BaseException as exc:  # surfaced on the calling thread
+            errors.append(exc)
+
+    if nd == 1:
+        _worker(0)
+    else:
+        import threading
+        ts = [threading.Thread(target=_worker, args=(k,), name=f"dpdfnet-gpu{runtimes[k].device}") for k in range(nd) if work[k]]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
 def enhance_batch(
     audio: Union[np.ndarray, Sequence[np.ndarray]],
     sample_rate: int,
@@ -98,32 +186,28 @@ def enhance_batch(
     onnx_path: Optional[Union[str, Path]] = None,
     attn_limit_db: Optional[float] = None,
     verbose: bool = False,
+    devices: Optional[Sequence[int]] = None,
 ) -> List[np.ndarray]:
-    """Enhance many mono clips in one GPU batch.  Clips may differ in length: they are grouped by
-    length (each clip's result equals `enhance()` on it alone; padding would change the reference's
-    tail handling, SURVEY appendix A.4, so equal-length groups are batched instead)."""
+    """Enhance many mono clips on the GPU(s).  Clips may differ in length: they are bucketed by length and each bucket
+    is ONE ragged engine call (`dpdf_enhance_batch_ragged`) in which every clip keeps its own tail semantics (SURVEY
+    appendix A.4), so each result equals `enhance()` on that clip alone.  `devices=[0, 1, ...]`: one engine handle and
+    host thread per listed GPU, clips sharded contiguously across them (no exchange: utterances are independent)."""
     from .audio import ensure_sample_rate, fit_length, to_mono, validate_attn_limit_db
 
     clips = [to_mono(np.asarray(a, dtype=np.float32)) for a in (audio if not isinstance(audio, np.ndarray) or audio.ndim != 2 else list(audio))]
     attn = validate_attn_limit_db(attn_limit_db)
     resolved = resolve_model(model=model, onnx_path=onnx_path, auto_download=True, verbose=verbose)
-    runtime = build_runtime_model(resolved.onnx_path, resolved.info, _device_from_env())
+    runtimes = _runtimes_for(resolved, devices)
     msr, sr_in = resolved.info.sample_rate, int(sample_rate)
     model_clips = [ensure_sample_rate(c, sr_in, msr) for c in clips]
-    out: List[Optional[np.ndarray]] = [None] * len(clips)
-    by_len: Dict[int, List[int]] = {}
-    for i, c in enumerate(model_clips):
-        by_len.setdefault(int(c.shape[0]), []).append(i)
-    for n, idxs in by_len.items():
-        if n == 0:
-            for i in idxs:
-                out[i] = clips[i].copy()
-            continue
-        res = runtime.session.enhance_batch(np.stack([model_clips[i] for i in idxs]), attn)
-        for j, i in enumerate(idxs):
-            e = ensure_sample_rate(res[j], msr, sr_in)
-            out[i] = fit_length(e, clips[i].shape[0]).astype(np.float32, copy=False)
-    return out  # type: ignore[return-value]
+    res = _enhance_model_rate_clips(runtimes, model_clips, attn)
+    out: List[np.ndarray] = []
+    for c, r in zip(clips, res):
+        if r is None:
+            out.append(c.copy())
+        else:
+            out.append(fit_length(ensure_sample_rate(r, msr, sr_in), c.shape[0]).astype(np.float32, copy=False))
+    return out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -186,10 +270,10 @@ def enhance_file(
 
 
 # directory batch (reference cli.py:222-311 `_run_enhance_dir`): the reference fans files out over a CPU thread pool,
-# one ORT session per thread; here the files are read, grouped by (input rate, length) and each group goes through
-# the GPU as ONE batched call.  Same discovery rules, output naming and error aggregation.
+# one ORT session per thread; here the files are read, brought to the model rate, bucketed by length and each bucket
+# goes through the GPU as ONE ragged call (`dpdf_enhance_batch_ragged`).  Same discovery rules, output naming and
+# error aggregation.  Files are decoded bucket-independent but results are written as soon as their bucket is done.
 SUPPORTED_EXTENSIONS = frozenset({".wav"})            # stdlib reader; soundfile (optional) widens this at run time
-MAX_BATCH_SAMPLES = 64 * 1024 * 1024                   # per engine call (model-rate samples); keeps spectra < 1 GB
 
 
 def _supported_extensions() -> frozenset:
@@ -209,6 +293,7 @@ def enhance_dir(
     attn_limit_db: Optional[float] = None,
     verbose: bool = False,
     file_callback: Optional[Callable[[Path, Path], None]] = None,
+    devices: Optional[Sequence[int]] = None,
 ) -> List[Path]:
     """Enhance every supported audio file of `input_dir` into `output_dir/<stem>_enhanced.wav`.
     Returns the written paths in the sorted order of the inputs."""
@@ -223,48 +308,45 @@ def enhance_dir(
         raise FileNotFoundError(f"No supported audio files found in {in_dir}\nSupported extensions: {', '.join(sorted(exts))}")
     attn = validate_attn_limit_db(attn_limit_db)
     resolved = resolve_model(model=model, onnx_path=onnx_path, auto_download=True, verbose=verbose)
-    runtime = build_runtime_model(resolved.onnx_path, resolved.info, _device_from_env())
+    runtimes = _runtimes_for(resolved, devices)
     msr = resolved.info.sample_rate
     out_dir.mkdir(parents=True, exist_ok=True)
 
     errors: List = []
-    clips: Dict[Path, tuple] = {}
-    groups: Dict[tuple, List[Path]] = {}
+    good: List[Path] = []
+    monos: List[np.ndarray] = []
+    rates: List[int] = []
+    model_clips: List[np.ndarray] = []
     for p in files:
         try:
             audio, sr = _read_audio(p)
             mono = to_mono(audio)
-            clips[p] = (mono, int(sr))
-            groups.setdefault((int(sr), int(mono.shape[0])), []).append(p)
+            mc = ensure_sample_rate(mono, int(sr), msr)
+            good.append(p); monos.append(mono); rates.append(int(sr)); model_clips.append(mc)
         except Exception as exc:  # one bad file must not stop the directory (cli.py:296-305)
             errors.append((p, exc))
 
     written: Dict[Path, Path] = {}
+    import threading
+    wlock = threading.Lock()
 
-    def _emit(p: Path, enhanced_model_sr: np.ndarray) -> None:
-        mono, sr = clips[p]
+    def _emit(i: int, enhanced_model_sr: np.ndarray) -> None:
+        p, mono, sr = good[i], monos[i], rates[i]
         y = fit_length(ensure_sample_rate(enhanced_model_sr, msr, sr), mono.shape[0])
         dst = out_dir / f"{p.stem}_enhanced.wav"
         _write_pcm16(dst, y, sr)
-        written[p] = dst
+        with wlock:
+            written[p] = dst
         if file_callback is not None:
             file_callback(p, dst)
 
-    for (sr, n), paths in groups.items():
-        try:
-            if n == 0:
-                for p in paths:
-                    _emit(p, clips[p][0].copy())
-                continue
-            batch = np.stack([clips[p][0] for p in paths])
-            batch = batch if sr == msr else ensure_sample_rate(batch, sr, msr)      # [B, n] in one device call
-            per_call = max(1, MAX_BATCH_SAMPLES // max(1, batch.shape[1]))
-            for lo in range(0, len(paths), per_call):
-                res = runtime.session.enhance_batch(batch[lo: lo + per_call], attn)
-                for j, p in enumerate(paths[lo: lo + per_call]):
-                    _emit(p, res[j])
-        except Exception as exc:
-            errors.extend((p, exc) for p in paths if p not in written)
+    try:
+        res = _enhance_model_rate_clips(runtimes, model_clips, attn, on_done=_emit)
+        for i, r in enumerate(res):
+            if r is None:                       # empty file: the reference returns the (empty) waveform itself
+                _emit(i, monos[i].copy())
+    except Exception as exc:
+        errors.extend((p, exc) for p in good if p not in written)
     if errors:
         msgs = "\n".join(f"  {p}: {e}" for p, e in errors)
         raise RuntimeError(f"Errors during processing:\n{msgs}")

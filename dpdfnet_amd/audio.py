@@ -9,7 +9,8 @@ from typing import Optional
 
 import numpy as np
 
-ATTN_LIMIT_NOISY_FRAME_OFFSET = 4   # reference audio.py:8 (2 frames feature look-ahead + 2 frames DF look-ahead)
+ATTN_LIMIT_NOISY_FRAME_OFFSET = 4   # reference audio.py:8 (2 frames feature look-ahead + 2 frames DF look-ahead); the blend
+                                    # itself (audio.py:50-76) runs in the GPU deep-filter kernel (csrc/misc_kernels.h df_apply_kernel)
 
 
 def to_mono(audio: np.ndarray) -> np.ndarray:
@@ -60,27 +61,6 @@ def validate_attn_limit_db(attn_limit_db: Optional[float]) -> Optional[float]:
     if np.isnan(value) or value < 0.0:
         raise ValueError("attn_limit_db must be non-negative, infinity, or None.")
     return value
-
-
-def apply_attn_limit(spec_noisy: np.ndarray, spec_enh: np.ndarray, attn_limit_db: Optional[float]) -> np.ndarray:
-    """alpha * noisy[t-4] + (1-alpha) * enh[t] on [1,T,F,2] spectra (reference audio.py:50-76).
-    Host twin of the blend fused into the GPU deep-filter kernel (used by the spectral API)."""
-    value = validate_attn_limit_db(attn_limit_db)
-    enhanced = np.asarray(spec_enh, dtype=np.float32)
-    if value is None:
-        return enhanced
-    noisy = np.asarray(spec_noisy, dtype=np.float32)
-    if noisy.shape != enhanced.shape:
-        raise ValueError(
-            "spec_noisy and spec_enh must have matching shapes, "
-            f"got {noisy.shape} and {enhanced.shape}."
-        )
-    shifted = np.zeros_like(noisy)
-    k = ATTN_LIMIT_NOISY_FRAME_OFFSET
-    if noisy.shape[1] > k:
-        shifted[:, k:] = noisy[:, :-k]
-    alpha = float(10.0 ** (-value / 20.0))
-    return np.ascontiguousarray(alpha * shifted + (1.0 - alpha) * enhanced, dtype=np.float32)
 
 
 def pcm16_safe(audio: np.ndarray) -> np.ndarray:

@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = (
     "dpdf_streams_destroy", "dpdf_streams_reset", "dpdf_streams_prime", "dpdf_streams_process",
     "dpdf_streams_get_state", "dpdf_sync", "dpdf_profile_enable", "dpdf_profile_report",
     "dpdf_set_chunk_frames", "dpdf_set_overlap", "dpdf_set_fuse_dprnn", "dpdf_debug_fetch",
-    "dpdf_resample_len", "dpdf_resample",
+    "dpdf_resample_len", "dpdf_resample", "dpdf_enhance_batch_ragged", "dpdf_debug_raise_device_error",
 )
 
 
@@ -92,6 +92,8 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_run_frames.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int]
         L.dpdf_enhance_batch.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, ctypes.c_int]
         L.dpdf_num_frames.argtypes = [vp, ctypes.c_int]
+        L.dpdf_enhance_batch_ragged.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_float, vp, ctypes.c_int]
+        L.dpdf_debug_raise_device_error.argtypes = [vp]
         L.dpdf_streams_create.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
         L.dpdf_streams_destroy.argtypes = [vp]
         L.dpdf_streams_destroy.restype = None
@@ -186,6 +188,7 @@ class HipModel:
         self.win_len = int(self._L.dpdf_win_len(h))
         self.hop = int(self._L.dpdf_hop(h))
         self.freq_bins = int(self._L.dpdf_freq_bins(h))
+        self.dims = query_dims(sample_rate, nb)
         if erb_norm_init is not None or spec_norm_init is not None:
             e = None if erb_norm_init is None else np.ascontiguousarray(erb_norm_init, dtype=np.float32)
             s = None if spec_norm_init is None else np.ascontiguousarray(spec_norm_init, dtype=np.float32)
@@ -241,6 +244,24 @@ class HipModel:
         _check(self._L.dpdf_enhance_batch(self._h, wav.ctypes.data, wav.shape[0], wav.shape[1], db, out.ctypes.data, DPDF_HOST_PTRS))
         return out
 
+    def enhance_batch_ragged(self, clips, attn_limit_db: Optional[float] = None) -> List[np.ndarray]:
+        """Clips of different lengths (1-D float32 at the model rate) in ONE engine call (`dpdf_enhance_batch_ragged`);
+        each result equals `enhance_batch` on that clip alone."""
+        clips = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in clips]
+        if not clips:
+            return []
+        lens = np.array([c.shape[0] for c in clips], dtype=np.int32)
+        n_max = int(lens.max())
+        wav = np.zeros((len(clips), n_max), dtype=np.float32)
+        for i, c in enumerate(clips):
+            wav[i, : c.shape[0]] = c
+        out = np.empty_like(wav)
+        db = float("nan") if attn_limit_db is None else float(attn_limit_db)
+        if n_max:
+            _check(self._L.dpdf_enhance_batch_ragged(self._h, wav.ctypes.data, len(clips), n_max,
+                                                     lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), db, out.ctypes.data, DPDF_HOST_PTRS))
+        return [out[i, : int(lens[i])].copy() for i in range(len(clips))]
+
     def enhance_batch_device(self, wav_ptr: int, B: int, N: int, out_ptr: int, attn_limit_db: Optional[float] = None) -> None:
         """Device-pointer form (HBM-resident input/output; asynchronous on the model's stream)."""
         db = float("nan") if attn_limit_db is None else float(attn_limit_db)
@@ -251,6 +272,10 @@ class HipModel:
 
     def sync(self) -> None:
         _check(self._L.dpdf_sync(self._h))
+
+    def debug_raise_device_error(self) -> None:
+        """Test hook: make the next synchronisation point report the device-side failure path."""
+        _check(self._L.dpdf_debug_raise_device_error(self._h))
 
     def set_chunk_frames(self, frames: int) -> None:
         _check(self._L.dpdf_set_chunk_frames(self._h, int(frames)))

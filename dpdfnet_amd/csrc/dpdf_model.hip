@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/dpdfnet_hip.h"
+#include "../../include/dpdf_norm_init.h"
 #include "common.h"
 #include "gemm_rows.h"
 #include "gru_scan.h"
@@ -275,6 +276,7 @@ struct dpdf_model {
     float* d_init_state = nullptr;     // [S]
     int chunk_frames = 0;
     int* d_err = nullptr;
+    int* d_lens = nullptr; size_t d_lens_cap = 0; std::vector<int> h_lens;   // per-clip lengths of a ragged batch
     int use_gru256_cluster = 1;
     // prepared weights (arena offsets)
     size_t conv0_w, conv0_b;
@@ -303,6 +305,20 @@ struct dpdf_streams {
     DevBuf state, in_tail, ola_tail, spec, spec_e, pcm_in, pcm_out;
     std::vector<int> primed;
 };
+
+// The GRU-256 cluster scans exchange h' between workgroups by spinning on granules (gru_scan.h).  A spin that times out
+// (peer workgroups never became co-resident: GPU shared with other processes, oversubscribed queues) raises the device
+// flag d_err and the scan carries on with stale data -- so every point where results become visible to the caller
+// reads the flag back and turns it into DPDF_E_RUNTIME instead of returning corrupted audio with DPDF_OK.
+static int check_device_err(dpdf_model* m) {
+    if (!m->d_err) return DPDF_OK;
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (!flag) return DPDF_OK;
+    HIP_TRY(hipMemset(m->d_err, 0, sizeof(int)));
+    return set_err(DPDF_E_RUNTIME, "GRU-256 cluster exchange timed out (peer workgroups were not co-resident); the results of "
+                                   "this call are invalid -- retry, or run the engine on a GPU it does not share");
+}
 
 namespace {
 
@@ -621,6 +637,12 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
             }
             Gru256CArgs a{gi, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc, L.gru_xbuf[which], L.gru_epoch[which], m->d_err};
             L.gru_epoch[which] += (unsigned)Tc;
+            // Forward progress of the cluster scans (peers spin on each other's granules under an ordinary, non-cooperative
+            // launch) rests on ONE assumption: workgroups are dispatched in blockIdx order.  The block -> (tile, slice)
+            // maps of both kernels put all workgroups of a tile inside one aligned run of 32 (resp. 64) consecutive
+            // blocks, so the resident set always contains whole clusters, these finish, and later blocks get their CUs
+            // (2048 clips = 512 workgroups on 256 CUs is covered by tests/test_gpu_fullsize.py).  If the assumption ever
+            // fails the spin times out, d_err is raised and the call returns DPDF_E_RUNTIME (check_device_err).
             // eight workgroups per tile: measured better up to 64 clips, worse from 128 (tools/sweep2.sh)
             if ((m->overlap & 16) && ntiles <= 4) hipLaunchKernelGGL(gru256_cluster8_kernel, dim3(ntiles * 8), dim3(256), 0, m->cur, a);
             else hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->cur, a);
@@ -1192,14 +1214,10 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
         HIP_TRY(hipMalloc((void**)&m->iconsts, ic.size() * sizeof(int)));
         HIP_TRY(hipMemcpy(m->iconsts, ic.data(), ic.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    // ErbNorm / SpecNorm initial states (reference onnx_model/layers.py:455-463, 516-522)
+    // ErbNorm / SpecNorm (16 kHz: linspace) and MagNorm48 / SpecNorm48 (48 kHz: empirical tables) initial states
+    // (reference onnx_model/layers.py:455-463, 516-522, 575-730; onnx_model/init_norms.py:21-139)
     m->erb_norm_init.resize(d.E); m->spec_norm_init.resize(d.D);
-    {
-        float step = (float)((-90.0 - (-60.0)) / (d.E - 1));
-        for (int i = 0; i < d.E; ++i) m->erb_norm_init[i] = -60.0f + (float)i * step;
-        float step2 = (float)((0.0001 - 0.001) / (d.D - 1));
-        for (int i = 0; i < d.D; ++i) m->spec_norm_init[i] = 0.001f + (float)i * step2;
-    }
+    dpdf_default_norm_init(&d, m->erb_norm_init.data(), m->spec_norm_init.data());
     HIP_TRY(hipMalloc((void**)&m->d_init_state, (size_t)d.state_size * sizeof(float)));
     {
         std::vector<float> st(d.state_size, 0.f);
@@ -1207,6 +1225,8 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
         std::copy(m->spec_norm_init.begin(), m->spec_norm_init.end(), st.begin() + m->L.spec_norm);
         HIP_TRY(hipMemcpy(m->d_init_state, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    HIP_TRY(hipMalloc((void**)&m->d_err, sizeof(int)));
+    HIP_TRY(hipMemset(m->d_err, 0, sizeof(int)));
     *out = m;
     return DPDF_OK;
 }
@@ -1228,6 +1248,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     if (m->consts) (void)hipFree(m->consts);
     if (m->iconsts) (void)hipFree(m->iconsts);
     if (m->d_err) (void)hipFree(m->d_err);
+    if (m->d_lens) (void)hipFree(m->d_lens);
     if (m->d_init_state) (void)hipFree(m->d_init_state);
     for (hipEvent_t e : m->prof_events) if (e) (void)hipEventDestroy(e);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -1298,6 +1319,15 @@ extern "C" int dpdf_sync(dpdf_model* m) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    return check_device_err(m);      // device-pointer calls surface a failed GRU-256 exchange here
+}
+extern "C" int dpdf_debug_raise_device_error(dpdf_model* m) {
+    if (!m) return set_err(DPDF_E_INVALID, "null model");
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->d_err) HIP_TRY(hipMalloc((void**)&m->d_err, sizeof(int)));
+    const int one = 1;
+    HIP_TRY(hipMemcpy(m->d_err, &one, sizeof(int), hipMemcpyHostToDevice));
     return DPDF_OK;
 }
 extern "C" int dpdf_profile_enable(dpdf_model* m, int on) {
@@ -1356,6 +1386,7 @@ extern "C" int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, f
         HIP_TRY(hipMemcpyAsync(spec_e, d_out, nspec * sizeof(float), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipMemcpyAsync(state, d_state, nstate * sizeof(float), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
+        return check_device_err(m);
     }
     return DPDF_OK;
 }
@@ -1364,15 +1395,30 @@ extern "C" int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, f
 // offline batch path: enhance() for B clips
 // ------------------------------------------------------------------------------------------------
 
-extern "C" int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N, float attn_limit_db, float* out, int flags) {
+// lengths: nullptr = every clip is N samples; else host array [B] of per-clip sample counts (<= N, the row stride)
+static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int* lengths, float attn_limit_db, float* out, int flags) {
     if (!m || !wav || !out) return set_err(DPDF_E_INVALID, "null argument");
     if (B <= 0 || N < 0) return set_err(DPDF_E_INVALID, "bad batch geometry B=%d N=%d", B, N);
     if (attn_limit_db < 0.f) return set_err(DPDF_E_INVALID, "attn_limit_db must be non-negative, infinity, or None.");
+    if (lengths)
+        for (int b = 0; b < B; ++b)
+            if (lengths[b] < 0 || lengths[b] > N) return set_err(DPDF_E_INVALID, "lengths[%d] = %d outside [0, %d]", b, lengths[b], N);
     if (N == 0) return DPDF_OK;
     std::lock_guard<std::mutex> lk(m->mu);
     HIP_TRY(hipSetDevice(m->device));
     const dpdf_dims& d = m->d;
     const int T = 1 + (N + d.win) / d.hop;
+    const int* d_lens = nullptr;
+    if (lengths) {
+        if ((size_t)B > m->d_lens_cap) {
+            if (m->d_lens) { HIP_TRY(hipStreamSynchronize(m->stream)); (void)hipFree(m->d_lens); m->d_lens = nullptr; m->d_lens_cap = 0; }
+            HIP_TRY(hipMalloc((void**)&m->d_lens, (size_t)B * sizeof(int)));
+            m->d_lens_cap = (size_t)B;
+        }
+        m->h_lens.assign(lengths, lengths + B);      // staging copy that outlives the async upload
+        HIP_TRY(hipMemcpyAsync(m->d_lens, m->h_lens.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        d_lens = m->d_lens;
+    }
     const bool host = !(flags & DPDF_DEVICE_PTRS);
     const size_t nw = (size_t)B * N, nspec = (size_t)B * T * d.F * 2;
     int rc;
@@ -1387,7 +1433,7 @@ extern "C" int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N,
     // A1: analysis STFT
     {
         ProfScope ps(m, "stft");
-        StftA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window)};
+        StftA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window), 0, d_lens};
         if (B * T <= SMALL_M_ROWS) {
             BiasActStore<2> ep{m->raw_spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
             ep.ncol_total = 2 * d.F;
@@ -1417,15 +1463,25 @@ extern "C" int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N,
         WindowStore<5> ep{m->frames.p, d.win, m->C(m->window)};
         if (B * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups / 4);
         else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups);
-        OlaArgs oa{m->frames.p, m->C(m->window), d_out, B, T, N, d.win, d.hop};
+        OlaArgs oa{m->frames.p, m->C(m->window), d_out, B, T, N, d.win, d.hop, d_lens};
         hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, m->stream, oa);
     }
     HIP_TRY(hipGetLastError());
     if (host) {
         HIP_TRY(hipMemcpyAsync(out, d_out, nw * sizeof(float), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
+        return check_device_err(m);
     }
     return DPDF_OK;
+}
+
+extern "C" int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N, float attn_limit_db, float* out, int flags) {
+    return enhance_impl(m, wav, B, N, nullptr, attn_limit_db, out, flags);
+}
+extern "C" int dpdf_enhance_batch_ragged(dpdf_model* m, const float* wav, int B, int n_max, const int* lengths,
+                                         float attn_limit_db, float* out, int flags) {
+    if (!lengths) return set_err(DPDF_E_INVALID, "null lengths");
+    return enhance_impl(m, wav, B, n_max, lengths, attn_limit_db, out, flags);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1533,6 +1589,7 @@ extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_
     if (host) {
         HIP_TRY(hipMemcpyAsync(pcm_out, dst, npcm * sizeof(float), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
+        return check_device_err(m);
     }
     return DPDF_OK;
 }

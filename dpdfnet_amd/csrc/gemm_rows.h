@@ -260,10 +260,11 @@ template <int KP>
 struct StftA {
     const float* wav; int N; int T; int win, hop; const float* window;
     int causal = 0;        // 1: frame t = x[t*hop : t*hop+win] (StreamEnhancer), no centre/reflect padding
+    const int* lens = nullptr;   // ragged batch: clip b holds lens[b] <= N valid samples (row stride stays N); its own tail pad,
+                                 // reflection point and frame count T_b = 1 + (lens[b] + win) / hop; frames t >= T_b are zero
     static constexpr int NI = GEMM_BM * KP / 256;
     struct Regs { float v[NI]; };
     __device__ __forceinline__ void load(Regs& R, int row0, int kp, int, int M) const {
-        const int np_ = N + win;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             int idx = threadIdx.x + i * 256;
@@ -272,6 +273,8 @@ struct StftA {
             float v = 0.f;
             if (row < M) {
                 int b = row / T, t = row - b * T;
+                const int nb_ = lens ? lens[b] : N;
+                const int np_ = nb_ + win;
                 int kk = kp + k;
                 int j = t * hop + kk;
                 if (!causal) {
@@ -279,7 +282,8 @@ struct StftA {
                     if (j < 0) j = -j;
                     if (j >= np_) j = 2 * (np_ - 1) - j;
                 }
-                if (j < N && kk < win) v = wav[(size_t)b * N + j] * window[kk];
+                const bool live = !lens || t < 1 + np_ / hop;
+                if (live && j >= 0 && j < nb_ && kk < win) v = wav[(size_t)b * N + j] * window[kk];
             }
             R.v[i] = v;
         }

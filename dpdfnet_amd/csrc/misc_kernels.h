@@ -269,15 +269,19 @@ struct OlaArgs {
     const float* window;
     float* out;            // [B][N]
     int B, T, N, win, hop;
+    const int* lens;       // ragged batch (else nullptr): clip b is lens[b] samples / T_b = 1 + (lens[b] + win) / hop frames long;
+                           // its own 2*win shift, zero tail and fit_length; out[b][lens[b]:N] = 0
 };
 __global__ void ola_kernel(OlaArgs a) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)a.B * a.N) return;
     const int b = (int)(idx / a.N), i = (int)(idx - (size_t)b * a.N);
-    const long ylen = (long)a.hop * (a.T - 1);
+    const int nb = a.lens ? a.lens[b] : a.N;
+    const int Tb = a.lens ? 1 + (nb + a.win) / a.hop : a.T;
+    const long ylen = (long)a.hop * (Tb - 1);
     const long src = (long)i + 2L * a.win;
     float v = 0.f;
-    if (src < ylen) {
+    if (i < nb && src < ylen) {
         const long p = src + a.win / 2;
         const int t1 = (int)(p / a.hop);
         const int t0 = t1 - 1;
@@ -286,7 +290,7 @@ __global__ void ola_kernel(OlaArgs a) {
             int k = (int)(p - (long)t0 * a.hop);
             if (k < a.win) { y += a.frames[((size_t)b * a.T + t0) * a.win + k]; wss += a.window[k] * a.window[k]; }
         }
-        if (t1 < a.T) {
+        if (t1 < Tb) {
             int k = (int)(p - (long)t1 * a.hop);
             y += a.frames[((size_t)b * a.T + t1) * a.win + k]; wss += a.window[k] * a.window[k];
         }

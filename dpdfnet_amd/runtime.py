@@ -24,16 +24,17 @@ class RuntimeModel:
     device: int = 0
 
 
-_cache: Dict[Tuple[str, int], RuntimeModel] = {}
+_cache: Dict[Tuple[str, int, int], RuntimeModel] = {}
 _cache_lock = threading.Lock()
 
 
-def build_runtime_model(weights_path: Union[str, Path], info: ModelInfo, device: int = 0) -> RuntimeModel:
+def build_runtime_model(weights_path: Union[str, Path], info: ModelInfo, device: int = 0, replica: int = 0) -> RuntimeModel:
     """Load weights (file or "synthetic:<seed>"), create the HIP model on `device`.  Cached per
-    (weights, device): unlike an ORT session the handle is immutable and thread-safe."""
+    (weights, device, replica): unlike an ORT session the handle is immutable and thread-safe; `replica` > 0 asks
+    for a further independent handle on the same GPU (own streams and workspace)."""
     from . import backend, weights
 
-    key = (str(weights_path), int(device))
+    key = (str(weights_path), int(device), int(replica))
     with _cache_lock:
         hit = _cache.get(key)
         if hit is not None and hit.info.name == info.name:

@@ -210,13 +210,22 @@ def load_weight_file(path: Union[str, Path], entries: List[ManifestEntry]) -> Tu
                 extras[k] = np.asarray(sd.pop(k), dtype=np.float32)
         return pack_state_dict(entries, sd), extras
     if suffix in (".pth", ".pt", ".ckpt"):
+        import os
         import torch
         try:
             sd = torch.load(str(p), map_location="cpu", weights_only=True)
-        except Exception:
+        except Exception as exc:
+            # The safe loader refuses anything but plain tensors/containers.  Full unpickling executes code from the
+            # file, so it is never a silent fallback: explicit opt-in only.
+            if os.environ.get("DPDFNET_ALLOW_UNSAFE_PICKLE") != "1":
+                raise ValueError(
+                    f"{p}: not a plain tensor state_dict (torch.load(weights_only=True) refused it: {exc}). Re-save it as "
+                    "a state_dict / .safetensors, or set DPDFNET_ALLOW_UNSAFE_PICKLE=1 if you trust the file.") from exc
             sd = torch.load(str(p), map_location="cpu", weights_only=False)
-        if isinstance(sd, dict) and "state_dict" in sd:
+        if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
             sd = sd["state_dict"]
+        if not isinstance(sd, dict):
+            raise ValueError(f"{p}: expected a state_dict mapping, got {type(sd).__name__}")
         return pack_state_dict(entries, sd), extras
     raise ValueError(f"Unsupported weight file format {suffix!r}: {p}")
 

@@ -52,8 +52,9 @@ int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_floats, int 
 void dpdf_destroy(dpdf_model* m);
 
 /* Replaces load_initial_state_from_metadata (onnx_backend.py:52-78).  The two norm init
- * vectors default to the reference's linspace initialisation; a weight file may carry the
- * exported `erb_norm_init` / `spec_norm_init` metadata instead (48 kHz empirical tables). */
+ * vectors default to the reference's own initial states (include/dpdf_norm_init.h: 16 kHz linspace, 48 kHz empirical
+ * tables of onnx_model/init_norms.py); this call overrides them, e.g. from `erb_norm_init` / `spec_norm_init`
+ * metadata carried by a weight file. */
 int dpdf_set_norm_init(dpdf_model* m, const float* erb_norm_init, int n_erb, const float* spec_norm_init, int n_spec);
 int dpdf_state_size(const dpdf_model* m);                  /* S of the reference flat state */
 int dpdf_initial_state(const dpdf_model* m, float* state); /* host pointer, S floats         */
@@ -76,6 +77,14 @@ int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, float* state
  * fit to N.  wav/out: [B,N].  attn_limit_db: NaN or +inf = off (reference None/inf). */
 int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N, float attn_limit_db, float* out, int flags);
 int dpdf_num_frames(const dpdf_model* m, int n_samples);   /* T = 1 + (N + win)/hop */
+/* The same for clips of DIFFERENT lengths in one call -- what a directory of files is (reference cli.py:222-311 runs
+ * enhance_file per file on a thread pool; api.py:172-280).  wav/out: [B, n_max] rows; clip b holds lengths[b] <= n_max
+ * samples (lengths: HOST array, also with DPDF_DEVICE_PTRS).  Every clip gets exactly the result of dpdf_enhance_batch
+ * on it alone: its own win-sample tail pad and reflection point, its own T_b frames, its own 2*win shift / zero tail /
+ * fit_length; out[b][lengths[b]:] = 0.  The frame function runs max_b T_b frames for every
+ * clip (causal: padding frames cannot reach earlier outputs), so callers bucket by length to bound the waste. */
+int dpdf_enhance_batch_ragged(dpdf_model* m, const float* wav, int B, int n_max, const int* lengths,
+                              float attn_limit_db, float* out, int flags);
 
 /* Device-resident streaming (StreamEnhancer.process hot loop, stream.py:116-156, for S
  * concurrent streams): state, analysis tail and overlap-add tail live in HBM.
@@ -90,8 +99,12 @@ int dpdf_streams_prime(dpdf_streams* s, const float* pcm_in, int flags);        
 int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, int flags);
 int dpdf_streams_get_state(dpdf_streams* s, int stream, float* state_host);          /* S floats */
 
-/* timing hooks for bench.py: HIP events on the model's own stream. */
+/* Wait for the model's stream.  Calls with DPDF_DEVICE_PTRS return as soon as the work is queued: dpdf_sync is where
+ * their completion -- and a device-side failure (DPDF_E_RUNTIME: a GRU-256 cluster exchange that timed out) -- is
+ * observed.  Host-pointer calls synchronise and check before returning. */
 int dpdf_sync(dpdf_model* m);
+/* Test hook: raise the device error flag so that the next synchronisation point reports DPDF_E_RUNTIME (and clears it). */
+int dpdf_debug_raise_device_error(dpdf_model* m);
 /* Enable per-kernel-class timing (HIP events around each launch class on the model stream);
  * dpdf_profile_report writes "name total_ms calls" lines.  Off by default. */
 int dpdf_profile_enable(dpdf_model* m, int on);

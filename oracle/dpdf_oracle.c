@@ -10,6 +10,7 @@
  * layout header include/dpdf_manifest.h.
  */
 #include "dpdf_oracle.h"
+#include "../include/dpdf_norm_init.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -226,14 +227,10 @@ dpdf_oracle* dpdf_oracle_create(const dpdf_cfg* cfg, const float* weights, size_
         o->dft_cos[j] = cos(2.0 * M_PI * j / d.win);
         o->dft_sin[j] = sin(2.0 * M_PI * j / d.win);
     }
-    /* ErbNorm / SpecNorm heuristic initial states (onnx_model/layers.py:455-463, 516-522):
-       torch computes init0 + arange(n) * step in float32. */
-    {
-        float step = (float)((-90.0 - (-60.0)) / (d.E - 1));
-        for (int i = 0; i < d.E; ++i) o->erb_norm_init[i] = -60.0f + (float)i * step;
-        float step2 = (float)((0.0001 - 0.001) / (d.D - 1));
-        for (int i = 0; i < d.D; ++i) o->spec_norm_init[i] = 0.001f + (float)i * step2;
-    }
+    /* Initial norm states: 16 kHz ErbNorm / SpecNorm linspace (onnx_model/layers.py:455-463, 516-522; torch computes
+       init0 + arange(n) * step in float32), 48 kHz MagNorm48 / SpecNorm48 empirical tables (onnx_model/init_norms.py:21-139
+       via layers.py:575-730) -- shared constant header include/dpdf_norm_init.h. */
+    dpdf_default_norm_init(&d, o->erb_norm_init, o->spec_norm_init);
 
     o->erb_conv0_w = W(o, "enc.erb_conv0.1.weight"); o->erb_conv0_bn = get_bn(o, "enc.erb_conv0.2");
     o->erb_conv1 = get_sepconv(o, "enc.erb_conv1", 1);

@@ -26,7 +26,7 @@ def build(force: bool = False) -> Path:
     src = _HERE / "dpdf_oracle.c"
     hdr = _HERE.parent / "include" / "dpdf_manifest.h"
     stale = (not _LIB_PATH.exists()) or any(
-        f.stat().st_mtime > _LIB_PATH.stat().st_mtime for f in (src, hdr, _HERE / "dpdf_oracle.h")
+        f.stat().st_mtime > _LIB_PATH.stat().st_mtime for f in (src, hdr, hdr.with_name("dpdf_norm_init.h"), _HERE / "dpdf_oracle.h")
     )
     if force or stale:
         subprocess.run(["make", "-C", str(_HERE), "-B", "libdpdf_oracle.so"], check=True,

@@ -22,6 +22,7 @@ from pathlib import Path
 
 import numpy as np
 
+sys.dont_write_bytecode = True          # importing the reference must not drop __pycache__ into its (read-only) checkout
 REPO = Path(__file__).resolve().parents[2]
 REF = Path("/root/reference")
 OUT = Path(__file__).resolve().parent
@@ -281,6 +282,95 @@ def make_stream_fixture(model, sr: int, tag: str):
     print(f"[golden] stream_{tag}.npz", {k: v.shape for k, v in out.items() if not k.endswith('nflush')})
 
 
+def make_checkpoint_keys_fixture():
+    """N1: the checkpoint key names a user's HF `checkpoints/*.pth` carries.  Instantiates the reference's OFFLINE twins
+    (model/dpdfnet.py, model/dpdfnet_48khz_hr.py), records every state_dict key with its shape, and the streaming-module key the
+    reference's own `correct_state_dict` maps it to (onnx_model/dpdfnet.py:876-888, onnx_model/dpdfnet_48khz_hr.py:948-963; None
+    = dropped, i.e. `mask.erb_inv_fb` at 48 kHz).  Also proves the naming both ways: our synthetic weights, renamed to the
+    offline names through that mapping, load into the offline twin with strict=True.  Data only: names and shapes."""
+    import contextlib, importlib.util, io
+    import torch
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import parse_manifest_text, synth_blob, unpack_to_streaming_state_dict
+    from onnx_model.dpdfnet import correct_state_dict as fix16, DPDFNet as S16
+    from onnx_model.dpdfnet_48khz_hr import correct_state_dict as fix48, DPDFNet48HR as S48
+
+    sys.path.insert(0, str(REF / "model"))      # the twins use bare `import multiframe`, `from modules import ...`
+    def load(fname, modname):
+        spec = importlib.util.spec_from_file_location(modname, REF / "model" / fname)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    out = {}
+    for tag, sr, fname, cls, fix, Stream in (("16k", 16000, "dpdfnet.py", "DPDFNet", fix16, S16),
+                                              ("48k", 48000, "dpdfnet_48khz_hr.py", "DPDFNet48HR", fix48, S48)):
+        mod = load(fname, f"ref_offline_{tag}")
+        nb = 1
+        with contextlib.redirect_stdout(io.StringIO()):
+            off = getattr(mod, cls)(dprnn_num_blocks=nb).eval()
+            stream = Stream(dprnn_num_blocks=nb).eval()
+        sd = off.state_dict()
+        # map each offline key individually through the reference's renaming
+        mapping = {}
+        for k, v in sd.items():
+            r = fix({k: v})
+            mapping[k] = next(iter(r.keys())) if r else None
+        # our synthetic weights under the offline names -> strict load into the offline twin
+        entries = parse_manifest_text(orc.manifest_text(sr, nb))
+        ssd = unpack_to_streaming_state_dict(entries, synth_blob(entries, SEED + 900))
+        renamed = {}
+        for k, v in sd.items():
+            sk = mapping[k]
+            renamed[k] = torch.from_numpy(ssd[sk]).reshape(v.shape) if sk in ssd else v
+        off.load_state_dict(renamed, strict=True)
+        # and the reference's own conversion of that offline checkpoint loads into the streaming module
+        missing, unexpected = stream.load_state_dict(fix(renamed), strict=False)
+        assert not unexpected, unexpected
+        covered = [k for k in sd if mapping[k] in ssd]
+        out[tag] = dict(sample_rate=sr, nb=nb,
+                        keys=[[k, list(v.shape), mapping[k], bool(mapping[k] in ssd)] for k, v in sd.items()])
+        print(f"[golden] checkpoint keys {tag}: {len(sd)} offline keys, {len(covered)} carried into the blob, "
+              f"{sum(1 for k in sd if mapping[k] is None)} dropped by correct_state_dict")
+    sys.path.remove(str(REF / "model"))
+    (OUT / "checkpoint_keys.json").write_text(json.dumps(out, indent=0))
+
+
+def make_eval_fixture():
+    """N4: known answers of the reference's SI-SNR and cross-correlation alignment (pesq_stoi_sisnr_calc.py:16-27, 101-146)."""
+    for name in ("pystoi", "pystoi.stoi", "pesq", "pandas"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+    sys.modules["pystoi.stoi"].stoi = getattr(sys.modules["pystoi.stoi"], "stoi", None)
+    sys.modules["pesq"].pesq = getattr(sys.modules["pesq"], "pesq", None)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_eval_calc", REF / "pesq_stoi_sisnr_calc.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(SEED + 31)
+    clean = synth_clip(6000, 16000, SEED + 32)
+    noisy = (clean + 0.03 * rng.standard_normal(6000)).astype(np.float32)
+    scaled = (0.37 * clean + 0.01).astype(np.float32)
+    out = dict(clean=clean, noisy=noisy, scaled=scaled,
+               sisnr_noisy=np.float64(mod.si_snr(clean, noisy)), sisnr_rev=np.float64(mod.si_snr(noisy, clean)),
+               sisnr_scaled=np.float64(mod.si_snr(clean, scaled)), sisnr_self=np.float64(mod.si_snr(clean, clean)))
+    for i, (shift, n_b) in enumerate(((37, 6000), (-113, 5200), (0, 6000), (250, 4000))):
+        b = np.zeros(n_b, dtype=np.float32)
+        src = noisy
+        if shift >= 0:
+            m = min(n_b - shift, len(src)); b[shift:shift + m] = src[:m]
+        else:
+            m = min(n_b, len(src) + shift); b[:m] = src[-shift:-shift + m]
+        a_al, b_al, lag = mod.align_by_xcorr_trim(clean, b)
+        out[f"xc{i}_b"] = b; out[f"xc{i}_a_al"] = a_al; out[f"xc{i}_b_al"] = b_al; out[f"xc{i}_lag"] = np.int32(lag)
+        a_al, b_al, lag = mod.align_by_xcorr_trim(b, clean)
+        out[f"xc{i}_rev_lag"] = np.int32(lag); out[f"xc{i}_rev_len"] = np.int32(len(a_al))
+    np.savez_compressed(OUT / "evalkit.npz", **out)
+    print("[golden] evalkit.npz", {k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items() if k.startswith(("sisnr", "xc0"))})
+
+
 def main():
     assert REF.is_dir(), "reference checkout not mounted; goldens can only be regenerated in the build container"
     _stub_modules()
@@ -292,13 +382,19 @@ def main():
 
     make_constants_fixture()
     make_host_dsp_fixture()
+    make_eval_fixture()
     make_model_fixture("16k_nb0", 16000, 0, 0.6, SEED + 100)
     make_model_fixture("16k_nb1", 16000, 1, 1.0, SEED + 101)
     m2, _, _ = make_model_fixture("16k_nb2", 16000, 2, 1.0, SEED + 102)
     make_stream_fixture(m2, 16000, "16k_nb2")
     make_model_fixture("16k_nb4", 16000, 4, 2.0, SEED + 104)
+    make_model_fixture("16k_nb8", 16000, 8, 0.7, SEED + 108)        # BASELINE config 4 (deep DPRNN stack)
     m48, _, _ = make_model_fixture("48k_nb1", 48000, 1, 0.6, SEED + 148)
     make_stream_fixture(m48, 48000, "48k_nb1")
+    make_model_fixture("48k_nb2", 48000, 2, 0.6, SEED + 150)        # dpdfnet2_48khz_hr
+    m488, _, _ = make_model_fixture("48k_nb8", 48000, 8, 0.6, SEED + 152)   # dpdfnet8_48khz_hr (BASELINE config 5)
+    make_stream_fixture(m488, 48000, "48k_nb8")
+    make_checkpoint_keys_fixture()
 
 
 if __name__ == "__main__":

@@ -36,19 +36,23 @@ def test_baseline_batch_configs_full_size(be, nb, B, check_oracle):
     m, blob = _model(be, sr, nb)
     m.set_chunk_frames(128)
     base = [synth_clip(n, sr, 9000 + i) for i in range(6)]
-    idx = np.arange(B) % 6
-    idx[200] = idx[3]                                   # slots 3 and 200 hold the same clip
-    wav = np.stack([base[i] for i in idx])
+    # every slot holds a DIFFERENT signal (6 clips x a slot-dependent gain and circular shift), so a slot-dependent bug
+    # shows up in the oracle spot checks below, not only in the bit-identity asserts
+    gain = 0.4 + 0.6 * ((np.arange(B) * 37) % 101) / 100.0
+    wav = np.stack([np.roll(base[b % 6], 131 * b) * gain[b] for b in range(B)]).astype(np.float32)
+    wav[200] = wav[3]                                   # slots 3 and 200 hold the same clip
+    wav[6] = wav[0]
     wav[7, 40000:] = 0.0                                # a clip that goes silent
     out = m.enhance_batch(wav, None)
     assert out.shape == wav.shape and np.isfinite(out).all()
     np.testing.assert_array_equal(out[3], out[200])
     np.testing.assert_array_equal(out[0], out[6])
+    assert rms(out[1] - out[7]) > 1e-3                  # different slots really carry different results
     assert np.all(out[:, -m.win_len:] == 0.0)
     assert m.num_frames(n) == 1003
     if check_oracle:
         o = orc.Oracle(sr, nb, blob)
-        for b in ((0, 7) if nb < 8 else (7,)):               # the oracle needs ~8 s per dpdfnet8 clip
+        for b in ((7, 131, 255) if nb < 8 else (7, 255)):    # the oracle needs ~8 s per dpdfnet8 clip
             err = rms(out[b] - o.enhance(wav[b]))
             assert err < WAVE_TOL, (b, err)
     # prefix/causality on a slice of the batch
@@ -64,23 +68,24 @@ def test_baseline_batch_configs_full_size(be, nb, B, check_oracle):
 
 
 def test_whole_config3_batch_on_one_gpu(be):
-    """configs[2] unsharded: all 2048 clips x 10 s (2.05 M frames) through ONE engine call -- what a single 288 GB
-    GPU is sized for; guards the 64-bit indexing of spectra / frame buffers (B*T*win = 657 M floats) and the
-    auto chunking at large B (16-frame chunks)."""
+    """configs[2] (dpdfnet4, 2048 clips x 10 s = 2.05 M frames) UNSHARDED through ONE engine call -- what a single
+    288 GB GPU is sized for; guards the 64-bit indexing of spectra / frame buffers (B*T*win = 657 M floats), the auto
+    chunking at large B (16-frame chunks) and the 512-workgroup GRU-256 cluster launches on 256 CUs."""
     from oracle import oracle as orc
-    sr, n, nb, B = 16000, 160000, 2, 2048
+    sr, n, nb, B = 16000, 160000, 4, 2048
     m, blob = _model(be, sr, nb)
     base = [synth_clip(n, sr, 9100 + i) for i in range(4)]
     wav = np.empty((B, n), np.float32)
     for b in range(B):
-        wav[b] = base[b % 4]
+        wav[b] = base[b % 4] * np.float32(0.5 + 0.5 * ((b * 29) % 64) / 63.0)
+    wav[2044] = wav[0]; wav[1025] = wav[1]
     wav[B - 1, :] = base[1][::-1]                        # the very last slot holds something unique
     out = m.enhance_batch(wav, None)
     assert out.shape == wav.shape and np.isfinite(out).all()
     np.testing.assert_array_equal(out[0], out[2044])
     np.testing.assert_array_equal(out[1], out[1025])
     o = orc.Oracle(sr, nb, blob)
-    for b in (2, B - 1):
+    for b in (1337, B - 1):
         err = rms(out[b] - o.enhance(wav[b]))
         assert err < WAVE_TOL, (b, err)
     m.close()

@@ -24,8 +24,7 @@ def be():
 def case(request, be):
     g, meta = load_golden(request.param)
     blob = golden_blob(meta)
-    e, s = norm_inits(meta["sample_rate"])
-    m = be.HipModel(meta["sample_rate"], meta["nb"], blob, 0, e, s)
+    m = be.HipModel(meta["sample_rate"], meta["nb"], blob, 0)      # engine-default initial state, nothing injected
     yield g, meta, make_oracle(meta, blob), m
     m.close()
 
@@ -34,6 +33,10 @@ def test_initial_state_and_geometry(case):
     g, meta, o, m = case
     assert m.state_size == meta["state_size"] == o.state_size
     np.testing.assert_array_equal(m.initial_state(), g["init_state"])
+    e, s = norm_inits(meta["sample_rate"])      # the reference's tables (constants.npz) with no extras passed in
+    np.testing.assert_array_equal(m.initial_state()[:e.size], e)
+    np.testing.assert_array_equal(m.initial_state()[e.size:e.size + s.size], s)
+    np.testing.assert_array_equal(o.initial_state(), g["init_state"])
     assert (m.win_len, m.hop, m.freq_bins) == (o.win_len, o.hop, o.freq_bins)
     assert m.num_frames(meta["n"]) == meta["T"]
 
@@ -82,6 +85,9 @@ def test_stage_tensors_match_reference_probes(case, be):
         fe = m.debug_fetch("feat_erb").reshape(T + 2, d.E)[2 + t]
         # log-domain feature of near-silent bins amplifies the (oracle-double vs torch-fp32) STFT rounding
         assert np.abs(fe - g[f"f{t}_feat_erb"]).max() < 5e-5
+        fs = m.debug_fetch("feat_spec").reshape(T + 2, 2, d.D)[2 + t]          # engine [re|im][D]; reference [D][re,im]
+        ref_fs = g[f"f{t}_feat_spec_ri"].reshape(d.D, 2).T
+        assert np.abs(fs - ref_fs).max() < STAGE_REL_TOL * max(1.0, float(np.abs(ref_fs).max())), (t, "feat_spec")
     assert checked >= 10
 
 
@@ -190,15 +196,14 @@ def test_error_behaviour(case):
 
 
 # ----- StreamEnhancer on the device-resident streaming path ------------------------------------
-@pytest.mark.parametrize("tag", ["16k_nb2", "48k_nb1"])
+@pytest.mark.parametrize("tag", ["16k_nb2", "48k_nb1", "48k_nb8"])
 def test_stream_enhancer_matches_reference_stream_goldens(tag, be, tmp_path, monkeypatch):
     """Reference StreamEnhancer driven by the real frame function (stream_*.npz 'real_*')."""
     from dpdfnet_amd import stream, weights
     from dpdfnet_amd.models import ModelInfo, ResolvedModel
     g, meta = load_golden(tag)
     sr = meta["sample_rate"]
-    e, s = norm_inits(sr)
-    wfile = weights.save_blob(tmp_path / "w.npz", golden_blob(meta), erb_norm_init=e, spec_norm_init=s)
+    wfile = weights.save_blob(tmp_path / "w.npz", golden_blob(meta))
     info = ModelInfo(name=f"test_{tag}", sample_rate=sr, frame_ms=20.0, description="", onnx_filename="w.onnx",
                      dprnn_num_blocks=meta["nb"])
     monkeypatch.setattr(stream, "resolve_model", lambda **_k: ResolvedModel(info=info, onnx_path=wfile))

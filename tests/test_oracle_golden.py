@@ -87,6 +87,9 @@ def test_constants_match_reference():
             np.testing.assert_array_equal(st[32:128], C["spec_norm_init_16k"])
         else:
             np.testing.assert_allclose(o.window(), C["window_960"], atol=1e-7)
+            st = o.initial_state()      # default = the empirical 48 kHz tables (onnx_model/init_norms.py:21-139)
+            np.testing.assert_array_equal(st[:481], C["erb_norm_init_48k"])
+            np.testing.assert_array_equal(st[481:577], C["spec_norm_init_48k"])
 
 
 def test_oracle_attn_limit_known_answers():

@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
 GOLDEN = ROOT / "tests" / "golden"
-MODEL_TAGS = ["16k_nb0", "16k_nb1", "16k_nb2", "16k_nb4", "48k_nb1"]
+MODEL_TAGS = ["16k_nb0", "16k_nb1", "16k_nb2", "16k_nb4", "16k_nb8", "48k_nb1", "48k_nb2", "48k_nb8"]
 
 
 def rms(x) -> float:
@@ -31,6 +31,7 @@ def load_golden(tag: str):
 
 
 def norm_inits(sr: int):
+    """The reference's initial norm states as captured in constants.npz (to ASSERT against, not to inject)."""
     C = np.load(GOLDEN / "constants.npz")
     k = "16k" if sr == 16000 else "48k"
     return C[f"erb_norm_init_{k}"], C[f"spec_norm_init_{k}"]
@@ -43,9 +44,9 @@ def golden_blob(meta) -> np.ndarray:
 
 
 def make_oracle(meta, blob):
+    """The oracle on its OWN default initial state (no tables injected): include/dpdf_norm_init.h is what is tested."""
     from oracle import oracle as orc
-    e, s = norm_inits(meta["sample_rate"])
-    return orc.Oracle(meta["sample_rate"], meta["nb"], blob, e, s)
+    return orc.Oracle(meta["sample_rate"], meta["nb"], blob)
 
 
 # ----- numpy passthrough doubles for the engine (host-logic tests without a GPU) ---------------
@@ -96,6 +97,7 @@ class PassthroughSession:
         self.freq_bins = win // 2 + 1
         self.state_size = 1
         self.calls = []
+        self.ragged_calls = []
 
     def initial_state(self):
         return np.zeros(1, dtype=np.float32)
@@ -103,9 +105,15 @@ class PassthroughSession:
     def open_streams(self, n: int):
         return PassthroughStreams(self.win_len, n, self.zero)
 
-    def enhance_batch(self, wav, attn_limit_db=None):
+    def enhance_batch_ragged(self, clips, attn_limit_db=None):
+        """One engine call for clips of different lengths; each clip is processed with its own tail semantics."""
+        self.ragged_calls.append([int(len(c)) for c in clips])
+        return [self.enhance_batch(np.asarray(c, np.float32)[None], attn_limit_db, _record=False)[0] for c in clips]
+
+    def enhance_batch(self, wav, attn_limit_db=None, _record=True):
         wav = np.asarray(wav, dtype=np.float32)
-        self.calls.append((wav.shape, attn_limit_db))
+        if _record:
+            self.calls.append((wav.shape, attn_limit_db))
         win, hop, w = self.win_len, self.hop, _window(self.win_len)
         out = np.zeros_like(wav)
         for b in range(wav.shape[0]):
