@@ -11,8 +11,9 @@ configuration: dpdfnet4 @ 16 kHz, 256 clips x 10 s per GPU (configs[2] is 2048 c
 launches this file under torch.distributed.run and the enhanced PCM of every rank is gathered to
 rank 0 over RCCL inside the timed region (the only collective on the path).
 
-Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, measured
-with HIP events on the engine's own stream during the timed steps) and `cpu_baseline` (the CPU
+Rank 0 prints ONE JSON line with the contract fields plus `value_incl_pcie` (the same steps including
+the H2D / D2H of the PCM), `roofline` (dominant kernel, measured with HIP events on the
+engine's own streams in a pass of the same steps right after the timed region) and `cpu_baseline` (the CPU
 oracle -- a port of the reference's frame-at-a-time execution model -- timed on the host cores on
 a bounded sample; the reference's own CPU runtime, onnxruntime + downloaded .onnx files, is not
 available offline).
@@ -167,6 +168,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra serial profiling step")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief timings of BASELINE's other single-GPU configs")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the H2D/D2H-inclusive pass (value_incl_pcie)")
+    ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the per-kernel HIP-event pass after the timed region (-1 = --steps, 0 = none)")
     ap.add_argument("--cpu-clip-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-clips-per-thread", type=int, default=5)
     args = ap.parse_args()
@@ -186,13 +189,28 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     if args.backend != "nccl":
         local_rank %= torch.cuda.device_count()      # functional test mode: ranks may share a GPU
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs are visible: one rank per GPU")
     torch.cuda.set_device(local_rank)
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.backend)
+        # pre-flight: the process group really has N ranks and (under RCCL) every rank sits on its own GPU
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+        props = torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "device": torch.cuda.current_device(), "uuid": str(getattr(props, "uuid", "")), "name": props.name}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        rccl_ranks = sorted(everyone, key=lambda r: r["rank"])
+        if args.backend == "nccl":
+            devs = [(r["device"], r["uuid"]) for r in rccl_ranks]
+            if len(set(devs)) != world:
+                raise SystemExit(f"ranks share a GPU under RCCL: {rccl_ranks}")
 
     blob = synth_blob(backend.manifest(SR, NB), WEIGHT_SEED)
     model = backend.HipModel(SR, NB, blob, device=local_rank)
@@ -211,11 +229,18 @@ def main() -> None:
     gathered = None
     do_gather = world > 1 and not args.no_gather
     gather_note = "none (single GPU)" if world == 1 else ((("rccl" if args.backend == "nccl" else args.backend) + " gather to rank 0") if do_gather else "disabled")
+    collective_error = None
 
     # two output buffers: with N > 1 the RCCL gather of step i reads one while the engine writes step i+1 into the other
     outs = [out, torch.empty_like(out)] if do_gather else [out, out]
+    # The gather runs on RCCL's stream, the engine on its own private stream: nothing orders them but the host.  An event
+    # recorded behind gather i is waited for (on the host; it is a whole step old by then) before step i+2 reuses its buffer.
+    gather_done = [None, None]
 
     def step(i: int = 0) -> None:
+        if gather_done[i & 1] is not None:
+            gather_done[i & 1].synchronize()
+            gather_done[i & 1] = None
         model.enhance_batch_device(wav.data_ptr(), B, N, outs[i & 1].data_ptr(), None)
 
     def sync() -> None:
@@ -229,30 +254,66 @@ def main() -> None:
         try:
             gathered = gather_to_root(out, world, rank)
             torch.cuda.synchronize()
-        except Exception as exc:  # keep the compute number even if the collective is unavailable
+        except Exception as exc:
+            # LOUD: the line still carries the compute figure (so a scaling run is not lost), but says so in two places
             do_gather = False
-            gather_note = f"failed, excluded: {type(exc).__name__}: {exc}"
+            collective_error = f"{type(exc).__name__}: {exc}"
+            gather_note = f"FAILED, excluded from the timed region: {collective_error}"
+            print(f"[bench.py] rank {rank}: the gather over {args.backend} FAILED ({collective_error}); timing compute only",
+                  file=sys.stderr, flush=True)
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(do_gather))
+        do_gather = all(flags)                            # every rank takes the same path
 
-    model.profile(True)
+    # ---- the timed region: EXACTLY --steps steps, per-kernel profiling OFF ----
     if world > 1:
         dist.barrier()
     sync()
+    gather_ms = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
         if do_gather:
             model.sync()          # host waits for this rank's step i; the gather below is asynchronous (RCCL's stream),
+            tg = time.perf_counter()
             gathered = gather_to_root(outs[i & 1], world, rank, gathered)   # so it runs under the compute of step i+1
+            ev = torch.cuda.Event(); ev.record(); gather_done[i & 1] = ev
+            gather_ms += 1e3 * (time.perf_counter() - tg)
     sync()
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    per_rank_ms = [1e3 * dt_local / args.steps]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    prof = model.profile_report()
-    model.profile(False)
+        allms = [None] * world
+        dist.all_gather_object(allms, {"rank": rank, "ms_per_step": 1e3 * dt_local / args.steps, "gather_host_ms_per_step": gather_ms / args.steps})
+        per_rank_ms = sorted(allms, key=lambda r: r["rank"])
+    gather_check = None
+    if do_gather:      # validate the gathered PCM once, outside the timed region: rank r's rows must be rank r's own output
+        mine = torch.stack([outs[(args.steps - 1) & 1].double().sum(), outs[(args.steps - 1) & 1].double().abs().sum()]).cpu()
+        sums = [None] * world
+        dist.all_gather_object(sums, mine.tolist())
+        if rank == 0:
+            got = [[float(gathered[r].double().sum()), float(gathered[r].double().abs().sum())] for r in range(world)]
+            gather_check = all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for g_, s_ in zip(got, sums) for a, b in zip(g_, s_))
+            if not gather_check:
+                print(f"[bench.py] gathered PCM does not match the ranks' outputs: {got} vs {sums}", file=sys.stderr, flush=True)
+
+    # ---- per-kernel pass: the same pipelined steps again with HIP events around every launch class ----
+    psteps = args.steps if args.profile_steps < 0 else args.profile_steps
+    prof, prof_ms = {}, None
+    if psteps > 0:
+        model.profile(True)
+        sync(); tp = time.perf_counter()
+        for i in range(psteps):
+            step(i)
+        sync(); prof_ms = 1e3 * (time.perf_counter() - tp) / psteps
+        prof = model.profile_report()
+        model.profile(False)
     fused = not args.no_fuse
     # one extra serial step (not timed into `value`) to time the kernels without co-running streams
     iso_prof, iso_ms, kernel_stats_iso = None, None, None
@@ -263,6 +324,51 @@ def main() -> None:
         iso_prof = model.profile_report()
         model.profile(False)
         model.set_overlap(args.overlap if args.overlap >= 0 else 27)
+
+    # ---- SURVEY 8(d)'s full metric: the same steps INCLUDING H2D of the noisy PCM and D2H of the enhanced PCM ----
+    # pinned host buffers, double-buffered device buffers; the upload of step i+1 and the download of step i-1 run on
+    # their own streams under the compute of step i.
+    pcie = None
+    if world == 1 and not args.no_pcie:
+        h_in = torch.from_numpy(wav_host).pin_memory()
+        h_out = [torch.empty((B, N), dtype=torch.float32).pin_memory() for _ in range(2)]
+        d_in = [torch.empty_like(wav), torch.empty_like(wav)]
+        d_out = [torch.empty_like(wav), torch.empty_like(wav)]
+        s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+        up = [None, None]; down = [None, None]
+
+        def upload(i: int) -> None:
+            with torch.cuda.stream(s_in):
+                d_in[i & 1].copy_(h_in, non_blocking=True)
+                e = torch.cuda.Event(); e.record(s_in); up[i & 1] = e
+
+        def run_pcie(nsteps: int) -> float:
+            sync(); t_ = time.perf_counter()
+            upload(0)
+            for i in range(nsteps):
+                up[i & 1].synchronize()                          # PCM of step i is in HBM
+                if down[i & 1] is not None:
+                    down[i & 1].synchronize()                    # download of step i-2 has left this output buffer
+                model.enhance_batch_device(d_in[i & 1].data_ptr(), B, N, d_out[i & 1].data_ptr(), None)
+                if i + 1 < nsteps:
+                    upload(i + 1)                                # under the compute of step i
+                model.sync()
+                with torch.cuda.stream(s_out):
+                    h_out[i & 1].copy_(d_out[i & 1], non_blocking=True)   # under the compute of step i+1
+                    e = torch.cuda.Event(); e.record(s_out); down[i & 1] = e
+            for e in down:
+                if e is not None:
+                    e.synchronize()
+            return time.perf_counter() - t_
+
+        run_pcie(1)
+        dtp = run_pcie(args.steps)
+        pcie = {"value_incl_pcie": B * T * args.steps / dtp, "ms_per_step_incl_pcie": 1e3 * dtp / args.steps,
+                "note": "host PCM (pinned) -> HBM -> enhance -> HBM -> host PCM (pinned), every step; copies double-buffered on "
+                        "their own streams under the compute of the neighbouring steps; includes the un-overlapped first upload "
+                        "and last download",
+                "bytes_per_step_each_way": int(B * N * 4),
+                "finite_output": bool(np.isfinite(h_out[(args.steps - 1) & 1].numpy()).all())}
 
     if rank == 0:
         finite = bool(torch.isfinite(out).all().item())
@@ -282,72 +388,17 @@ def main() -> None:
             "gru64_scan_gi_kernel": GRU64_FLOP_PER_ROW_STEP,      # small --clips only: hoisted input GEMM + h-part scan
         }
 
-        def kernel_stats(p):
-            out = {}
+        def kernel_stats(p, nsteps):
+            out_ = {}
             for kname, flop_rs in fam.items():
                 sel = {k: v for k, v in p.items() if k.split("/")[0] == kname}
                 ms_ = sum(v[0] for v in sel.values()); n_ = sum(v[1] for v in sel.values())
                 if n_:
-                    fl = flop_rs * rs * args.steps
-                    out[kname] = {"ms_total": ms_, "launches": n_, "avg_launch_ms": ms_ / n_,
-                                  "flop_per_launch": fl / n_, "tflops": fl / (ms_ * 1e-3) / 1e12}
-            return out
+                    fl = flop_rs * rs * nsteps
+                    out_[kname] = {"ms_total": ms_, "launches": n_, "avg_launch_ms": ms_ / n_,
+                                   "flop_per_launch": fl / n_, "tflops": fl / (ms_ * 1e-3) / 1e12}
+            return out_
 
-        ks = kernel_stats(prof)
-        if iso_prof is not None:
-            steps_saved = args.steps; args.steps = 1
-            kernel_stats_iso = kernel_stats(iso_prof)
-            args.steps = steps_saved
-        dom = next((k for k in ("gru64_epi_kernel<2>", "gru64_scan_kernel", "gru64_scan_gi_kernel") if k in ks), None)
-        if dom is None:
-            raise SystemExit("no GRU-64 kernel launches were profiled: cannot form the roofline block")
-        ms, calls = ks[dom]["ms_total"], ks[dom]["launches"]
-        achieved = ks[dom]["tflops"]
-        fam_ms = sum(v["ms_total"] for v in ks.values())
-        fam_flop = sum(v["flop_per_launch"] * v["launches"] for v in ks.values())
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-        # separate --pmc runs of this same command, gfx950 x2 read correction applied; profiles/README.md)
-        traffic, traffic_note = None, "no PMC summary in profiles/ for this kernel"
-        try:
-            pmc_all = json.loads((ROOT / "profiles" / "pmc_summary.json").read_text())
-            pmc = next(v for k, v in pmc_all.items() if k.replace("void ", "") == dom)
-            traffic = pmc["hbm_bytes_per_dispatch_corrected"]
-            traffic_note = "bytes/launch, profiles/pmc_summary.json (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-        except Exception:
-            pass
-        # algorithmic bytes: x row in, (hf row in,) y row out = 256 B each per (row, step)
-        alg_bytes = {"gru64_scan_kernel": 2 * 256, "gru64_epi_kernel<2>": 3 * 256, "gru64_epi_kernel<1>": 2 * 256,
-                     "gru64_scan_gi_kernel": 256 + 768 + 256}[dom]
-        roofline = {
-            "bound": "mfma", "kernel": dom + " (all launches, DF + ERB branch)",
-            "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-            "algorithmic_bytes_per_launch": alg_bytes * rs * args.steps / calls,
-            "avg_launch_ms": ms / calls, "launches": calls, "flop_per_launch": ks[dom]["flop_per_launch"],
-            "timing": "HIP events on the launching stream inside the timed region; launches overlap with the other "
-                      "streams of the pipeline there (see roofline_isolated for the same kernels run back to back)",
-            "gru64_family": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "launches": v["launches"],
-                                 "tflops": round(v["tflops"], 1)} for k, v in ks.items()},
-            "gru64_family_tflops": fam_flop / (fam_ms * 1e-3) / 1e12 if fam_ms else None,
-            "whole_path_frac": value * FLOP_PER_FRAME / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
-            # the three GRU-64 kernels' algorithmic FLOPs over the WALL time of the timed region: a lower bound on what
-            # they achieve while sharing the chip (unlike per-launch durations it only goes up when throughput goes up)
-            "gru64_family_wallclock_frac": fam_flop / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-            "per_class_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in sorted(prof.items())},
-        }
-        if iso_prof is not None:
-            ki = kernel_stats_iso
-            roofline["frac_isolated"] = round(ki[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if dom in ki else None
-            roofline["frac_note"] = ("`frac` divides by the launch duration seen INSIDE the 4-stream pipeline, where the kernel "
-                                     "shares the CUs with three other streams (faster pipeline => longer individual launches); "
-                                     "`frac_isolated` is the same kernel, same launches, run back to back in the extra serial "
-                                     "step; `whole_path_frac` is frames/s x FLOP/frame over the fp32 MFMA peak")
-            roofline["roofline_isolated"] = {
-                "note": "one extra step AFTER the timed region with the stream pipeline switched off (kernels back to back)",
-                "ms_per_step": iso_ms,
-                "kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "tflops": round(v["tflops"], 1),
-                                "frac": round(v["tflops"] / FP32_MFMA_PEAK_TFLOPS, 3)} for k, v in ki.items()},
-            }
         line = {
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
@@ -357,8 +408,79 @@ def main() -> None:
                        "clips_per_gpu": B, "frames_per_clip": T, "chunk_frames": args.chunk,
                        "sharding": f"utterances, contiguous blocks per rank; collective: {gather_note}"},
             "finite_output": finite,
-            "roofline": roofline,
         }
+        if pcie is not None:
+            line.update({"value_incl_pcie": pcie["value_incl_pcie"], "ms_per_step_incl_pcie": pcie["ms_per_step_incl_pcie"]})
+            line["pcie"] = pcie
+        if world > 1:
+            line["multi_gpu"] = {"backend": "rccl" if args.backend == "nccl" else args.backend, "rccl_ranks": rccl_ranks,
+                                 "per_rank": per_rank_ms, "collective_ok": bool(do_gather) if not args.no_gather else None,
+                                 "collective_error": collective_error, "gathered_matches_rank_outputs": gather_check,
+                                 "gathered_shape": list(gathered.shape) if gathered is not None else None}
+        ks = kernel_stats(prof, psteps) if prof else {}
+        dom = next((k for k in ("gru64_epi_kernel<2>", "gru64_scan_kernel", "gru64_scan_gi_kernel") if k in ks), None)
+        if dom is not None:
+            if iso_prof is not None:
+                kernel_stats_iso = kernel_stats(iso_prof, 1)
+            ms, calls = ks[dom]["ms_total"], ks[dom]["launches"]
+            achieved = ks[dom]["tflops"]
+            fam_ms = sum(v["ms_total"] for v in ks.values())
+            fam_flop = sum(v["flop_per_launch"] * v["launches"] for v in ks.values())
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+            # separate --pmc runs of this same command, gfx950 x2 read correction applied; profiles/README.md)
+            traffic, traffic_note = None, "no PMC summary in profiles/ for this kernel"
+            try:
+                pmc_all = json.loads((ROOT / "profiles" / "pmc_summary.json").read_text())
+                pmc = next(v for k, v in pmc_all.items() if k.replace("void ", "") == dom)
+                traffic = pmc["hbm_bytes_per_dispatch_corrected"]
+                traffic_note = "bytes/launch, profiles/pmc_summary.json (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            except Exception:
+                pass
+            # algorithmic bytes: x row in, (hf row in,) y row out = 256 B each per (row, step)
+            alg_bytes = {"gru64_scan_kernel": 2 * 256, "gru64_epi_kernel<2>": 3 * 256, "gru64_epi_kernel<1>": 2 * 256,
+                         "gru64_scan_gi_kernel": 256 + 768 + 256}[dom]
+            serial_mode = args.overlap == 0
+            roofline = {
+                "bound": "mfma", "kernel": dom + " (all launches, DF + ERB branch)",
+                "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                "algorithmic_bytes_per_launch": alg_bytes * rs * psteps / calls,
+                "avg_launch_ms": ms / calls, "launches": calls, "flop_per_launch": ks[dom]["flop_per_launch"],
+                "timing": f"HIP events on the launching stream around every launch of {psteps} steps run right after the timed "
+                          "region in the same execution shape (the timed region itself runs with these events off: "
+                          f"{1e3 * dt / args.steps:.2f} ms/step timed vs {prof_ms:.2f} ms/step with events)",
+                "reproduce": ("profiles/r2_serial_kernel_stats.csv" if serial_mode else "profiles/r2_pipelined_kernel_stats.csv")
+                             + ": rocprofv3 --kernel-trace --stats of `python bench.py --no-isolated --no-other-configs --no-cpu-baseline "
+                               "--no-pcie" + (" --overlap 0`" if serial_mode else "`") + " -- every launch of that run has this execution "
+                               "shape, so the CSV's AverageNs for the kernel is this avg_launch_ms (profiles/README.md)",
+                "gru64_family": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "launches": v["launches"],
+                                     "tflops": round(v["tflops"], 1)} for k, v in ks.items()},
+                "gru64_family_tflops": fam_flop / (fam_ms * 1e-3) / 1e12 if fam_ms else None,
+                "whole_path_frac": value * FLOP_PER_FRAME / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
+                # the three GRU-64 kernels' algorithmic FLOPs over the WALL time of a step: a lower bound on what
+                # they achieve while sharing the chip (unlike per-launch durations it only goes up when throughput goes up)
+                "gru64_family_wallclock_frac": fam_flop / psteps / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                "per_class_ms_per_step": {k: round(v[0] / psteps, 3) for k, v in sorted(prof.items())},
+            }
+            if kernel_stats_iso is not None:
+                ki = kernel_stats_iso
+                roofline["frac_isolated"] = round(ki[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if dom in ki else None
+                roofline["frac_note"] = ("`frac` divides by the launch duration seen INSIDE the 4-stream pipeline, where the kernel "
+                                         "shares the CUs with three other streams (faster pipeline => longer individual launches); "
+                                         "`frac_isolated` is the same kernel, same launches, run back to back in the extra serial "
+                                         "step (= profiles/r2_serial_kernel_stats.csv, the --overlap 0 run); `whole_path_frac` is "
+                                         "frames/s x FLOP/frame over the fp32 MFMA peak")
+                roofline["roofline_isolated"] = {
+                    "note": "one extra step AFTER the timed region with the stream pipeline switched off (kernels back to back)",
+                    "ms_per_step": iso_ms,
+                    "kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "tflops": round(v["tflops"], 1),
+                                    "frac": round(v["tflops"] / FP32_MFMA_PEAK_TFLOPS, 3)} for k, v in ki.items()},
+                    "per_class_ms_per_step": {k: round(v[0], 3) for k, v in sorted(iso_prof.items())},
+                }
+            line["roofline"] = roofline
+        else:
+            line["roofline"] = None
+            print("[bench.py] no GRU-64 kernel launches were profiled (--profile-steps 0?): the roofline block is empty", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blob, args.cpu_clip_seconds, args.cpu_clips_per_thread)
         if world == 1 and not args.no_other_configs and not args.no_isolated:

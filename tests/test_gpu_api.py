@@ -38,6 +38,7 @@ def test_ragged_batch_equals_each_clip_alone(tag, be):
     o = make_oracle(meta, blob)
     lens = [len(g["wav"]), 7 * hop, 7 * hop + 1, 9 * hop - 1, 2 * hop + 33, hop // 3, 1, 0, 23 * hop + 5, 7 * hop]
     clips = [g["wav"]] + [synth_clip(n, sr, 300 + i) for i, n in enumerate(lens[1:])]
+    clips[9] = clips[1].copy()                                           # the same clip in two slots
     for attn in (None, 12.0):
         outs = m.enhance_batch_ragged(clips, attn)
         assert [len(x) for x in outs] == lens

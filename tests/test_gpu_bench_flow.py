@@ -40,8 +40,11 @@ def test_single_gpu_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "mfma" and 0.0 < rf["frac"] < 1.0
+    assert "profiles/r2_pipelined_kernel_stats.csv" in rf["reproduce"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    # the H2D/D2H-inclusive figure rides on the same line and can only be slower than the HBM-resident one
+    assert 0 < d["value_incl_pcie"] <= d["value"] * 1.05 and d["pcie"]["finite_output"] is True
 
 
 def test_two_ranks_control_flow_over_gloo():
@@ -57,3 +60,8 @@ def test_two_ranks_control_flow_over_gloo():
     assert "gather to rank 0" in d["config"]["sharding"] and "cpu_baseline" not in d
     T = d["config"]["frames_per_clip"]
     assert abs(d["value"] - 2 * 8 * T * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
+    mg = d["multi_gpu"]                                      # the pre-flight block the 8-GPU run reports
+    assert [r["rank"] for r in mg["rccl_ranks"]] == [0, 1] and len(mg["per_rank"]) == 2
+    assert mg["collective_ok"] is True and mg["collective_error"] is None and mg["gathered_matches_rank_outputs"] is True
+    assert mg["gathered_shape"][:2] == [2, 8]
+    assert max(r["ms_per_step"] for r in mg["per_rank"]) <= d["ms_per_step"] * 1.001
