@@ -170,6 +170,7 @@ def main() -> None:
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief timings of BASELINE's other single-GPU configs")
     ap.add_argument("--no-pcie", action="store_true", help="skip the H2D/D2H-inclusive pass (value_incl_pcie)")
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the per-kernel HIP-event pass after the timed region (-1 = --steps, 0 = none)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="engine A/B switch (dpdf_set_option), repeatable")
     ap.add_argument("--cpu-clip-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-clips-per-thread", type=int, default=5)
     args = ap.parse_args()
@@ -220,6 +221,9 @@ def main() -> None:
         model.set_overlap(args.overlap)
     if args.no_fuse:
         model.set_fuse_dprnn(False)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        model.set_option(k, int(v))
     B, N = args.clips, int(CLIP_SECONDS * SR)
     T = model.num_frames(N)
     lo, hi = shard_range(B * world, world, rank)          # contiguous block of clips per rank

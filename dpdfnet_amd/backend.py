@@ -48,6 +48,7 @@ EXPORTED_SYMBOLS = (
     "dpdf_streams_get_state", "dpdf_sync", "dpdf_profile_enable", "dpdf_profile_report",
     "dpdf_set_chunk_frames", "dpdf_set_overlap", "dpdf_set_fuse_dprnn", "dpdf_debug_fetch",
     "dpdf_resample_len", "dpdf_resample", "dpdf_enhance_batch_ragged", "dpdf_debug_raise_device_error",
+    "dpdf_set_option",
 )
 
 
@@ -94,6 +95,7 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_num_frames.argtypes = [vp, ctypes.c_int]
         L.dpdf_enhance_batch_ragged.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_float, vp, ctypes.c_int]
         L.dpdf_debug_raise_device_error.argtypes = [vp]
+        L.dpdf_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
         L.dpdf_streams_create.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
         L.dpdf_streams_destroy.argtypes = [vp]
         L.dpdf_streams_destroy.restype = None
@@ -288,6 +290,10 @@ class HipModel:
         kernels; "auto" (engine default): fused only when the chunk fills the chip."""
         code = {"never": 0, "auto": 1, "always": 2, False: 0, True: 2}[mode]
         _check(self._L.dpdf_set_fuse_dprnn(self._h, code))
+
+    def set_option(self, name: str, value: int) -> None:
+        """Named A/B switch (`dpdf_set_option`): "fuse_mask", "hoist_gi", "gru256_cluster"."""
+        _check(self._L.dpdf_set_option(self._h, name.encode(), int(value)))
 
     def debug_fetch(self, name: str) -> np.ndarray:
         n = self._L.dpdf_debug_fetch(self._h, name.encode(), None, 0)

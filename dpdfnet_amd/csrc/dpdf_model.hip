@@ -266,6 +266,7 @@ struct dpdf_model {
     // 0 = everything serial on the main stream (A/B timing).
     int overlap = 27;
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
+    int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
     bool two_lanes_active = false;
@@ -771,6 +772,14 @@ void run_subpix(dpdf_model* m, const SepConvW& w, const PathW& p, TView e, TView
     BiasReluToView ep{out, rm, m->C(w.bias)};
     launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.pwfrag), ep, B * Tc * out.Fp, 64, 1);
 }
+// convt1 with the mask head's 64 -> 1 contraction in its epilogue (MaskSumEpi): d1 never reaches HBM
+template <int S>
+void run_subpix_mask(dpdf_model* m, const SepConvW& w, const PathW& p, TView e, TView prev, const float* e0, float* ssum, int Fo, int B, int Tc) {
+    RowMap rm = RowMap::make(Tc, Fo);
+    SubpixA<S> ap{e, prev, rm, m->C(p.ps), m->C(p.pb), m->C(w.dw)};
+    MaskSumEpi ep{e0, ssum, m->C(w.bias), m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w)};
+    launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.pwfrag), ep, B * Tc * Fo, 64, 1);
+}
 void run_subpix_s(dpdf_model* m, const SepConvW& w, const PathW& p, TView e, TView prev, TView out, int B, int Tc, int s) {
     if (s == 1) run_subpix<1>(m, w, p, e, prev, out, B, Tc);
     else if (s == 2) run_subpix<2>(m, w, p, e, prev, out, B, Tc);
@@ -954,10 +963,18 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         TView d3v{w.d3.p, Tc, 0, d.F2, 64}, d2v{w.d2.p, Tc, 0, d.F1, 64}, d1v{w.d1.p, Tc, 0, d.Ec, 64};
         run_subpix_s(m, m->convt3, m->conv3p, e3v, dembv, d3v, B, Tc, d.s3);
         run_subpix_s(m, m->convt2, m->conv2p, e2v, d3v, d2v, B, Tc, d.s2);
-        run_subpix_s(m, m->convt1, m->conv1p, e1v, d2v, d1v, B, Tc, d.s1);
-        MaskOutArgs ma{x.e0.p, w.d1.p, w.m.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias,
-                       BT * d.Ec, d.Ec, d.E, d.is48};
-        hipLaunchKernelGGL(mask_out_kernel, dim3((BT * d.Ec + 3) / 4), dim3(256), 0, st, ma);
+        if (m->fuse_mask) {
+            // w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
+            if (d.s1 == 2) run_subpix_mask<2>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
+            else run_subpix_mask<3>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
+            MaskFinArgs mf{w.d1.p, w.m.p, m->c0out_bias, BT * d.Ec, d.Ec, d.E, d.is48};
+            hipLaunchKernelGGL(mask_fin_kernel, dim3((BT * d.Ec + 255) / 256), dim3(256), 0, st, mf);
+        } else {
+            run_subpix_s(m, m->convt1, m->conv1p, e1v, d2v, d1v, B, Tc, d.s1);
+            MaskOutArgs ma{x.e0.p, w.d1.p, w.m.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias,
+                           BT * d.Ec, d.Ec, d.E, d.is48};
+            hipLaunchKernelGGL(mask_out_kernel, dim3((BT * d.Ec + 3) / 4), dim3(256), 0, st, ma);
+        }
     }
     if (fork) { HIP_TRY(hipEventRecord(m->ln->ev_djn[c.parity], sd)); HIP_TRY(hipStreamWaitEvent(st, m->ln->ev_djn[c.parity], 0)); }
     // ---- mask + deep filter (layers.py:414-445, multiframe.py:200-232) ----
@@ -1313,6 +1330,19 @@ extern "C" int dpdf_set_fuse_dprnn(dpdf_model* m, int on) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
     std::lock_guard<std::mutex> lk(m->mu);
     m->fuse_dprnn = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return DPDF_OK;
+}
+// A/B switches for measurements (never change results beyond rounding); unknown names are an error.
+extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
+    if (!m || !name) return set_err(DPDF_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
+    (void)hipSetDevice(m->device);
+    for (int g = 0; g < 2; ++g) { (void)hipStreamSynchronize(m->lanes[g].sA); (void)hipStreamSynchronize(m->lanes[g].sB); (void)hipStreamSynchronize(m->lanes[g].sC); (void)hipStreamSynchronize(m->lanes[g].sD); }
+    const std::string n(name);
+    if (n == "fuse_mask") m->fuse_mask = value != 0;
+    else if (n == "hoist_gi") m->hoist_gi = value != 0;
+    else if (n == "gru256_cluster") m->use_gru256_cluster = value != 0;
+    else return set_err(DPDF_E_INVALID, "unknown option '%s'", name);
     return DPDF_OK;
 }
 extern "C" int dpdf_sync(dpdf_model* m) {

@@ -347,6 +347,52 @@ struct BiasReluToView {
     }
 };
 
+// Last decoder stage + mask head, fused (reference onnx_model/dpdfnet.py:320-323, 364-366): the GEMM produces
+// d1 = relu(convt1(..) + BN shift); the mask head needs u = relu(ps*e0 + pb) + d1 (conv0p pathway + skip) and then
+// conv0_out = dense 64->1 k(1,3) over frequency + BN + sigmoid.  The 64->1 contraction is done HERE, on the
+// accumulators: s_k[row] = sum_c w[c][k] * u[row][c] for the three taps (one DPP row all-reduce each), 16 bytes per
+// row go to HBM instead of the 256-byte d1 row (which the stand-alone mask kernel then read back together with e0:
+// 1.4x its algorithmic traffic and no MFMA).  mask_fin_kernel adds the three neighbours and applies the sigmoid.
+struct MaskSumEpi {
+    const float* e0;       // [rows][64], same flat row index as the GEMM
+    float* s;              // [rows][4]: s_0, s_1, s_2, unused
+    const float* bias;     // convt1 BN shift [64]
+    const float* ps; const float* pb;   // conv0p folded scale / shift [64]
+    const float* w;        // conv0_out [64][3], BN folded
+    struct Pref { float r[4][4]; };
+    __device__ __forceinline__ void prefetch(Pref& P, int row0, int lane, int, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = row0 + rq + i;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) P.r[nt][i] = row < M ? e0[(size_t)row * 64 + nt * 16 + cl] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void call(f32x4 (&acc)[4], const Pref& P, int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+        float bv[4], sc[4], sh[4], w0[4], w1[4], w2[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int c = nt * 16 + cl;
+            bv[nt] = bias[c]; sc[nt] = ps[c]; sh[nt] = pb[c];
+            w0[nt] = w[c * 3 + 0]; w1[nt] = w[c * 3 + 1]; w2[nt] = w[c * 3 + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float u = fmaxf(acc[nt][i] + bv[nt], 0.f) + fmaxf(__builtin_fmaf(sc[nt], P.r[nt][i], sh[nt]), 0.f);
+                s0 = __builtin_fmaf(w0[nt], u, s0); s1 = __builtin_fmaf(w1[nt], u, s1); s2 = __builtin_fmaf(w2[nt], u, s2);
+            }
+            s0 = row16_allreduce_sum(s0); s1 = row16_allreduce_sum(s1); s2 = row16_allreduce_sum(s2);
+            const int row = row0 + rq + i;
+            if (cl == 0 && row < M) *(float4*)(s + (size_t)row * 4) = make_float4(s0, s1, s2, 0.f);
+        }
+    }
+};
+
 // Linear bias + LayerNorm(64, eps 1e-5, biased var) + residual  (DPRNNBlock fc_intra/ln_intra and
 // fc_inter/ln_inter, reference onnx_model/layers.py:178-193).  Rows are contiguous [M][64].
 struct LnResStore {

@@ -188,6 +188,27 @@ __global__ __launch_bounds__(256) void mask_out_kernel(MaskOutArgs a) {
     }
 }
 
+// mask head, second half (first half: MaskSumEpi in gemm_rows.h): m[f] = sigmoid(bias + s_0[f-1] + s_1[f] + s_2[f+1])
+// = conv0_out k(1,3), zero pad 1, + BN + Sigmoid (reference onnx_model/dpdfnet.py:320-323).  One thread per band.
+struct MaskFinArgs {
+    const float* s;        // [rows][4]
+    float* m;              // [B*Tc][Em]
+    float bias;
+    int rows, Ec, Em, is48;
+};
+__global__ __launch_bounds__(256) void mask_fin_kernel(MaskFinArgs a) {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (size_t)a.rows) return;
+    const int f = (int)(row % a.Ec);
+    const size_t bt = row / a.Ec;
+    float acc = a.s[row * 4 + 1];
+    if (f > 0) acc += a.s[(row - 1) * 4 + 0];
+    if (f + 1 < a.Ec) acc += a.s[(row + 1) * 4 + 2];
+    const float mv = sigmoid_f(acc + a.bias);
+    a.m[bt * a.Em + f] = mv;
+    if (a.is48 && f == a.Ec - 2) a.m[bt * a.Em + a.Ec] = mv;   // F.pad reflect (0,1): m[480] = m[478]
+}
+
 // ---------------------------------------------------------------------------------------------
 // Mask.forward / MagnitudeMask.forward: masked spec of the frame from two steps ago
 // (reference onnx_model/layers.py:414-445, dpdfnet_48khz_hr.py:55-69).

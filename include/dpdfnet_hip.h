@@ -121,6 +121,10 @@ int dpdf_set_overlap(dpdf_model* m, int mask);
  * 0 always as separate GEMM kernels; 1 (default) picks per chunk -- fused once streams x frames fills the
  * chip (>= 3072 frame rows), separate below that (single-hop streaming, small batches). */
 int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
+/* Further A/B switches by name (measurement only; results equal to rounding): "fuse_mask" (1: the mask head's 64->1
+ * contraction runs in the last decoder GEMM's epilogue, 0: stand-alone kernel), "hoist_gi" (small-batch GRU-64 input
+ * GEMM hoisting), "gru256_cluster" (0: single-workgroup GRU-256 scan).  Unknown name -> DPDF_E_INVALID. */
+int dpdf_set_option(dpdf_model* m, const char* name, int value);
 
 /* Rational polyphase resampler on the device, for `ensure_sample_rate` when the caller's rate differs from the
  * model's (reference package/src/dpdfnet/audio.py:20-27 -> librosa.resample(res_type="soxr_hq"); stream.py:112,

@@ -7,10 +7,16 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-rX}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
+# Every launch of a traced run has ONE execution shape (no appended serial step, no side configs), so that the CSV's
+# AverageNs of a kernel IS the bench line's roofline.avg_launch_ms of the same run:
+#   trace_pipelined: the default 4-stream pipeline  -> roofline.frac
+#   trace_serial:    --overlap 0, kernels back to back -> roofline.frac_isolated of the default run
+CMD="python bench.py --steps 3 --warmup 1 --no-isolated --no-other-configs --no-cpu-baseline --no-pcie"
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
-tail -1 $OUT/bench_trace.log > $OUT/bench_line_under_trace.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -o bench -- $CMD > $OUT/bench_trace_pipelined.log 2>&1
+grep '^{"metric"' $OUT/bench_trace_pipelined.log > $OUT/bench_line_under_trace_pipelined.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -o bench -- $CMD --overlap 0 > $OUT/bench_trace_serial.log 2>&1
+grep '^{"metric"' $OUT/bench_trace_serial.log > $OUT/bench_line_under_trace_serial.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o pmc -- $CMD > $OUT/pmc_mfma.log 2>&1
@@ -46,4 +52,4 @@ json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1)
 for k, e in sorted(res.items(), key=lambda kv: -kv[1].get("mfma_flop", 0))[:8]:
     print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in e.items()})
 PY
-ls $OUT $OUT/trace
+ls $OUT $OUT/trace_pipelined $OUT/trace_serial
