@@ -53,7 +53,8 @@ EXPORTED_SYMBOLS = (
 
 
 def lib_path() -> Path:
-    return _PKG_DIR / _LIB_NAME
+    override = os.environ.get("DPDFNET_HIP_LIB")       # tools/: timing ablation builds of the same library
+    return Path(override) if override else _PKG_DIR / _LIB_NAME
 
 
 def load_library() -> ctypes.CDLL:

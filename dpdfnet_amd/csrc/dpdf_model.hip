@@ -266,6 +266,8 @@ struct dpdf_model {
     // 0 = everything serial on the main stream (A/B timing).
     int overlap = 27;
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
+    int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
+                                       // of >= 8 tiles).  Measured and left OFF: DESIGN.md section 7.
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
@@ -560,9 +562,12 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
     ENS(w.feat_spec, (size_t)B * (Tc + 2) * 2 * d.D);
     ENS(w.hcat, BT * d.Fd * 128); ENS(w.hin, BT * d.Fd * 64);
     ENS(w.hcat_e, BT * d.F3 * 128); ENS(w.hin_e, BT * d.F3 * 64);
-    ENS(w.embin, BT * 1024); ENS(w.g256a, BT * 256); ENS(w.g256b, BT * 256); ENS(w.g256c, BT * 256);
-    ENS(w.gi, BT * 768); ENS(w.emb, BT * 512); ENS(w.demb, BT * 512);
-    ENS(w.g256d, BT * 256); ENS(w.g256e, BT * 256); ENS(w.g256f, BT * 256); ENS(w.gi2, BT * 768);
+    // GRU-256 scan inputs / outputs: rows rounded up to whole 16-clip tiles (gru256_ring_kernel addresses rows
+    // unclamped; the padding rows are read, never written or used)
+    const size_t BTp = (size_t)((B + 15) & ~15) * Tc;
+    ENS(w.embin, BT * 1024); ENS(w.g256a, BTp * 256); ENS(w.g256b, BTp * 256); ENS(w.g256c, BTp * 256);
+    ENS(w.gi, BTp * 768); ENS(w.emb, BT * 512); ENS(w.demb, BT * 512);
+    ENS(w.g256d, BTp * 256); ENS(w.g256e, BTp * 256); ENS(w.g256f, BTp * 256); ENS(w.gi2, BTp * 768);
     ENS(w.demb2, BT * (size_t)d.F3 * 64);
     ENS(w.d3, BT * d.F2 * 64); ENS(w.d2, BT * d.F1 * 64); ENS(w.d1, BT * d.Ec * 64);
     ENS(w.m, BT * d.E); ENS(w.dfo, BT * d.D * 10);
@@ -645,7 +650,15 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
             // (2048 clips = 512 workgroups on 256 CUs is covered by tests/test_gpu_fullsize.py).  If the assumption ever
             // fails the spin times out, d_err is raised and the call returns DPDF_E_RUNTIME (check_device_err).
             // eight workgroups per tile: measured better up to 64 clips, worse from 128 (tools/sweep2.sh)
+            // two interleaved tiles per cluster from 8 tiles (128 streams) on: the launch is throughput-relevant there (it
+            // pins CUs the GRU-64 kernels want) and stage 2 has slack; below that the step latency matters
             if ((m->overlap & 16) && ntiles <= 4) hipLaunchKernelGGL(gru256_cluster8_kernel, dim3(ntiles * 8), dim3(256), 0, m->cur, a);
+            else if (m->gru256_pair && ntiles >= 8 && ntiles % m->gru256_pair == 0) {
+                const int nt = m->gru256_pair;
+                if (nt == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(gru256_ring_kernel<4>), dim3(ntiles), dim3(256), 0, m->cur, a);
+                else if (nt == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(gru256_ring_kernel<3>), dim3(ntiles / 3 * 4), dim3(256), 0, m->cur, a);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(gru256_ring_kernel<2>), dim3(ntiles * 2), dim3(256), 0, m->cur, a);
+            }
             else hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->cur, a);
         } else {
             Gru256Args a{gi, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
@@ -1023,12 +1036,15 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
         HIP_TRY(hipEventRecord(m->lanes[0].ev_fork, m->stream));
         HIP_TRY(hipStreamWaitEvent(m->lanes[1].sA, m->lanes[0].ev_fork, 0));
     }
-    int i = 0;
-    for (int t0 = 0; t0 < T; t0 += chunk, ++i) {
+    // (Measured and dropped: ending on a quarter-size chunk to shorten the pipeline drain -- 115.0 vs 114.6 ms/step.)
+    std::vector<int> sizes;
+    for (int rem = T; rem > 0; rem -= std::min(chunk, rem)) sizes.push_back(std::min(chunk, rem));
+    int i = 0, t0 = 0;
+    for (size_t ci = 0; ci < sizes.size(); t0 += sizes[ci], ++ci, ++i) {
         int b0 = 0;
         for (int g = 0; g < G; ++g) {
             m->ln = &m->lanes[g];
-            ChunkArgs c{raw + (size_t)b0 * clip_stride + (size_t)t0 * d.F * 2, clip_stride, Bg[g], std::min(chunk, T - t0),
+            ChunkArgs c{raw + (size_t)b0 * clip_stride + (size_t)t0 * d.F * 2, clip_stride, Bg[g], sizes[ci],
                         state + (size_t)b0 * d.state_size, out + (size_t)b0 * clip_stride, clip_stride, t0,
                         attn_raw ? attn_raw + (size_t)b0 * clip_stride : nullptr, alpha, i & 1};
             if ((rc = run_stage1(m, c)) || (rc = run_stage2(m, c))) { m->ln = &m->lanes[0]; return rc; }
@@ -1341,6 +1357,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
+    else if (n == "gru256_pair") m->gru256_pair = (value >= 2 && value <= 4) ? value : 0;
     else if (n == "gru256_cluster") m->use_gru256_cluster = value != 0;
     else return set_err(DPDF_E_INVALID, "unknown option '%s'", name);
     return DPDF_OK;
