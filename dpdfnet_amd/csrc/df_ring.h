@@ -1,0 +1,142 @@
+// df_ring.h -- the DF branch's two consumers of c0 in ONE pass over it.
+//
+// c0 = df_conv0(feat_spec) [B][T][96 bands][64 ch] (reference onnx_model/dpdfnet.py:94-101) feeds
+//   * df_conv1: depthwise k(1,3) stride 2 over bands + pointwise 64x64 + BN + ReLU -> c1 [B][T][48][64]
+//     (dpdfnet.py:102, layers.py:761-834), and
+//   * the DF decoder's pathway conv df_convp: grouped k(5,1) conv over the last FIVE frames + pointwise 10x10 + BN
+//     + ReLU -> 10 values per (frame, band) (dpdfnet.py:424-431, 508-515; folded on the host into one [320 -> 10]
+//     matrix), added to df_out's taps in stage 2.
+// As two gemm_rows launches c0 was read 1x by the first and ~1.5x by the second (five row tiles touch every c0 row, the
+// L2 catches most) -- 15 GB per step of the headline workload, the pathway GEMM latency-bound at 1.6 TB/s with five
+// dependent K panels per tile.  Here a workgroup owns (clip, 32-band tile) and walks TIME: the last five c0 frames of
+// its tile live in an LDS ring, every frame is loaded from HBM exactly once (plus one halo band for the stride-2 conv),
+// and both products come out of the ring:
+//     pathway  [32 rows x K=320] . [320 x 16]   waves = 2 row tiles x 2 K halves, halves summed through LDS
+//     df_conv1 depthwise on the VALU from the newest ring slot -> [16 rows x 64] . [64 x 64], wave = 16-column tile
+// The pathway result p = relu(. + BN shift) does not depend on the GRUs, so it is produced here in stage 1 and only
+// ADDED to tanh(df_out) in stage 2 (DfOutEpi).  Used when clips x 3 workgroups fill the chip; small batches keep the
+// two gemm_rows launches (time-parallel, latency-friendly).
+#pragma once
+#include "common.h"
+
+struct DfRingArgs {
+    const float* c0;       // [B][4 + Tc][96][64]: 4 halo frames (imported from the state FIFO) in front of each clip
+    float* c1;             // [B*Tc][48][64]
+    float* p;              // [B*Tc][96][10]
+    const float* dw;       // df_conv1 depthwise [64][3]
+    const float* pwfrag;   // df_conv1 pointwise (BN folded), MFMA B fragments [chunk 4][tile 4][kb 4][lane 64]
+    const float* pwbias;   // [64]
+    const float* cpfrag;   // pathway [320 -> 16], fragments [chunk 20][kb 4][lane 64]
+    const float* cpbias;   // [10]
+    int B, Tc;
+};
+
+__global__ __launch_bounds__(256, 3) void df_ring_kernel(DfRingArgs a) {
+    constexpr int D = 96, FD = 48;
+    __shared__ __attribute__((aligned(16))) float R[5][33][68];     // ring of frames; row 0 = halo band f0-1, rows 1..32 = bands f0..f0+31
+    __shared__ __attribute__((aligned(16))) float A1[16][68];       // depthwise output rows of the newest frame
+    __shared__ float Pz[2][4][64];                                  // pathway partial sums of the upper K half
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x / 3, jt = blockIdx.x - 3 * b;
+    const int f0 = 32 * jt, fo0 = 16 * jt;
+    const int mt = w & 1, kh = w >> 1;
+
+    float cp[40], pw[16];
+#pragma unroll
+    for (int i = 0; i < 40; ++i) cp[i] = a.cpfrag[(size_t)(40 * kh + i) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) pw[c * 4 + kb] = a.pwfrag[(size_t)((c * 4 + w) * 4 + kb) * 64 + lane];
+    const float pwb = a.pwbias[16 * w + cl];
+    const float cpb = cl < 10 ? a.cpbias[cl] : 0.f;
+    const int fo_l = tid >> 4, c4 = (tid & 15) * 4;                 // depthwise: this thread's output row / channel quad
+    float dwv[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dwv[j][k] = a.dw[(c4 + j) * 3 + k];
+
+    // frame tile loader: 33 rows x 16 float4 = 528 pieces over 256 threads (3 rounds, the last one 16 threads wide)
+    const float* cbase = a.c0 + ((size_t)b * (a.Tc + 4) + 4) * D * 64;           // frame 0 of this clip
+    auto load_frame = [&](int t, float4 (&v)[3]) __attribute__((always_inline)) {
+        const float* fb = cbase + (long)t * D * 64;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 4, band = f0 - 1 + row;
+            v[i] = (idx < 528 && band >= 0) ? *(const float4*)(fb + (size_t)band * 64 + (idx & 15) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_frame = [&](int slot, const float4 (&v)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 528) *(float4*)&R[slot][idx >> 4][(idx & 15) * 4] = v[i];
+        }
+    };
+    float4 fr[3];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {             // the four halo frames t = -4..-1 -> slots 1..4
+        load_frame(h - 4, fr);
+        store_frame(h + 1, fr);
+    }
+    load_frame(0, fr);
+
+    int slot = 0;                              // slot of frame t: (t mod 5)
+    for (int t = 0; t < a.Tc; ++t) {
+        store_frame(slot, fr);
+        if (t + 1 < a.Tc) load_frame(t + 1, fr);
+        __syncthreads();                       // ring holds frames t-4 .. t
+        // ---- pathway conv: rows mt*16.., K chunks [10 kh, 10 kh + 10): chunk cg = 4 kt + cc <-> frame t-4+kt, channels 16 cc..
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ci = 0; ci < 10; ++ci) {
+            const int cg = 10 * kh + ci, kt = cg >> 2, cc = cg & 3;
+            int s = slot + 1 + kt; s = s >= 5 ? s - 5 : s;           // frame t-4+kt = slot (slot + 1 + kt) mod 5
+            const float4 a4 = *(const float4*)&R[s][1 + mt * 16 + cl][cc * 16 + 4 * q];
+            acc = mfma16(a4.x, cp[ci * 4 + 0], acc);
+            acc = mfma16(a4.y, cp[ci * 4 + 1], acc);
+            acc = mfma16(a4.z, cp[ci * 4 + 2], acc);
+            acc = mfma16(a4.w, cp[ci * 4 + 3], acc);
+        }
+        // ---- df_conv1 depthwise (stride 2, zero pad 1): output band fo <- c0 bands 2 fo - 1 .. 2 fo + 1 = ring rows 2 fo_l + {0,1,2}
+        {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 x = *(const float4*)&R[slot][2 * fo_l + k][c4];
+                v.x += dwv[0][k] * x.x; v.y += dwv[1][k] * x.y; v.z += dwv[2][k] * x.z; v.w += dwv[3][k] * x.w;
+            }
+            *(float4*)&A1[fo_l][c4] = v;
+        }
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Pz[mt][i][lane] = acc[i];
+        }
+        __syncthreads();
+        // ---- df_conv1 pointwise: [16 x 64] . [64 x 16 w ..]
+        f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 a4 = *(const float4*)&A1[cl][c * 16 + 4 * q];
+            a1 = mfma16(a4.x, pw[c * 4 + 0], a1);
+            a1 = mfma16(a4.y, pw[c * 4 + 1], a1);
+            a1 = mfma16(a4.z, pw[c * 4 + 2], a1);
+            a1 = mfma16(a4.w, pw[c * 4 + 3], a1);
+        }
+        const size_t bt = (size_t)b * a.Tc + t;
+        {
+            float* dst = a.c1 + (bt * FD + fo0 + q * 4) * 64 + 16 * w + cl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[(size_t)i * 64] = fmaxf(a1[i] + pwb, 0.f);
+        }
+        if (kh == 0 && cl < 10) {
+            float* dst = a.p + (bt * D + f0 + mt * 16 + q * 4) * 10 + cl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[(size_t)i * 10] = fmaxf(acc[i] + Pz[mt][i][lane] + cpb, 0.f);
+        }
+        slot = slot == 4 ? 0 : slot + 1;
+    }
+}

@@ -27,6 +27,7 @@
 #include "gru_scan.h"
 #include "misc_kernels.h"
 #include "resample.h"
+#include "df_ring.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -212,10 +213,11 @@ struct DevBuf {
 // decoders, mask, deep filter).  Double-buffered by chunk parity so that stage 2 of chunk i runs on
 // its own HIP stream underneath stage 1 of chunk i+1.
 struct XSet {
-    DevBuf xs, e0, e1, e2, e3, xe_a, xe_b, c0, c1, xd_a, xd_b;
+    DevBuf xs, e0, e1, e2, e3, xe_a, xe_b, c0, c1, xd_a, xd_b, pconv;
     const float* e3d = nullptr; const float* c1d = nullptr;
+    bool have_pconv = false;          // stage 1 produced the DF pathway conv (df_ring_kernel) for this chunk
     void release() {
-        DevBuf* all[] = {&xs, &e0, &e1, &e2, &e3, &xe_a, &xe_b, &c0, &c1, &xd_a, &xd_b};
+        DevBuf* all[] = {&xs, &e0, &e1, &e2, &e3, &xe_a, &xe_b, &c0, &c1, &xd_a, &xd_b, &pconv};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -268,6 +270,7 @@ struct dpdf_model {
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
                                        // of >= 8 tiles).  Measured and left OFF: DESIGN.md section 7.
+    int df_ring = 1;                   // df_conv1 + DF pathway conv as one time-walking pass over c0 (df_ring.h) for big batches
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
@@ -557,6 +560,7 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
         ENS(x.xe_a, BT * d.F3 * 64); ENS(x.xe_b, BT * d.F3 * 64);
         ENS(x.c0, (size_t)B * (Tc + 4) * d.D * 64); ENS(x.c1, BT * d.Fd * 64);
         ENS(x.xd_a, BT * d.Fd * 64); ENS(x.xd_b, BT * d.Fd * 64);
+        ENS(x.pconv, BT * d.D * 10);
     }
     ENS(w.feat_erb, (size_t)B * (Tc + 2) * d.E);
     ENS(w.feat_spec, (size_t)B * (Tc + 2) * 2 * d.D);
@@ -875,7 +879,16 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm};
         BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
         launch_gemm_rows<4, 32, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 32, 1);
-        run_dwconv_s(m, m->df_conv1, c0v, c1v, B, Tc, 2);
+        // df_conv1 (+ the DF decoder's pathway conv): one time-walking pass over c0 when clips x 3 workgroups fill the
+        // chip, else the time-parallel gemm_rows forms (df_ring.h)
+        x.have_pconv = m->df_ring && B * 3 >= 192;
+        if (x.have_pconv) {
+            DfRingArgs ra{x.c0.p, x.c1.p, x.pconv.p, m->C(m->df_conv1.dw), m->C(m->df_conv1.pwfrag), m->C(m->df_conv1.bias),
+                          m->C(m->convp_frag), m->C(m->convp_bias), B, Tc};
+            hipLaunchKernelGGL(df_ring_kernel, dim3(B * 3), dim3(256), 0, sA, ra);
+        } else {
+            run_dwconv_s(m, m->df_conv1, c0v, c1v, B, Tc, 2);
+        }
     }
     x.c1d = x.c1.p;
     if (d.nb > 0) {
@@ -949,11 +962,18 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
             ProfScope ps(m, "df_coefs");
             size_t n = (size_t)BT * 256;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(axpy_kernel), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, sd, gc, ga, n);
-            run_gl_auto(m, m->df_out, gc, 256, w.dfo.p, (size_t)d.D * 10, BT, ACT_TANH);
-            RowMap rm = RowMap::make(Tc, d.D);
-            ConvpA ap{c0v, rm};
-            ConvpEpi ep{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
-            launch_gemm_rows<1, 64, false>(sd, ap, m->C(m->convp_frag), ep, BT * d.D, 320, 1);
+            if (x.have_pconv) {      // pathway conv already done in stage 1: df_out's epilogue adds it and writes the taps
+                const GlW& g = m->df_out;
+                PlainA<16> ap{gc, 256, g.Ig, g.Ig};
+                DfOutEpi ep{w.coefs.p, Tc, FastDiv::make(Tc), x.pconv.p, m->C(g.bias), g.Og};
+                launch_gemm_rows<4, 16, false>(sd, ap, m->C(g.frag), ep, BT, g.Ig, g.G);
+            } else {
+                run_gl_auto(m, m->df_out, gc, 256, w.dfo.p, (size_t)d.D * 10, BT, ACT_TANH);
+                RowMap rm = RowMap::make(Tc, d.D);
+                ConvpA ap{c0v, rm};
+                ConvpEpi ep{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
+                launch_gemm_rows<1, 64, false>(sd, ap, m->C(m->convp_frag), ep, BT * d.D, 320, 1);
+            }
         }
         m->cur = st;
     }
@@ -1356,6 +1376,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     for (int g = 0; g < 2; ++g) { (void)hipStreamSynchronize(m->lanes[g].sA); (void)hipStreamSynchronize(m->lanes[g].sB); (void)hipStreamSynchronize(m->lanes[g].sC); (void)hipStreamSynchronize(m->lanes[g].sD); }
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
+    else if (n == "df_ring") m->df_ring = value != 0;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
     else if (n == "gru256_pair") m->gru256_pair = (value >= 2 && value <= 4) ? value : 0;
     else if (n == "gru256_cluster") m->use_gru256_cluster = value != 0;

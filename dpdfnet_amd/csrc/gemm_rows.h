@@ -470,6 +470,43 @@ struct ConvpEpi {
     }
 };
 
+// df_out epilogue when the pathway conv ran in stage 1 (df_ring.h): coefs[b, 2 + t, col] = tanh(acc + bias) + p[row, col],
+// col = grp * 60 + n  (reference onnx_model/dpdfnet.py:508-515: c = df_out(..).tanh() ; c + pathway)
+struct DfOutEpi {
+    float* coefs; int Tc; FastDiv dT;      // coefs [B][2 + Tc][960], halo 2
+    const float* p;                        // [B*Tc][960]
+    const float* bias; int Og;             // 60 valid columns per group
+    struct Pref { float d[4][4]; };
+    __device__ __forceinline__ void prefetch(Pref& P, int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = nt * 16 + cl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + rq + i;
+                P.d[nt][i] = (col < Og && row < M) ? p[(size_t)row * 960 + grp * Og + col] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void call(f32x4 (&acc)[4], const Pref& P, int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = nt * 16 + cl;
+            if (col >= Og) continue;
+            const float bv = bias[grp * Og + col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + rq + i;
+                if (row >= M) continue;
+                const int b = dT.div(row), t = row - b * Tc;
+                coefs[((size_t)b * (Tc + 2) + 2 + t) * 960 + grp * Og + col] = tanh_f(acc[nt][i] + bv) + P.d[nt][i];
+            }
+        }
+    }
+};
+
 // iSTFT frame epilogue: frames[r][n] = acc * window[n]
 template <int NT>
 struct WindowStore {

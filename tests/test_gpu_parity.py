@@ -307,3 +307,36 @@ def test_models_in_concurrent_host_threads(be):
     for i in range(4):
         np.testing.assert_array_equal(got_own[i], want[i])
         np.testing.assert_array_equal(got_shared[i], want[i])
+
+
+@pytest.mark.parametrize("sr,nb", [(16000, 2), (48000, 1)])
+def test_big_batch_kernel_forms_match_small_batch_forms_and_oracle(be, sr, nb):
+    """Launch shapes that only big batches select -- the time-walking DF pass over c0 (df_ring_kernel: df_conv1 + pathway
+    conv, >= 64 clips), the mask head folded into the last decoder GEMM, the round-robin GRU-256 ring scan (opt-in) --
+    against the small-batch forms of the same engine (stage tensors) and the oracle (waveforms), on 192 distinct clips
+    (12 GRU-256 tiles: divisible by 2, 3 and 4)."""
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import synth_blob
+    blob = synth_blob(be.manifest(sr, nb), 777)
+    m = be.HipModel(sr, nb, blob, 0)
+    B, n = 192, int(0.25 * sr) + 17
+    wav = np.stack([synth_clip(n, sr, 2000 + i) * (0.5 + (i % 7) / 7.0) for i in range(B)]).astype(np.float32)
+    m.set_chunk_frames(16)                      # several chunks: the ring's halo frames come through the state FIFO
+    ref_probe = {}
+    outs = {}
+    for tag, opts in (("small_forms", {"df_ring": 0, "fuse_mask": 0}), ("big_forms", {"df_ring": 1, "fuse_mask": 1}),
+                      ("ring4", {"gru256_pair": 4}), ("ring3", {"gru256_pair": 3}), ("ring2", {"gru256_pair": 2})):
+        for k, v in opts.items():
+            m.set_option(k, v)
+        outs[tag] = m.enhance_batch(wav, 6.0)
+        ref_probe[tag] = {k: m.debug_fetch(k) for k in ("c1", "coefs", "m")}
+    m.set_option("gru256_pair", 0)
+    for tag in ("big_forms", "ring4", "ring3", "ring2"):
+        assert rms(outs[tag] - outs["small_forms"]) < 1e-6, tag
+        for k in ("c1", "coefs", "m"):
+            a_, b_ = ref_probe[tag][k], ref_probe["small_forms"][k]
+            assert np.abs(a_ - b_).max() < 2e-5 * max(1.0, float(np.abs(b_).max())), (tag, k)
+    o = orc.Oracle(sr, nb, blob)
+    for b in (0, 41, 191):
+        assert rms(outs["big_forms"][b] - o.enhance(wav[b], 6.0)) < WAVE_TOL, b
+    m.close()
