@@ -1,0 +1,164 @@
+// dec_last.h -- the ERB decoder's last stage and the mask head as one kernel (16 kHz geometry: 16 -> 32 bands).
+//
+// reference onnx_model/dpdfnet.py:361-366: d1 = convt1(conv1p(e1) + d2); m = conv0_out(conv0p(e0) + d1), with
+// convt1 = sub-pixel (2 depthwise k(1,3) convs interleaved along frequency, layers.py:895-916) + pointwise 64x64 + BN +
+// ReLU, conv{1,0}p = per-channel scale + BN + ReLU, conv0_out = dense 64 -> 1 k(1,3) + BN + Sigmoid.
+// As a gemm_rows launch (SubpixA<2> producer + MaskSumEpi) this stage took 0.41 ms per chunk of the headline
+// workload -- 1.3 TB/s: every thread fetched the three taps of both inputs itself (6x redundant through the L1) and
+// recomputed the pathway term per tap, with a runtime modulo per row.  Here a 64-row tile is exactly two frames, so a
+// workgroup loads each of its three input tiles ONCE, fully coalesced (they are contiguous in memory), forms
+// u1 = relu(ps1 e1 + pb1) + d2 once per element into LDS, builds the depthwise panel from LDS, runs the pointwise
+// GEMM on the matrix cores, and finishes the mask in place: 64 -> 1 contraction on the accumulators (DPP row
+// reductions), the three-band sum and the sigmoid through a 1 KB LDS array.  Only m [frames][32] is written.
+#pragma once
+#include "common.h"
+
+struct DecLastArgs {
+    const float* e1; const float* d2;   // [BT][16][64]
+    const float* e0;                    // [BT][32][64]
+    float* m;                           // [BT][32]
+    const float* ps1; const float* pb1; // conv1p folded [64]
+    const float* dw;                    // convt1 depthwise [2][64][3]
+    const float* pwfrag;                // convt1 pointwise (BN folded), B fragments [chunk 4][tile 4][kb 4][lane 64]
+    const float* bias;                  // convt1 BN shift [64]
+    const float* ps0; const float* pb0; // conv0p folded [64]
+    const float* w0;                    // conv0_out [64][3] (BN folded)
+    float bias0;
+    int BT;                             // frames (even or odd; a trailing single frame is handled)
+};
+
+__global__ __launch_bounds__(256, 2) void dec_last_kernel(DecLastArgs a) {
+    __shared__ __attribute__((aligned(16))) float U1[2][18][68];    // u1 per frame, rows 0 and 17 = zero padding bands
+    __shared__ __attribute__((aligned(16))) float E0[64][68];       // relu(ps0 e0 + pb0)
+    __shared__ __attribute__((aligned(16))) float As[64][68];       // depthwise panel
+    __shared__ float Ss[64][4];                                     // tap sums per output row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, q = lane >> 4;
+    const int c4 = (tid & 15) * 4;
+
+    float breg[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) breg[i] = a.pwfrag[(size_t)i * 64 + lane];
+    float4 s1 = *(const float4*)(a.ps1 + c4), b1 = *(const float4*)(a.pb1 + c4);
+    float4 s0 = *(const float4*)(a.ps0 + c4), b0 = *(const float4*)(a.pb0 + c4);
+    float dwv[2][4][3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dwv[k][j][t] = a.dw[((size_t)k * 64 + c4 + j) * 3 + t];
+    float bv[4], w0v[4][3];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int c = nt * 16 + cl;
+        bv[nt] = a.bias[c];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w0v[nt][t] = a.w0[c * 3 + t];
+    }
+    // zero the padding bands once
+    if (tid < 4 * 17) {
+        const int fr = tid / 34, rem = tid - fr * 34, row = rem / 17 ? 17 : 0, cc = (rem % 17) * 4;
+        *(float4*)&U1[fr][row][cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int ntiles = (a.BT + 1) >> 1;
+    auto load_tile = [&](int tile, float4 (&ve1)[2], float4 (&vd2)[2], float4 (&ve0)[4]) __attribute__((always_inline)) {
+        const size_t bt0 = (size_t)tile * 2;
+        const bool two = bt0 + 1 < (size_t)a.BT;                     // second frame of the tile exists
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = i == 0 || two;                           // piece i of e1/d2 = frame i (256 float4 per frame)
+            ve1[i] = ok ? *(const float4*)(a.e1 + bt0 * 1024 + (size_t)(tid + 256 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vd2[i] = ok ? *(const float4*)(a.d2 + bt0 * 1024 + (size_t)(tid + 256 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = i < 2 || two;                            // pieces 0,1 = frame 0; 2,3 = frame 1
+            ve0[i] = ok ? *(const float4*)(a.e0 + bt0 * 2048 + (size_t)(tid + 256 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    float4 ve1[2], vd2[2], ve0[4];
+    load_tile(tile, ve1, vd2, ve0);
+    for (; tile < ntiles; tile += gridDim.x) {
+        // ---- stage the tile: u1 and the pathway term of e0, once per element
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int band = tid >> 4;                               // piece i: frame i, band tid>>4
+            float4 u;
+            u.x = fmaxf(__builtin_fmaf(s1.x, ve1[i].x, b1.x), 0.f) + vd2[i].x;
+            u.y = fmaxf(__builtin_fmaf(s1.y, ve1[i].y, b1.y), 0.f) + vd2[i].y;
+            u.z = fmaxf(__builtin_fmaf(s1.z, ve1[i].z, b1.z), 0.f) + vd2[i].z;
+            u.w = fmaxf(__builtin_fmaf(s1.w, ve1[i].w, b1.w), 0.f) + vd2[i].w;
+            *(float4*)&U1[i][1 + band][c4] = u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            float4 u;
+            u.x = fmaxf(__builtin_fmaf(s0.x, ve0[i].x, b0.x), 0.f); u.y = fmaxf(__builtin_fmaf(s0.y, ve0[i].y, b0.y), 0.f);
+            u.z = fmaxf(__builtin_fmaf(s0.z, ve0[i].z, b0.z), 0.f); u.w = fmaxf(__builtin_fmaf(s0.w, ve0[i].w, b0.w), 0.f);
+            *(float4*)&E0[row][c4] = u;
+        }
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next, ve1, vd2, ve0);           // in flight under the rest of this tile
+        __syncthreads();
+        // ---- sub-pixel depthwise: output band fo = 2 f + k <- u1 bands f-1 .. f+1 with conv k
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 4) + 16 * i, fr = r >> 5, fo = r & 31, f = fo >> 1, k = fo & 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float4 x = *(const float4*)&U1[fr][f + t][c4];
+                v.x += (k ? dwv[1][0][t] : dwv[0][0][t]) * x.x; v.y += (k ? dwv[1][1][t] : dwv[0][1][t]) * x.y;
+                v.z += (k ? dwv[1][2][t] : dwv[0][2][t]) * x.z; v.w += (k ? dwv[1][3][t] : dwv[0][3][t]) * x.w;
+            }
+            *(float4*)&As[r][c4] = v;
+        }
+        __syncthreads();
+        // ---- pointwise 64 x 64 on the matrix cores: wave w = rows 16 w .. 16 w + 15
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* arow = &As[16 * w + cl][4 * q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 a4 = *(const float4*)(arow + 16 * c);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int bi = (c * 4 + nt) * 4;
+                acc[nt] = mfma16(a4.x, breg[bi + 0], acc[nt]);
+                acc[nt] = mfma16(a4.y, breg[bi + 1], acc[nt]);
+                acc[nt] = mfma16(a4.z, breg[bi + 2], acc[nt]);
+                acc[nt] = mfma16(a4.w, breg[bi + 3], acc[nt]);
+            }
+        }
+        // ---- mask head on the accumulators: u0 = relu(d1) + pathway(e0); three tap sums per row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 16 * w + 4 * q + i;
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float u = fmaxf(acc[nt][i] + bv[nt], 0.f) + E0[row][nt * 16 + cl];
+                t0 = __builtin_fmaf(w0v[nt][0], u, t0); t1 = __builtin_fmaf(w0v[nt][1], u, t1); t2 = __builtin_fmaf(w0v[nt][2], u, t2);
+            }
+            t0 = row16_allreduce_sum(t0); t1 = row16_allreduce_sum(t1); t2 = row16_allreduce_sum(t2);
+            if (cl == 0) { Ss[row][0] = t0; Ss[row][1] = t1; Ss[row][2] = t2; }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int fo = tid & 31;
+            float s = Ss[tid][1];
+            if (fo > 0) s += Ss[tid - 1][0];
+            if (fo < 31) s += Ss[tid + 1][2];
+            const size_t bt = (size_t)tile * 2 + (tid >> 5);
+            if (bt < (size_t)a.BT) a.m[bt * 32 + fo] = sigmoid_f(s + a.bias0);
+        }
+        // the next iteration's staging writes U1 / E0: every wave has passed the barrier above after its last read of
+        // them (U1: depthwise, E0: mask head); As and Ss are rewritten only after the next iteration's first barrier
+    }
+}

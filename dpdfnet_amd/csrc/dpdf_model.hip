@@ -28,6 +28,7 @@
 #include "misc_kernels.h"
 #include "resample.h"
 #include "df_ring.h"
+#include "dec_last.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -996,7 +997,14 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         TView d3v{w.d3.p, Tc, 0, d.F2, 64}, d2v{w.d2.p, Tc, 0, d.F1, 64}, d1v{w.d1.p, Tc, 0, d.Ec, 64};
         run_subpix_s(m, m->convt3, m->conv3p, e3v, dembv, d3v, B, Tc, d.s3);
         run_subpix_s(m, m->convt2, m->conv2p, e2v, d3v, d2v, B, Tc, d.s2);
-        if (m->fuse_mask) {
+        if (m->fuse_mask && !d.is48 && d.s1 == 2 && d.Ec == 32 && d.F1 == 16) {
+            // 16 kHz geometry: last decoder stage + mask head in one kernel, m written directly (dec_last.h)
+            DecLastArgs da{x.e1.p, w.d2.p, x.e0.p, w.m.p, m->C(m->conv1p.ps), m->C(m->conv1p.pb), m->C(m->convt1.dw),
+                           m->C(m->convt1.pwfrag), m->C(m->convt1.bias), m->C(m->conv0p.ps), m->C(m->conv0p.pb),
+                           m->C(m->c0out_w), m->c0out_bias, BT};
+            const int ntiles = (BT + 1) / 2;
+            hipLaunchKernelGGL(dec_last_kernel, dim3(std::min(ntiles, 256 * 3 * 4)), dim3(256), 0, st, da);
+        } else if (m->fuse_mask) {
             // w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
             if (d.s1 == 2) run_subpix_mask<2>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
             else run_subpix_mask<3>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
