@@ -222,17 +222,26 @@ struct XSet {
         for (DevBuf* b : all) b->release();
     }
 };
+constexpr int NRING = 4;            // chunk-ring depth of the stage-crossing tensors: 2 used by the two-stage pipeline, 4 by the sub-stage pipeline
 struct Workspace {
     int Bcap = 0, Tcap = 0;
-    XSet x[2];
+    XSet x[NRING];
     // stage-1 temporaries (DF branch on the main stream, ERB branch on its own stream)
     DevBuf feat_erb, feat_spec, hcat, hin, hcat_e, hin_e;
     DevBuf gi64, gi64_e;               // input-side GRU-64 pre-activations of the small-batch scans (grown on first use)
     // stage-2 temporaries
     DevBuf embin, g256a, g256b, g256c, gi, emb, demb, demb2, d3, d2, d1, m, dfo, coefs, xm;
     DevBuf g256d, g256e, g256f, gi2;   // DF-decoder chain's own scratch (runs beside the ERB decoder)
+    // sub-stage pipeline of stage 2 (small batches): tensors handed from one sub-stage to the next, by chunk parity,
+    // and per-cell scratch for the cells that then run concurrently
+    DevBuf embr[NRING], hbe[NRING], hbd[NRING], ge_in, gi3, gi4, gi5;
+    int pipeB = 0, pipeT = 0;
     void release() {
-        x[0].release(); x[1].release();
+        for (int k = 0; k < NRING; ++k) x[k].release();
+        DevBuf* pipe[] = {&ge_in, &gi3, &gi4, &gi5};
+        for (DevBuf* b : pipe) b->release();
+        for (int k = 0; k < NRING; ++k) { embr[k].release(); hbe[k].release(); hbd[k].release(); }
+        pipeB = pipeT = 0;
         DevBuf* all[] = {&feat_erb, &feat_spec, &hcat, &hin, &hcat_e, &hin_e, &gi64, &gi64_e,
                          &embin, &g256a, &g256b, &g256c, &gi, &g256d, &g256e, &g256f, &gi2, &emb, &demb, &demb2, &d3, &d2, &d1, &m, &dfo, &coefs, &xm};
         for (DevBuf* b : all) b->release();
@@ -245,14 +254,22 @@ struct Workspace {
 // HBM-bound phases of one lane run under MFMA-bound scans of the other.
 struct Lane {
     hipStream_t sA = nullptr, sB = nullptr, sC = nullptr, sD = nullptr;   // sD: DF-decoder half of stage 2
-    hipEvent_t ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
-    hipEvent_t ev_fk[2] = {nullptr, nullptr}, ev_jn[2] = {nullptr, nullptr};   // ERB-branch fork/join, per chunk parity
-    hipEvent_t ev_dfk[2] = {nullptr, nullptr}, ev_djn[2] = {nullptr, nullptr}; // decoder fork/join inside stage 2
-    bool s2_pending[2] = {false, false};
+    hipStream_t sE = nullptr, sF = nullptr, sG = nullptr;                  // small batches: stage 2 as a pipeline of sub-stages (run_stage2_pipe)
+    hipEvent_t ev_a[NRING] = {}, ev_be[NRING] = {}, ev_bd[NRING] = {}, ev_cd[NRING] = {};
+    void sync_all() const {
+        hipStream_t all[] = {sA, sB, sC, sD, sE, sF, sG};
+        for (hipStream_t st : all) if (st) (void)hipStreamSynchronize(st);
+    }
+    hipEvent_t ev_s1[NRING] = {}, ev_s2[NRING] = {}, ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
+    hipEvent_t ev_fk[NRING] = {}, ev_jn[NRING] = {};   // ERB-branch fork/join, per chunk-ring slot
+    hipEvent_t ev_dfk[NRING] = {}, ev_djn[NRING] = {}; // decoder fork/join inside stage 2
+    bool s2_pending[NRING] = {};
+    int prev_slot = -1;                                // ring slot of the chunk before the current one (sub-stage pipeline)
     Workspace ws;
     // GRU-256 cluster exchange granules: [0] embedding + ERB-decoder cells, [1] DF-decoder cells (they may run concurrently)
-    unsigned long long* gru_xbuf[2] = {nullptr, nullptr}; int gru_xbuf_tiles[2] = {0, 0}; unsigned gru_epoch[2] = {0, 0};
-    const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
+    // (the sub-stage pipeline runs all five cells concurrently: [2] ERB-decoder cell 0, [3] cell 1, [4] DF-decoder cell 1)
+    unsigned long long* gru_xbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int gru_xbuf_tiles[5] = {0, 0, 0, 0, 0}; unsigned gru_epoch[5] = {0, 0, 0, 0, 0};
+    const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; const float* dbg_emb = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
 };
 
 struct ProfEntry { double ms = 0; long calls = 0; };
@@ -267,7 +284,8 @@ struct dpdf_model {
     // bit 2: split the batch over two lanes; bit 3: DF decoder beside the ERB decoder inside stage 2 (needs bit 0);
     // bit 4: GRU-256 scans on 8 workgroups per tile when the launch has <= 4 tiles.
     // 0 = everything serial on the main stream (A/B timing).
-    int overlap = 27;
+    int overlap = 27;                  // bit 5 (sub-stage pipeline of stage 2 for <= 64 streams) is OFF by default: measured slower (run_stage2_pipe)
+    int pipe_chunk = 128;              // automatic chunk length (frames) of the sub-stage pipeline for small batches
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
                                        // of >= 8 tiles).  Measured and left OFF: DESIGN.md section 7.
@@ -531,6 +549,21 @@ void erb_bands(int nfft, int fs, std::vector<int>& start, std::vector<int>& band
     }
 }
 
+int ensure_xset(dpdf_model* m, XSet& x, int B, int Tc) {
+    const dpdf_dims& d = m->d;
+    const size_t BT = (size_t)B * Tc;
+    int rc = DPDF_OK;
+#define ENSX(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
+    ENSX(x.xs, (size_t)B * (Tc + 2) * d.F * 2);
+    ENSX(x.e0, BT * d.Ec * 64); ENSX(x.e1, BT * d.F1 * 64); ENSX(x.e2, BT * d.F2 * 64); ENSX(x.e3, BT * d.F3 * 64);
+    ENSX(x.xe_a, BT * d.F3 * 64); ENSX(x.xe_b, BT * d.F3 * 64);
+    ENSX(x.c0, (size_t)B * (Tc + 4) * d.D * 64); ENSX(x.c1, BT * d.Fd * 64);
+    ENSX(x.xd_a, BT * d.Fd * 64); ENSX(x.xd_b, BT * d.Fd * 64);
+    ENSX(x.pconv, BT * d.D * 10);
+#undef ENSX
+    return DPDF_OK;
+}
+
 int ensure_ws(dpdf_model* m, int B, int Tc) {
     Workspace& w = m->ln->ws;
     {   // hoisted input-side GRU-64 pre-activations (run_dprnn): intra form (2 dirs x 192 per band row) only below 3072
@@ -541,28 +574,20 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
         const size_t need_d = std::max(bt_small * d.Fd * 384, (size_t)B * d.Fd < 64 * 16 ? BT * d.Fd * 192 : (size_t)0);
         const size_t need_e = std::max(bt_small * d.F3 * 384, (size_t)B * d.F3 < 64 * 16 ? BT * d.F3 * 192 : (size_t)0);
         if (need_d > w.gi64.n || need_e > w.gi64_e.n) {
-            (void)hipStreamSynchronize(m->ln->sA); (void)hipStreamSynchronize(m->ln->sB); (void)hipStreamSynchronize(m->ln->sC); (void)hipStreamSynchronize(m->ln->sD);
+            m->ln->sync_all();
             int rc = w.gi64.ensure(need_d); if (rc) return rc;
             rc = w.gi64_e.ensure(need_e); if (rc) return rc;
         }
     }
     if (B <= w.Bcap && Tc <= w.Tcap) return DPDF_OK;    // every size below is monotone in B and Tc
     // growing: make sure nothing in flight still uses the old buffers
-    (void)hipStreamSynchronize(m->ln->sA); (void)hipStreamSynchronize(m->ln->sB); (void)hipStreamSynchronize(m->ln->sC); (void)hipStreamSynchronize(m->ln->sD);
+    m->ln->sync_all();
     B = std::max(B, w.Bcap); Tc = std::max(Tc, w.Tcap);
     const dpdf_dims& d = m->d;
     const size_t BT = (size_t)B * Tc;
     int rc = DPDF_OK;
 #define ENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
-    for (int k = 0; k < 2; ++k) {
-        XSet& x = w.x[k];
-        ENS(x.xs, (size_t)B * (Tc + 2) * d.F * 2);
-        ENS(x.e0, BT * d.Ec * 64); ENS(x.e1, BT * d.F1 * 64); ENS(x.e2, BT * d.F2 * 64); ENS(x.e3, BT * d.F3 * 64);
-        ENS(x.xe_a, BT * d.F3 * 64); ENS(x.xe_b, BT * d.F3 * 64);
-        ENS(x.c0, (size_t)B * (Tc + 4) * d.D * 64); ENS(x.c1, BT * d.Fd * 64);
-        ENS(x.xd_a, BT * d.Fd * 64); ENS(x.xd_b, BT * d.Fd * 64);
-        ENS(x.pconv, BT * d.D * 10);
-    }
+    for (int k = 0; k < 2; ++k) { rc = ensure_xset(m, w.x[k], B, Tc); if (rc) return rc; }
     ENS(w.feat_erb, (size_t)B * (Tc + 2) * d.E);
     ENS(w.feat_spec, (size_t)B * (Tc + 2) * 2 * d.D);
     ENS(w.hcat, BT * d.Fd * 128); ENS(w.hin, BT * d.Fd * 64);
@@ -586,7 +611,7 @@ int ensure_gru_xbuf(dpdf_model* m, int ntiles, int which) {
     Lane& L = *m->ln;
     if (ntiles <= L.gru_xbuf_tiles[which] && L.gru_xbuf[which] && m->d_err) return DPDF_OK;
     if (L.gru_xbuf[which]) {
-        (void)hipStreamSynchronize(L.sA); (void)hipStreamSynchronize(L.sB); (void)hipStreamSynchronize(L.sD);
+        L.sync_all();
         (void)hipFree(L.gru_xbuf[which]); L.gru_xbuf[which] = nullptr;
     }
     const size_t bytes = (size_t)ntiles * 2 * 16 * 256 * 8;
@@ -621,9 +646,10 @@ void run_gl_auto(dpdf_model* m, const GlW& g, const float* in, size_t lda, float
 // handful of workgroups walking all K panels one after the other; narrower column blocks multiply the workgroups.
 constexpr int SMALL_M_ROWS = 512;
 // which: 0 = embedding / ERB-decoder cells (scratch ws.gi, granules [0]); 1 = DF-decoder cells (ws.gi2, granules [1])
-void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int Tc, int which = 0) {
+void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int Tc, int which = 0,
+                float* gi_buf = nullptr) {
     const int M = B * Tc;
-    float* gi = which ? m->ln->ws.gi2.p : m->ln->ws.gi.p;
+    float* gi = gi_buf ? gi_buf : (which ? m->ln->ws.gi2.p : m->ln->ws.gi.p);
     {
         ProfScope ps(m, "gru256_proj");
         PlainA<64> ap{x, 256, 0, 256};
@@ -907,6 +933,51 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     return DPDF_OK;
 }
 
+// ERB decoder convs + mask head (reference onnx_model/dpdfnet.py:361-366) on stream st: dembp [B*Tc][F3][64] -> w.m
+void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStream_t st) {
+    const dpdf_dims& d = m->d; Workspace& w = m->ln->ws;
+    const int BT = B * Tc;
+    m->cur = st;
+    TView e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
+    ProfScope ps(m, "dec_convs");
+    TView dembv{dembp, Tc, 0, d.F3, 64};
+    TView d3v{w.d3.p, Tc, 0, d.F2, 64}, d2v{w.d2.p, Tc, 0, d.F1, 64}, d1v{w.d1.p, Tc, 0, d.Ec, 64};
+    run_subpix_s(m, m->convt3, m->conv3p, e3v, dembv, d3v, B, Tc, d.s3);
+    run_subpix_s(m, m->convt2, m->conv2p, e2v, d3v, d2v, B, Tc, d.s2);
+    if (m->fuse_mask && !d.is48 && d.s1 == 2 && d.Ec == 32 && d.F1 == 16) {
+        // 16 kHz geometry: last decoder stage + mask head in one kernel, m written directly (dec_last.h)
+        DecLastArgs da{x.e1.p, w.d2.p, x.e0.p, w.m.p, m->C(m->conv1p.ps), m->C(m->conv1p.pb), m->C(m->convt1.dw),
+                       m->C(m->convt1.pwfrag), m->C(m->convt1.bias), m->C(m->conv0p.ps), m->C(m->conv0p.pb),
+                       m->C(m->c0out_w), m->c0out_bias, BT};
+        const int ntiles = (BT + 1) / 2;
+        hipLaunchKernelGGL(dec_last_kernel, dim3(std::min(ntiles, 256 * 3 * 4)), dim3(256), 0, st, da);
+    } else if (m->fuse_mask) {
+        // w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
+        if (d.s1 == 2) run_subpix_mask<2>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
+        else run_subpix_mask<3>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
+        MaskFinArgs mf{w.d1.p, w.m.p, m->c0out_bias, BT * d.Ec, d.Ec, d.E, d.is48};
+        hipLaunchKernelGGL(mask_fin_kernel, dim3((BT * d.Ec + 255) / 256), dim3(256), 0, st, mf);
+    } else {
+        run_subpix_s(m, m->convt1, m->conv1p, e1v, d2v, d1v, B, Tc, d.s1);
+        MaskOutArgs ma{x.e0.p, w.d1.p, w.m.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias,
+                       BT * d.Ec, d.Ec, d.E, d.is48};
+        hipLaunchKernelGGL(mask_out_kernel, dim3((BT * d.Ec + 3) / 4), dim3(256), 0, st, ma);
+    }
+}
+// mask + deep filter (layers.py:414-445, multiframe.py:200-232) on stream st
+void run_mask_df(dpdf_model* m, const ChunkArgs& c, XSet& x, hipStream_t st) {
+    const dpdf_dims& d = m->d; Workspace& w = m->ln->ws;
+    const int B = c.B, Tc = c.Tc, BT = B * Tc;
+    m->cur = st;
+    ProfScope ps(m, "mask_df");
+    MaskApplyArgs mk{x.xs.p, w.m.p, w.xm.p, d.is48 ? nullptr : m->iconsts + 33, B, Tc, d.F, d.E};
+    size_t total = (size_t)BT * d.F;
+    hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mk);
+    DfApplyArgs da{w.xm.p, w.coefs.p, c.out, c.out_clip_stride, c.out_t0, c.attn_raw, c.alpha, (float)(1.0 - (double)c.alpha),
+                   B, Tc, d.F, d.D, (float)(1.0 / (double)d.wnorm)};
+    hipLaunchKernelGGL(df_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, da);
+}
+
 int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L;
     Workspace& w = m->ln->ws; XSet& x = w.x[c.parity];
@@ -991,51 +1062,160 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         run_gl_auto(m, m->ed_lin_out, w.g256c.p, 256, w.demb.p, 512, BT, ACT_RELU);
         if (d.is48) { run_gl_auto(m, m->ed_erb_fc, w.demb.p, 512, w.demb2.p, (size_t)d.F3 * 64, BT, ACT_RELU); dembp = w.demb2.p; }
     }
-    {
-        ProfScope ps(m, "dec_convs");
-        TView dembv{dembp, Tc, 0, d.F3, 64};
-        TView d3v{w.d3.p, Tc, 0, d.F2, 64}, d2v{w.d2.p, Tc, 0, d.F1, 64}, d1v{w.d1.p, Tc, 0, d.Ec, 64};
-        run_subpix_s(m, m->convt3, m->conv3p, e3v, dembv, d3v, B, Tc, d.s3);
-        run_subpix_s(m, m->convt2, m->conv2p, e2v, d3v, d2v, B, Tc, d.s2);
-        if (m->fuse_mask && !d.is48 && d.s1 == 2 && d.Ec == 32 && d.F1 == 16) {
-            // 16 kHz geometry: last decoder stage + mask head in one kernel, m written directly (dec_last.h)
-            DecLastArgs da{x.e1.p, w.d2.p, x.e0.p, w.m.p, m->C(m->conv1p.ps), m->C(m->conv1p.pb), m->C(m->convt1.dw),
-                           m->C(m->convt1.pwfrag), m->C(m->convt1.bias), m->C(m->conv0p.ps), m->C(m->conv0p.pb),
-                           m->C(m->c0out_w), m->c0out_bias, BT};
-            const int ntiles = (BT + 1) / 2;
-            hipLaunchKernelGGL(dec_last_kernel, dim3(std::min(ntiles, 256 * 3 * 4)), dim3(256), 0, st, da);
-        } else if (m->fuse_mask) {
-            // w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
-            if (d.s1 == 2) run_subpix_mask<2>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
-            else run_subpix_mask<3>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
-            MaskFinArgs mf{w.d1.p, w.m.p, m->c0out_bias, BT * d.Ec, d.Ec, d.E, d.is48};
-            hipLaunchKernelGGL(mask_fin_kernel, dim3((BT * d.Ec + 255) / 256), dim3(256), 0, st, mf);
-        } else {
-            run_subpix_s(m, m->convt1, m->conv1p, e1v, d2v, d1v, B, Tc, d.s1);
-            MaskOutArgs ma{x.e0.p, w.d1.p, w.m.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias,
-                           BT * d.Ec, d.Ec, d.E, d.is48};
-            hipLaunchKernelGGL(mask_out_kernel, dim3((BT * d.Ec + 3) / 4), dim3(256), 0, st, ma);
-        }
-    }
+    run_dec_convs(m, x, dembp, B, Tc, st);
     if (fork) { HIP_TRY(hipEventRecord(m->ln->ev_djn[c.parity], sd)); HIP_TRY(hipStreamWaitEvent(st, m->ln->ev_djn[c.parity], 0)); }
-    // ---- mask + deep filter (layers.py:414-445, multiframe.py:200-232) ----
-    {
-        ProfScope ps(m, "mask_df");
-        MaskApplyArgs mk{x.xs.p, w.m.p, w.xm.p, d.is48 ? nullptr : m->iconsts + 33, B, Tc, d.F, d.E};
-        size_t total = (size_t)BT * d.F;
-        hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mk);
-        DfApplyArgs da{w.xm.p, w.coefs.p, c.out, c.out_clip_stride, c.out_t0, c.attn_raw, c.alpha, (float)(1.0 - (double)c.alpha),
-                       B, Tc, d.F, d.D, (float)(1.0 / (double)d.wnorm)};
-        hipLaunchKernelGGL(df_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, da);
-    }
+    run_mask_df(m, c, x, st);
     {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;
         hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, st, sio);
     }
     if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_s2[c.parity], st)); m->ln->s2_pending[c.parity] = true; }
+    m->ln->dbg_emb = w.emb.p;
     HIP_TRY(hipGetLastError());
     m->cur = m->ln->sA;
+    return DPDF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2 for SMALL batches as a pipeline of sub-stages across chunks.  With few streams a GRU-256 scan step is pure
+// latency (~4.4 us: MFMAs of 16 rows + one cross-CU exchange), and stage 2 is three scans deep (embedding cell ->
+// decoder cell 0 -> decoder cell 1): one 10 s clip = 3 x 1003 dependent steps = 13.2 ms, the whole call.  The cells
+// only depend on each other chunk-wise, so while cell 1 works on chunk i, cell 0 can work on chunk i+1 and the
+// embedding cell on chunk i+2 -- five cells on five streams, the chain three deep only at the pipeline's ends:
+//   sB: import . embedding linears . GRU enc . linear_out            -> emb[parity]          (ev_a)
+//   sE: ERB decoder linear_in . GRU 0                                -> hbe[parity]          (ev_be)
+//   sD: DF  decoder linear_in . GRU 0                                -> hbd[parity]          (ev_bd)
+//   sG: DF  decoder GRU 1 . skip . df_out (+ pathway) -> coefs                               (ev_cd)
+//   sF: ERB decoder GRU 1 . linear_out . decoder convs -> m ; join sG ; FIFO import . mask . deep filter . export (ev_s2)
+// Each stream sees the chunks in order, so every cell's carried state (its own segment of the flat state) stays
+// ordered; tensors that cross streams are double-buffered by chunk parity and are rewritten only after stage 1 of
+// chunk i+2, which waits for ev_s2 of chunk i; per-cell scratch is private to its stream; every cell has its own
+// granule buffer.  coefs / xm are single buffers: sG's write of chunk i+1 waits for the end of chunk i on sF.
+// For <= 64 streams (four GRU-256 tiles: 5 cells x 32 workgroups leave the chip to stage 1); bit 5 of `overlap`.
+// MEASURED AND LEFT OFF (tools/pipe_sweep.py, tools/trace_model.sh): 1 clip x 10 s 13.3 ms two-stage vs 16.4 / 20.3 / 32.2
+// ms here at 256- / 128- / 64-frame chunks.  The kernel trace shows why: with one clip a chunk is ~120 launches of
+// 5-60 us kernels, stage 1 alone leaves ~1.8 ms of gaps per chunk on its stream (the host enqueues the ERB branch's
+// ~55 launches before the DF branch's), and a deeper pipeline needs MORE, shorter chunks -- the call becomes bound by
+// the host's launch rate, not by the three-deep scan chain.  It would take the whole call as one hipGraph to cash in.
+// ------------------------------------------------------------------------------------------------
+int ensure_pipe_ws(dpdf_model* m, int B, int Tc) {
+    Workspace& w = m->ln->ws;
+    if (B <= w.pipeB && Tc <= w.pipeT) return DPDF_OK;
+    m->ln->sync_all();
+    B = std::max(B, w.pipeB); Tc = std::max(Tc, w.pipeT);
+    const size_t BT = (size_t)B * Tc, BTp = (size_t)((B + 15) & ~15) * Tc;
+    int rc;
+#define ENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
+    for (int k = 0; k < NRING; ++k) { ENS(w.embr[k], BT * 512); ENS(w.hbe[k], BTp * 256); ENS(w.hbd[k], BTp * 256); }
+    for (int k = 2; k < NRING; ++k) { rc = ensure_xset(m, w.x[k], B, Tc); if (rc) return rc; }
+    ENS(w.ge_in, BTp * 256); ENS(w.gi3, BTp * 768); ENS(w.gi4, BTp * 768); ENS(w.gi5, BTp * 768);
+#undef ENS
+    w.pipeB = B; w.pipeT = Tc;
+    return DPDF_OK;
+}
+
+int run_stage2_pipe(dpdf_model* m, const ChunkArgs& c) {
+    const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L;
+    Lane& ln = *m->ln; Workspace& w = ln.ws; XSet& x = w.x[c.parity];
+    const int B = c.B, Tc = c.Tc, BT = B * Tc, p = c.parity;
+    const long S = d.state_size;
+    float* state = c.state;
+    float* emb = w.embr[p].p;
+    StateIoArgs sio = make_sio(m, c, x);
+    sio.seg_lo = 4; sio.seg_hi = 6;                    // DF coefs delay / masked-spec FIFOs
+    const float* e3d = x.e3d; const float* c1d = x.c1d;
+    TView e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
+    TView c0v{x.c0.p, Tc + 4, 4, d.D, 64};
+    // ---- sB: embedding (dpdfnet.py:233-241) ----
+    m->cur = ln.sB;
+    HIP_TRY(hipStreamWaitEvent(ln.sB, ln.ev_s1[p], 0));
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->df_fc_emb, c1d, (size_t)d.Fd * 64, w.embin.p + 512, 1024, BT, ACT_RELU);
+        if (d.is48) run_gl_auto(m, m->enc_erb_fc, e3d, (size_t)d.F3 * 64, w.embin.p, 1024, BT, ACT_RELU);
+        else HIP_TRY(hipMemcpy2DAsync(w.embin.p, 1024 * sizeof(float), e3d, 512 * sizeof(float), 512 * sizeof(float), BT,
+                                      hipMemcpyDeviceToDevice, ln.sB));
+        run_gl_auto(m, m->enc_lin_in, w.embin.p, 1024, w.g256a.p, 256, BT, ACT_RELU);
+    }
+    run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc, 0, w.gi.p);
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->enc_lin_out, w.g256b.p, 256, emb, 512, BT, ACT_RELU);
+    }
+    HIP_TRY(hipEventRecord(ln.ev_a[p], ln.sB));
+    // ---- sE: ERB decoder, cell 0 ----
+    m->cur = ln.sE;
+    HIP_TRY(hipStreamWaitEvent(ln.sE, ln.ev_a[p], 0));
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->ed_lin_in, emb, 512, w.ge_in.p, 256, BT, ACT_RELU);
+    }
+    run_gru256(m, m->ed_gru0, w.ge_in.p, w.hbe[p].p, state, S, L.erb_dec_gru, B, Tc, 2, w.gi3.p);
+    HIP_TRY(hipEventRecord(ln.ev_be[p], ln.sE));
+    // ---- sD: DF decoder, cell 0 ----
+    m->cur = ln.sD;
+    HIP_TRY(hipStreamWaitEvent(ln.sD, ln.ev_a[p], 0));
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->df_lin_in, emb, 512, w.g256d.p, 256, BT, ACT_RELU);
+    }
+    run_gru256(m, m->df_gru0, w.g256d.p, w.hbd[p].p, state, S, L.df_dec_gru, B, Tc, 1, w.gi2.p);
+    HIP_TRY(hipEventRecord(ln.ev_bd[p], ln.sD));
+    // ---- sG: DF decoder, cell 1 + taps (dpdfnet.py:486-519) ----
+    m->cur = ln.sG;
+    HIP_TRY(hipStreamWaitEvent(ln.sG, ln.ev_bd[p], 0));
+    run_gru256(m, m->df_gru1, w.hbd[p].p, w.g256f.p, state, S, L.df_dec_gru + 256, B, Tc, 4, w.gi5.p);
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->df_skip, emb, 512, w.g256e.p, 256, BT, ACT_NONE);   // c = df_gru(emb) + df_skip(emb)
+    }
+    if (ln.prev_slot >= 0 && ln.s2_pending[ln.prev_slot]) HIP_TRY(hipStreamWaitEvent(ln.sG, ln.ev_s2[ln.prev_slot], 0));   // coefs / dfo of the previous chunk consumed
+    {
+        ProfScope ps(m, "df_coefs");
+        size_t n = (size_t)BT * 256;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(axpy_kernel), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ln.sG, w.g256f.p, w.g256e.p, n);
+        if (x.have_pconv) {
+            const GlW& g = m->df_out;
+            PlainA<16> ap{w.g256f.p, 256, g.Ig, g.Ig};
+            DfOutEpi ep{w.coefs.p, Tc, FastDiv::make(Tc), x.pconv.p, m->C(g.bias), g.Og};
+            launch_gemm_rows<4, 16, false>(ln.sG, ap, m->C(g.frag), ep, BT, g.Ig, g.G);
+        } else {
+            run_gl_auto(m, m->df_out, w.g256f.p, 256, w.dfo.p, (size_t)d.D * 10, BT, ACT_TANH);
+            RowMap rm = RowMap::make(Tc, d.D);
+            ConvpA ap{c0v, rm};
+            ConvpEpi ep{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
+            launch_gemm_rows<1, 64, false>(ln.sG, ap, m->C(m->convp_frag), ep, BT * d.D, 320, 1);
+        }
+    }
+    HIP_TRY(hipEventRecord(ln.ev_cd[p], ln.sG));
+    // ---- sF: ERB decoder, cell 1 + convs (dpdfnet.py:343-368), then mask + deep filter ----
+    m->cur = ln.sF;
+    HIP_TRY(hipStreamWaitEvent(ln.sF, ln.ev_be[p], 0));
+    run_gru256(m, m->ed_gru1, w.hbe[p].p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc, 3, w.gi4.p);
+    float* dembp = w.demb.p;
+    {
+        ProfScope ps(m, "grouped_linear");
+        run_gl_auto(m, m->ed_lin_out, w.g256c.p, 256, w.demb.p, 512, BT, ACT_RELU);
+        if (d.is48) { run_gl_auto(m, m->ed_erb_fc, w.demb.p, 512, w.demb2.p, (size_t)d.F3 * 64, BT, ACT_RELU); dembp = w.demb2.p; }
+    }
+    run_dec_convs(m, x, dembp, B, Tc, ln.sF);
+    HIP_TRY(hipStreamWaitEvent(ln.sF, ln.ev_cd[p], 0));
+    {
+        ProfScope ps(m, "state_io");
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, ln.sF, sio);
+    }
+    run_mask_df(m, c, x, ln.sF);
+    {
+        ProfScope ps(m, "state_io");
+        sio.do_export = 1;
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, ln.sF, sio);
+    }
+    HIP_TRY(hipEventRecord(ln.ev_s2[p], ln.sF)); ln.s2_pending[p] = true;
+    ln.prev_slot = p;
+    ln.dbg_emb = emb;
+    HIP_TRY(hipGetLastError());
+    m->cur = ln.sA;
     return DPDF_OK;
 }
 
@@ -1052,13 +1232,17 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     // chunk_frames: >0 explicit, <0 whole sequence, 0 auto: ~32k frames per launch wave, but never more than 256 per
     // chunk -- a small batch is latency-bound and wants several chunks so that stage 2 of one runs under stage 1 of the
     // next (tools/latency_bench.py --chunks: 1 clip x 10 s 22.0 -> 18.2 ms, 32 clips 39.3 -> 29.7 ms)
+    // <= 64 streams: stage 2 as a pipeline of sub-stages across chunks (run_stage2_pipe); its fill and drain are two
+    // sub-stages long, so it wants shorter chunks than the two-stage pipeline
+    const bool pipe2 = (m->overlap & 32) && (m->overlap & 1) && !two && B <= 64 && m->use_gru256_cluster;
     int chunk = T;
     if (m->chunk_frames > 0) chunk = std::min(m->chunk_frames, T);
-    else if (m->chunk_frames == 0) chunk = std::min(T, std::min(256, std::max(64, (32768 + Bg[0] - 1) / Bg[0])));
+    else if (m->chunk_frames == 0) chunk = std::min(T, std::min(pipe2 ? m->pipe_chunk : 256, std::max(64, (32768 + Bg[0] - 1) / Bg[0])));
     int rc;
     for (int g = 0; g < G; ++g) {
         m->ln = &m->lanes[g];
         if ((rc = ensure_ws(m, Bg[g], chunk))) { m->ln = &m->lanes[0]; return rc; }
+        if (pipe2 && (rc = ensure_pipe_ws(m, Bg[g], chunk))) { m->ln = &m->lanes[0]; return rc; }
     }
     if (two) {       // lane 1 starts after everything already queued on the main stream
         HIP_TRY(hipEventRecord(m->lanes[0].ev_fork, m->stream));
@@ -1074,15 +1258,16 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
             m->ln = &m->lanes[g];
             ChunkArgs c{raw + (size_t)b0 * clip_stride + (size_t)t0 * d.F * 2, clip_stride, Bg[g], sizes[ci],
                         state + (size_t)b0 * d.state_size, out + (size_t)b0 * clip_stride, clip_stride, t0,
-                        attn_raw ? attn_raw + (size_t)b0 * clip_stride : nullptr, alpha, i & 1};
-            if ((rc = run_stage1(m, c)) || (rc = run_stage2(m, c))) { m->ln = &m->lanes[0]; return rc; }
+                        attn_raw ? attn_raw + (size_t)b0 * clip_stride : nullptr, alpha, pipe2 ? i % NRING : (i & 1)};
+            if ((rc = run_stage1(m, c)) || (rc = (pipe2 ? run_stage2_pipe(m, c) : run_stage2(m, c)))) { m->ln = &m->lanes[0]; return rc; }
             b0 += Bg[g];
         }
     }
     for (int g = 0; g < G; ++g) {
         Lane& L = m->lanes[g];
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < NRING; ++p)
             if (L.s2_pending[p]) { HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_s2[p], 0)); L.s2_pending[p] = false; }
+        L.prev_slot = -1;
         if (g > 0) { HIP_TRY(hipEventRecord(L.ev_done, L.sA)); HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_done, 0)); }
     }
     m->ln = &m->lanes[0];
@@ -1246,7 +1431,18 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
             HIP_TRY(hipStreamCreateWithPriority(&L.sD, hipStreamNonBlocking, hi));
         }
-        for (int p = 0; p < 2; ++p) {
+        {
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&L.sE, hipStreamNonBlocking, hi));
+            HIP_TRY(hipStreamCreateWithPriority(&L.sF, hipStreamNonBlocking, hi));
+            HIP_TRY(hipStreamCreateWithPriority(&L.sG, hipStreamNonBlocking, hi));
+        }
+        for (int p = 0; p < NRING; ++p) {
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_a[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_be[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_bd[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_cd[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_s1[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_s2[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_fk[p], hipEventDisableTiming));
@@ -1297,12 +1493,9 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     (void)hipSetDevice(m->device);
     for (int g = 0; g < 2; ++g) {
         Lane& L = m->lanes[g];
-        if (L.sA) (void)hipStreamSynchronize(L.sA);
-        if (L.sB) (void)hipStreamSynchronize(L.sB);
-        if (L.sC) (void)hipStreamSynchronize(L.sC);
+        L.sync_all();
         L.ws.release();
-        if (L.sD) (void)hipStreamSynchronize(L.sD);
-        for (int k = 0; k < 2; ++k) if (L.gru_xbuf[k]) (void)hipFree(L.gru_xbuf[k]);
+        for (int k = 0; k < 5; ++k) if (L.gru_xbuf[k]) (void)hipFree(L.gru_xbuf[k]);
     }
     DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state};
     for (DevBuf* b : bufs) b->release();
@@ -1316,13 +1509,17 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     for (int g = 0; g < 2; ++g) {
         Lane& L = m->lanes[g];
-        for (int p = 0; p < 2; ++p) { if (L.ev_s1[p]) (void)hipEventDestroy(L.ev_s1[p]); if (L.ev_s2[p]) (void)hipEventDestroy(L.ev_s2[p]); if (L.ev_fk[p]) (void)hipEventDestroy(L.ev_fk[p]); if (L.ev_jn[p]) (void)hipEventDestroy(L.ev_jn[p]); if (L.ev_dfk[p]) (void)hipEventDestroy(L.ev_dfk[p]); if (L.ev_djn[p]) (void)hipEventDestroy(L.ev_djn[p]); }
+        for (int p = 0; p < NRING; ++p) { if (L.ev_s1[p]) (void)hipEventDestroy(L.ev_s1[p]); if (L.ev_s2[p]) (void)hipEventDestroy(L.ev_s2[p]); if (L.ev_fk[p]) (void)hipEventDestroy(L.ev_fk[p]); if (L.ev_jn[p]) (void)hipEventDestroy(L.ev_jn[p]); if (L.ev_dfk[p]) (void)hipEventDestroy(L.ev_dfk[p]); if (L.ev_djn[p]) (void)hipEventDestroy(L.ev_djn[p]); }
         if (L.ev_fork) (void)hipEventDestroy(L.ev_fork);
         if (L.ev_join) (void)hipEventDestroy(L.ev_join);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+        for (int p = 0; p < NRING; ++p) { if (L.ev_a[p]) (void)hipEventDestroy(L.ev_a[p]); if (L.ev_be[p]) (void)hipEventDestroy(L.ev_be[p]); if (L.ev_bd[p]) (void)hipEventDestroy(L.ev_bd[p]); if (L.ev_cd[p]) (void)hipEventDestroy(L.ev_cd[p]); }
         if (L.sB) (void)hipStreamDestroy(L.sB);
         if (L.sC) (void)hipStreamDestroy(L.sC);
         if (L.sD) (void)hipStreamDestroy(L.sD);
+        if (L.sE) (void)hipStreamDestroy(L.sE);
+        if (L.sF) (void)hipStreamDestroy(L.sF);
+        if (L.sG) (void)hipStreamDestroy(L.sG);
         if (L.sA) (void)hipStreamDestroy(L.sA);
     }
     delete m;
@@ -1366,7 +1563,7 @@ extern "C" int dpdf_set_overlap(dpdf_model* m, int on) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
     std::lock_guard<std::mutex> lk(m->mu);
     (void)hipSetDevice(m->device);
-    for (int g = 0; g < 2; ++g) { (void)hipStreamSynchronize(m->lanes[g].sA); (void)hipStreamSynchronize(m->lanes[g].sB); (void)hipStreamSynchronize(m->lanes[g].sC); (void)hipStreamSynchronize(m->lanes[g].sD); }
+    for (int g = 0; g < 2; ++g) m->lanes[g].sync_all();
     m->overlap = on;
     return DPDF_OK;
 }
@@ -1381,10 +1578,11 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     if (!m || !name) return set_err(DPDF_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(m->mu);
     (void)hipSetDevice(m->device);
-    for (int g = 0; g < 2; ++g) { (void)hipStreamSynchronize(m->lanes[g].sA); (void)hipStreamSynchronize(m->lanes[g].sB); (void)hipStreamSynchronize(m->lanes[g].sC); (void)hipStreamSynchronize(m->lanes[g].sD); }
+    for (int g = 0; g < 2; ++g) m->lanes[g].sync_all();
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
     else if (n == "df_ring") m->df_ring = value != 0;
+    else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
     else if (n == "gru256_pair") m->gru256_pair = (value >= 2 && value <= 4) ? value : 0;
     else if (n == "gru256_cluster") m->use_gru256_cluster = value != 0;
@@ -1703,7 +1901,7 @@ extern "C" long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, l
     else if (s == "c0") { src = x.c0.p; n = B * (Tc + 4) * d.D * 64; }
     else if (s == "c1") { src = x.c1.p; n = BT * d.Fd * 64; }
     else if (s == "c1_dprnn") { src = L0.dbg_c1d; n = BT * d.Fd * 64; }
-    else if (s == "emb") { src = w.emb.p; n = BT * 512; }
+    else if (s == "emb") { src = L0.dbg_emb ? L0.dbg_emb : w.emb.p; n = BT * 512; }
     else if (s == "m") { src = w.m.p; n = BT * d.E; }
     else if (s == "coefs") { src = w.coefs.p; n = B * (Tc + 2) * d.D * 10; }
     else if (s == "xm") { src = w.xm.p; n = B * (Tc + 4) * d.F * 2; }

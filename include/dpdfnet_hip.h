@@ -114,8 +114,9 @@ int dpdf_set_chunk_frames(dpdf_model* m, int frames);
 /* Execution-shape mask (default 27 = 1|2|8|16): bit 0 stage 2 of chunk i (GRU-256 scans, decoders) on its own HIP stream
  * underneath stage 1 of chunk i+1; bit 1 the ERB encoder branch on its own stream; bit 2 split the batch over two lanes
  * (measured slower, off); bit 3 the DF decoder beside the ERB decoder inside stage 2; bit 4 eight (not four) workgroups per
- * tile in the GRU-256 cluster scans of small launches.  0: everything serial on one
- * stream (A/B timing). */
+ * tile in the GRU-256 cluster scans of small launches; bit 5 (off: measured slower, host-launch-bound) for <= 64
+ * streams stage 2 as a pipeline of sub-stages across chunks (the five GRU-256 cells on five streams).  0: everything
+ * serial on one stream (A/B timing). */
 int dpdf_set_overlap(dpdf_model* m, int mask);
 /* Where fc + LayerNorm + residual of every DPRNN block run: 2 always inside the GRU-64 scan kernels;
  * 0 always as separate GEMM kernels; 1 (default) picks per chunk -- fused once streams x frames fills the

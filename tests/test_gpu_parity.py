@@ -59,8 +59,9 @@ def test_stage_tensors_match_reference_probes(case, be):
     g, meta, o, m = case
     spec = o.stft(g["wav"])
     T = spec.shape[0]
-    m.set_chunk_frames(0)
+    m.set_chunk_frames(-1)                      # the whole sequence as ONE chunk: debug_fetch returns the last chunk's tensors
     m.run_frames(spec, m.initial_state())
+    m.set_chunk_frames(0)
     d = be.query_dims(meta["sample_rate"], meta["nb"])
     shapes = {"e0": d.Ec, "e1": d.F1, "e2": d.F2, "e3": d.F3, "e3_dprnn": d.F3, "c1": d.Fd, "c1_dprnn": d.Fd}
     checked = 0
@@ -93,6 +94,7 @@ def test_stage_tensors_match_reference_probes(case, be):
 
 @pytest.mark.parametrize("chunk", [1, 3, 16, 50])
 def test_time_chunking_and_state_carry_invariance(case, chunk):
+    # both execution shapes of stage 2: the two-stage pipeline (default) and the opt-in sub-stage pipeline (ring of 4 chunk slots)
     """Splitting T frames into chunks (state carried in the reference flat layout) changes nothing;
     chunk = 1 is literally one session.run per frame."""
     g, meta, o, m = case
@@ -101,7 +103,12 @@ def test_time_chunking_and_state_carry_invariance(case, chunk):
     ref, st_ref = m.run_frames(spec, m.initial_state())
     m.set_chunk_frames(chunk)
     out, st = m.run_frames(spec, m.initial_state())
+    m.set_overlap(59)
+    out59, st59 = m.run_frames(spec, m.initial_state())
+    m.set_overlap(27)
     m.set_chunk_frames(0)
+    np.testing.assert_allclose(out59, out, atol=1e-5 * float(np.abs(ref).max()))
+    np.testing.assert_allclose(st59, st, rtol=5e-6, atol=2e-5 * max(1.0, meta["nb"] / 4.0))
     np.testing.assert_allclose(out, ref, atol=1e-5 * float(np.abs(ref).max()))
     # different chunk lengths pick different kernel forms of the recurrences (fused / hoisted-input / plain): equal to
     # rounding, and the rounding differences of a DPRNN stack grow with its depth (8 blocks: 2.1e-5 seen on one state value)
@@ -134,14 +141,16 @@ def test_single_frame_chunks_are_race_free_under_stream_overlap(case):
     m.set_chunk_frames(0)
     ref, st_ref = m.run_frames(spec, m.initial_state())
     m.set_chunk_frames(1)
-    m.set_overlap(27)
     try:
-        for _ in range(60):
-            out, st = m.run_frames(spec, m.initial_state())
-            assert np.abs(out - ref).max() < 1e-5 * float(np.abs(ref).max())
-            np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5)
+        for mask in (27, 59):                   # 59: also the (opt-in) five-stream sub-stage pipeline of stage 2
+            m.set_overlap(mask)
+            for _ in range(40):
+                out, st = m.run_frames(spec, m.initial_state())
+                assert np.abs(out - ref).max() < 1e-5 * float(np.abs(ref).max())
+                np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5)
     finally:
         m.set_chunk_frames(0)
+        m.set_overlap(27)
 
 
 def test_frame_by_frame_host_loop_is_a_drop_in_for_session_run(case):
