@@ -384,7 +384,6 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
         rt = blockIdx.x >> 2; j = blockIdx.x & 3;
     }
     const int row0 = rt * 16;
-    const int nvalid = a.B - row0 < 16 ? a.B - row0 : 16;      // rows of this tile that hold a stream
     const int u0 = 64 * j + 16 * w;            // first hidden unit of this wave
 
     float wr[64], wz[64], wn[64];
@@ -454,15 +453,12 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
             float n = gru_candidate(r, ahn[i], axn[i]);
             h_own[i] = gru_blend(z, n, h_own[i]);
         }
-        // publish first (the peers' next step waits on these), then the local copies.  Only rows that hold a stream
-        // are exchanged (nvalid < 16 in the last tile, e.g. 1 for a single clip): a one-clip step moves 192 granules per
-        // workgroup instead of 3072 (1 clip x 10 s: 13.4 -> 13.2 ms -- the exchange is latency, not volume).
+        // publish first (the peers' next step waits on these), then the local copies
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (ok[i])
-                __hip_atomic_store(slot + (q * 4 + i) * 256 + u0 + cl,
-                                   ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(h_own[i]),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + (q * 4 + i) * 256 + u0 + cl,
+                               ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(h_own[i]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             Hs[nxt][q * 4 + i][u0 + cl] = h_own[i];
@@ -482,8 +478,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
                 for (int k = 0; k < 12; ++k) {
                     const int idx = tid + 256 * k;
                     const int s = idx >> 10, r = (idx >> 6) & 15, u = 64 * ((j + 1 + s) & 3) + (idx & 63);
-                    xv[k] = r < nvalid ? __hip_atomic_load(slot + r * 256 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                       : ((unsigned long long)epoch << 32);      // a padding row: nothing to wait for
+                    xv[k] = __hip_atomic_load(slot + r * 256 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
                 for (int k = 0; k < 12; ++k) all_in &= (unsigned)(xv[k] >> 32) == epoch;
@@ -495,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
             for (int k = 0; k < 12; ++k) {
                 const int idx = tid + 256 * k;
                 const int s = idx >> 10, r = (idx >> 6) & 15, u = 64 * ((j + 1 + s) & 3) + (idx & 63);
-                if (r < nvalid) Hs[nxt][r][u] = __uint_as_float((unsigned)xv[k]);
+                Hs[nxt][r][u] = __uint_as_float((unsigned)xv[k]);
             }
         }
         __syncthreads();
@@ -729,7 +724,6 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster8_kernel(Gru256CArgs a) 
         rt = blockIdx.x >> 3; j = blockIdx.x & 7;
     }
     const int row0 = rt * 16;
-    const int nvalid = a.B - row0 < 16 ? a.B - row0 : 16;      // rows of this tile that hold a stream (see gru256_cluster_kernel)
     const int u0 = 32 * j + 16 * uh;           // first hidden unit of this wave's column block
 
     float wr[32], wz[32], wn[32];              // K half kh: chunks [8 kh, 8 kh + 8)
@@ -813,10 +807,9 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster8_kernel(Gru256CArgs a) 
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-            if (ok[e])
-                __hip_atomic_store(slot + (q * 4 + 2 * kh + e) * 256 + u0 + cl,
-                                   ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(h_own[e]),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + (q * 4 + 2 * kh + e) * 256 + u0 + cl,
+                               ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(h_own[e]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             Hs[nxt][q * 4 + 2 * kh + e][u0 + cl] = h_own[e];
@@ -833,8 +826,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster8_kernel(Gru256CArgs a) 
                 for (int k = 0; k < 14; ++k) {
                     const int idx = tid + 256 * k;
                     const int s = idx >> 9, r = (idx >> 5) & 15, u = 32 * ((j + 1 + s) & 7) + (idx & 31);
-                    xv[k] = r < nvalid ? __hip_atomic_load(slot + r * 256 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                       : ((unsigned long long)epoch << 32);      // a padding row: nothing to wait for
+                    xv[k] = __hip_atomic_load(slot + r * 256 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
                 for (int k = 0; k < 14; ++k) all_in &= (unsigned)(xv[k] >> 32) == epoch;
@@ -846,7 +838,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster8_kernel(Gru256CArgs a) 
             for (int k = 0; k < 14; ++k) {
                 const int idx = tid + 256 * k;
                 const int s = idx >> 9, r = (idx >> 5) & 15, u = 32 * ((j + 1 + s) & 7) + (idx & 31);
-                if (r < nvalid) Hs[nxt][r][u] = __uint_as_float((unsigned)xv[k]);
+                Hs[nxt][r][u] = __uint_as_float((unsigned)xv[k]);
             }
         }
         __syncthreads();
