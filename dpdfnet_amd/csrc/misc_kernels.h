@@ -364,12 +364,20 @@ __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
         float* t0 = a.c0 + ((size_t)b * (Tc + 4) + 4) * fsz;
         const int j = jz;
         if (j >= (a.do_export ? 0 : 1) && j < 5) {
+            // a [64][D] <-> [D][64] transpose per frame: through LDS, so that BOTH sides move whole cache lines (the
+            // direct form touched 64 lines per wave on the tensor side: 29 us per launch of the headline workload)
+            __shared__ float Tt[64][97];                                    // D = 96 (+1: conflict-free columns)
             long tf = a.do_export ? (long)Tc - 5 + j : (long)j - 5;
             float* tp = t0 + tf * fsz;
             float* sp = st + a.off_convp + (long)j * fsz;
-            for (long i = tid; i < fsz; i += 256) {
-                int c = (int)(i / a.D), f = (int)(i - (long)c * a.D);       // state index = c*D + f
-                if (a.do_export) sp[i] = tp[(long)f * 64 + c]; else tp[(long)f * 64 + c] = sp[i];
+            if (a.do_export) {
+                for (int i = tid; i < (int)fsz; i += 256) Tt[i & 63][i >> 6] = tp[i];          // tensor index = f*64 + c
+                __syncthreads();
+                for (int i = tid; i < (int)fsz; i += 256) { int c = i / a.D; sp[i] = Tt[c][i - c * a.D]; }   // state index = c*D + f
+            } else {
+                for (int i = tid; i < (int)fsz; i += 256) { int c = i / a.D; Tt[c][i - c * a.D] = sp[i]; }
+                __syncthreads();
+                for (int i = tid; i < (int)fsz; i += 256) tp[i] = Tt[i & 63][i >> 6];
             }
         }
     } else if (seg == 4) {
