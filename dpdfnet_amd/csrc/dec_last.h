@@ -162,3 +162,122 @@ __global__ __launch_bounds__(256, 2) void dec_last_kernel(DecLastArgs a) {
         // them (U1: depthwise, E0: mask head); As and Ss are rewritten only after the next iteration's first barrier
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// dec_stage_kernel<S, FO>: an inner ERB-decoder stage d_out = convt(conv_p(e) + d_in) (reference
+// onnx_model/dpdfnet.py:361-364; sub-pixel S = 2 or plain S = 1 depthwise k(1,3) + pointwise + BN + ReLU) for
+// geometries where a 64-row tile is a whole number of frames (16 kHz: FO = 8 or 16 output bands).  Same plan as
+// dec_last_kernel: the two input tiles are contiguous and loaded once, coalesced; u = relu(ps e + pb) + d_in once
+// per element into LDS; depthwise panel from LDS; pointwise GEMM; the output tile leaves through LDS as whole rows.
+struct DecStageArgs {
+    const float* e; const float* prev;  // [BT][FO/S][64]
+    float* out;                         // [BT][FO][64]
+    const float* ps; const float* pb;   // pathway conv folded [64]
+    const float* dw;                    // [S][64][3]
+    const float* pwfrag; const float* bias;
+    int BT;
+};
+template <int S, int FO>
+__global__ __launch_bounds__(256, 2) void dec_stage_kernel(DecStageArgs a) {
+    constexpr int FI = FO / S, NF = 64 / FO, NIN = 64 / S;              // input bands, frames per tile, input rows per tile
+    constexpr int NL = NIN * 16 / 256;                                   // float4 pieces per thread and tensor (S=1: 4, S=2: 2)
+    static_assert(64 % FO == 0 && FO % S == 0 && NL >= 1, "tile must hold whole frames");
+    __shared__ __attribute__((aligned(16))) float U1[NF][FI + 2][68];
+    __shared__ __attribute__((aligned(16))) float As[64][68];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, q = lane >> 4;
+    const int c4 = (tid & 15) * 4;
+    float breg[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) breg[i] = a.pwfrag[(size_t)i * 64 + lane];
+    const float4 s1 = *(const float4*)(a.ps + c4), b1 = *(const float4*)(a.pb + c4);
+    float dwv[S][4][3];
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dwv[k][j][t] = a.dw[((size_t)k * 64 + c4 + j) * 3 + t];
+    float bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bv[nt] = a.bias[nt * 16 + cl];
+    for (int i = tid; i < NF * 2 * 17; i += 256) {                       // zero the padding bands once
+        const int fr = i / 34, rem = i - fr * 34;
+        *(float4*)&U1[fr][rem / 17 ? FI + 1 : 0][(rem % 17) * 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int ntiles = (a.BT + NF - 1) / NF;
+    auto load_tile = [&](int tile, float4 (&ve)[NL], float4 (&vp)[NL]) __attribute__((always_inline)) {
+        const size_t row0 = (size_t)tile * NIN;                          // first input row (frame-major, FI rows per frame)
+        const size_t nrows = (size_t)a.BT * FI;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + 256 * i;
+            const bool ok = row0 + (idx >> 4) < nrows;
+            ve[i] = ok ? *(const float4*)(a.e + row0 * 64 + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vp[i] = ok ? *(const float4*)(a.prev + row0 * 64 + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    float4 ve[NL], vp[NL];
+    load_tile(tile, ve, vp);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int row = (tid >> 4) + 16 * i, fr = row / FI, band = row - fr * FI;
+            float4 u;
+            u.x = fmaxf(__builtin_fmaf(s1.x, ve[i].x, b1.x), 0.f) + vp[i].x; u.y = fmaxf(__builtin_fmaf(s1.y, ve[i].y, b1.y), 0.f) + vp[i].y;
+            u.z = fmaxf(__builtin_fmaf(s1.z, ve[i].z, b1.z), 0.f) + vp[i].z; u.w = fmaxf(__builtin_fmaf(s1.w, ve[i].w, b1.w), 0.f) + vp[i].w;
+            *(float4*)&U1[fr][1 + band][c4] = u;
+        }
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next, ve, vp);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 4) + 16 * i, fr = r / FO, fo = r - fr * FO, f = fo / S, k = fo - f * S;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float4 x = *(const float4*)&U1[fr][f + t][c4];
+                v.x += (S > 1 && k ? dwv[S - 1][0][t] : dwv[0][0][t]) * x.x; v.y += (S > 1 && k ? dwv[S - 1][1][t] : dwv[0][1][t]) * x.y;
+                v.z += (S > 1 && k ? dwv[S - 1][2][t] : dwv[0][2][t]) * x.z; v.w += (S > 1 && k ? dwv[S - 1][3][t] : dwv[0][3][t]) * x.w;
+            }
+            *(float4*)&As[r][c4] = v;
+        }
+        __syncthreads();
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* arow = &As[16 * w + cl][4 * q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 a4 = *(const float4*)(arow + 16 * c);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int bi = (c * 4 + nt) * 4;
+                acc[nt] = mfma16(a4.x, breg[bi + 0], acc[nt]);
+                acc[nt] = mfma16(a4.y, breg[bi + 1], acc[nt]);
+                acc[nt] = mfma16(a4.z, breg[bi + 2], acc[nt]);
+                acc[nt] = mfma16(a4.w, breg[bi + 3], acc[nt]);
+            }
+        }
+        // out tile through LDS: wave w overwrites only the rows it has just read (As[16 w ..]) -- no barrier needed before
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) As[16 * w + 4 * q + i][nt * 16 + cl] = fmaxf(acc[nt][i] + bv[nt], 0.f);
+        __syncthreads();
+        {
+            const size_t orow0 = (size_t)tile * 64, nrows = (size_t)a.BT * FO;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (tid >> 4) + 16 * i;
+                if (orow0 + r < nrows) *(float4*)(a.out + (orow0 + r) * 64 + c4) = *(const float4*)&As[r][c4];
+            }
+        }
+        // U1 is rewritten at the top of the next iteration: its last readers (depthwise) are two barriers back; As is
+        // rewritten after the next iteration's first barrier, i.e. after every thread has finished the read-out above
+    }
+}

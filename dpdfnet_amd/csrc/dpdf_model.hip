@@ -942,8 +942,17 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
     ProfScope ps(m, "dec_convs");
     TView dembv{dembp, Tc, 0, d.F3, 64};
     TView d3v{w.d3.p, Tc, 0, d.F2, 64}, d2v{w.d2.p, Tc, 0, d.F1, 64}, d1v{w.d1.p, Tc, 0, d.Ec, 64};
-    run_subpix_s(m, m->convt3, m->conv3p, e3v, dembv, d3v, B, Tc, d.s3);
-    run_subpix_s(m, m->convt2, m->conv2p, e2v, d3v, d2v, B, Tc, d.s2);
+    const bool geo16 = m->fuse_mask && !d.is48 && d.s1 == 2 && d.s2 == 2 && d.s3 == 1 && d.Ec == 32 && d.F1 == 16 && d.F2 == 8 && d.F3 == 8;
+    if (geo16) {    // 16 kHz geometry: whole frames per 64-row tile, inputs loaded once (dec_last.h)
+        const int cap = 256 * 3 * 4;
+        DecStageArgs a3{x.e3.p, dembp, w.d3.p, m->C(m->conv3p.ps), m->C(m->conv3p.pb), m->C(m->convt3.dw), m->C(m->convt3.pwfrag), m->C(m->convt3.bias), BT};
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_stage_kernel<1, 8>), dim3(std::min((BT + 7) / 8, cap)), dim3(256), 0, st, a3);
+        DecStageArgs a2{x.e2.p, w.d3.p, w.d2.p, m->C(m->conv2p.ps), m->C(m->conv2p.pb), m->C(m->convt2.dw), m->C(m->convt2.pwfrag), m->C(m->convt2.bias), BT};
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_stage_kernel<2, 16>), dim3(std::min((BT + 3) / 4, cap)), dim3(256), 0, st, a2);
+    } else {
+        run_subpix_s(m, m->convt3, m->conv3p, e3v, dembv, d3v, B, Tc, d.s3);
+        run_subpix_s(m, m->convt2, m->conv2p, e2v, d3v, d2v, B, Tc, d.s2);
+    }
     if (m->fuse_mask && !d.is48 && d.s1 == 2 && d.Ec == 32 && d.F1 == 16) {
         // 16 kHz geometry: last decoder stage + mask head in one kernel, m written directly (dec_last.h)
         DecLastArgs da{x.e1.p, w.d2.p, x.e0.p, w.m.p, m->C(m->conv1p.ps), m->C(m->conv1p.pb), m->C(m->convt1.dw),
