@@ -20,7 +20,8 @@
 #include "common.h"
 
 struct DfRingArgs {
-    const float* c0;       // [B][4 + Tc][96][64]: 4 halo frames (imported from the state FIFO) in front of each clip
+    float* c0;             // [B][4 + Tc][96][64]: 4 halo frames (imported from the state FIFO) in front of each clip.
+                           // CONV0: only the halo is read and only the last five frames of the chunk are written (state export)
     float* c1;             // [B*Tc][48][64]
     float* p;              // [B*Tc][96][10]
     const float* dw;       // df_conv1 depthwise [64][3]
@@ -29,13 +30,23 @@ struct DfRingArgs {
     const float* cpfrag;   // pathway [320 -> 16], fragments [chunk 20][kb 4][lane 64]
     const float* cpbias;   // [10]
     int B, Tc;
+    // CONV0 = true: df_conv0 itself runs here as well (c0 is never written to HBM except the frames the state FIFO needs)
+    const float* fs;       // feat_spec [B][2 + Tc][2][96]: halo 2
+    const float* c0frag;   // df_conv0 folded [32 -> 64] (gemm_rows.h Conv0DfA: k = kt*8 + g*4 + kf), fragments [chunk 2][tile 4][kb 4][lane 64]
+    const float* c0bias;   // [64]
 };
 
+// CONV0: c0[t] of the tile is computed from the feature frames t-2..t (kept in a 3-slot LDS ring) straight into the ring
+// slot -- [33 (48) rows x K = 32] . [32 x 64], wave = 16-column tile, 24 MFMAs -- instead of being loaded: the 805 MB per
+// launch that df_conv0 wrote and this kernel read back disappear, and so does the df_conv0 launch (HBM-write-bound at
+// 3.5 TB/s, 1.8 ms per step).
+template <bool CONV0>
 __global__ __launch_bounds__(256, 3) void df_ring_kernel(DfRingArgs a) {
     constexpr int D = 96, FD = 48;
     __shared__ __attribute__((aligned(16))) float R[5][33][68];     // ring of frames; row 0 = halo band f0-1, rows 1..32 = bands f0..f0+31
     __shared__ __attribute__((aligned(16))) float A1[16][68];       // depthwise output rows of the newest frame
     __shared__ float Pz[2][4][64];                                  // pathway partial sums of the upper K half
+    __shared__ float FSr[CONV0 ? 3 : 1][2][CONV0 ? 52 : 1];         // feature frames t..t+2 (buffer index), bands f0-2 .. f0+49 (zero outside 0..95)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, q = lane >> 4;
@@ -82,13 +93,67 @@ __global__ __launch_bounds__(256, 3) void df_ring_kernel(DfRingArgs a) {
         load_frame(h - 4, fr);
         store_frame(h + 1, fr);
     }
-    load_frame(0, fr);
+    // ---- CONV0 state: feature ring + df_conv0 operand
+    float c0w[8]; float c0b = 0.f;
+    const float* fsb = nullptr;
+    auto load_feat = [&](int bf) __attribute__((always_inline)) {      // buffer frame bf -> FSr slot bf % 3
+        if (tid < 104) {
+            const int g = tid / 52, i = tid - 52 * g, band = f0 - 2 + i;
+            FSr[bf % 3][g][i] = (band >= 0 && band < D && bf < a.Tc + 2) ? fsb[((size_t)bf * 2 + g) * D + band] : 0.f;
+        }
+    };
+    if (CONV0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) c0w[c * 4 + kb] = a.c0frag[(size_t)((c * 4 + w) * 4 + kb) * 64 + lane];
+        c0b = a.c0bias[16 * w + cl];
+        fsb = a.fs + (size_t)b * (a.Tc + 2) * 2 * D;
+        load_feat(0); load_feat(1); load_feat(2);
+        __syncthreads();
+    } else {
+        load_frame(0, fr);
+    }
 
     int slot = 0;                              // slot of frame t: (t mod 5)
     for (int t = 0; t < a.Tc; ++t) {
-        store_frame(slot, fr);
-        if (t + 1 < a.Tc) load_frame(t + 1, fr);
+        if (CONV0) {
+            // df_conv0 for tile rows r = 0..32 (band f0 - 1 + r): A[r][k = kt*8 + g*4 + kf] = feat[t + kt][g][band + kf - 1]
+            f32x4 c0acc[3];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) c0acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int kt = 2 * c + (q >> 1), g = q & 1;
+                const bool live = kt < 3;                               // kt = 3: zero-padded K rows (zero weights)
+                const float* fp = &FSr[live ? (t + kt) % 3 : 0][g][cl];
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) {
+                    const float x0 = live ? fp[mt * 16] : 0.f, x1 = live ? fp[mt * 16 + 1] : 0.f, x2 = live ? fp[mt * 16 + 2] : 0.f;
+                    c0acc[mt] = mfma16(x0, c0w[c * 4 + 0], c0acc[mt]);
+                    c0acc[mt] = mfma16(x1, c0w[c * 4 + 1], c0acc[mt]);
+                    c0acc[mt] = mfma16(x2, c0w[c * 4 + 2], c0acc[mt]);
+                    c0acc[mt] = mfma16(0.f, c0w[c * 4 + 3], c0acc[mt]);
+                }
+            }
+            const bool keep = t + 5 >= a.Tc;                            // the state FIFO exports the chunk's last five frames
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = mt * 16 + q * 4 + i;
+                    if (r < 33) {
+                        const float v = (r == 0 && f0 == 0) ? 0.f : fmaxf(c0acc[mt][i] + c0b, 0.f);
+                        R[slot][r][16 * w + cl] = v;
+                        if (keep && r >= 1) a.c0[(((size_t)b * (a.Tc + 4) + 4 + t) * D + f0 + r - 1) * 64 + 16 * w + cl] = v;
+                    }
+                }
+        } else {
+            store_frame(slot, fr);
+            if (t + 1 < a.Tc) load_frame(t + 1, fr);
+        }
         __syncthreads();                       // ring holds frames t-4 .. t
+        if (CONV0) load_feat(t + 3);           // slot t % 3 is free: its last readers are behind the barrier above
         // ---- pathway conv: rows mt*16.., K chunks [10 kh, 10 kh + 10): chunk cg = 4 kt + cc <-> frame t-4+kt, channels 16 cc..
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -289,7 +289,7 @@ struct dpdf_model {
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
                                        // of >= 8 tiles).  Measured and left OFF: DESIGN.md section 7.
-    int df_ring = 1;                   // df_conv1 + DF pathway conv as one time-walking pass over c0 (df_ring.h) for big batches
+    int df_ring = 2;                   // big batches: 1 = df_conv1 + DF pathway conv as one time-walking pass over c0 (df_ring.h), 2 = df_conv0 in it too
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
@@ -902,17 +902,21 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     TView c0v{x.c0.p, Tc + 4, 4, d.D, 64}, c1v{x.c1.p, Tc, 0, d.Fd, 64};
     {
         ProfScope ps(m, "enc_convs_df");
-        RowMap rm = RowMap::make(Tc, d.D);
-        Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm};
-        BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
-        launch_gemm_rows<4, 32, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 32, 1);
-        // df_conv1 (+ the DF decoder's pathway conv): one time-walking pass over c0 when clips x 3 workgroups fill the
-        // chip, else the time-parallel gemm_rows forms (df_ring.h)
+        // df_conv1 (+ the DF decoder's pathway conv, + df_conv0 itself): one time-walking pass when clips x 3 workgroups
+        // fill the chip, else the time-parallel gemm_rows forms (df_ring.h)
         x.have_pconv = m->df_ring && B * 3 >= 192;
+        const bool conv0_in_ring = x.have_pconv && m->df_ring >= 2;
+        if (!conv0_in_ring) {
+            RowMap rm = RowMap::make(Tc, d.D);
+            Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm};
+            BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
+            launch_gemm_rows<4, 32, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 32, 1);
+        }
         if (x.have_pconv) {
             DfRingArgs ra{x.c0.p, x.c1.p, x.pconv.p, m->C(m->df_conv1.dw), m->C(m->df_conv1.pwfrag), m->C(m->df_conv1.bias),
-                          m->C(m->convp_frag), m->C(m->convp_bias), B, Tc};
-            hipLaunchKernelGGL(df_ring_kernel, dim3(B * 3), dim3(256), 0, sA, ra);
+                          m->C(m->convp_frag), m->C(m->convp_bias), B, Tc, w.feat_spec.p, m->C(m->dfc0_pwfrag), m->C(m->dfc0_bias)};
+            if (conv0_in_ring) hipLaunchKernelGGL(HIP_KERNEL_NAME(df_ring_kernel<true>), dim3(B * 3), dim3(256), 0, sA, ra);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(df_ring_kernel<false>), dim3(B * 3), dim3(256), 0, sA, ra);
         } else {
             run_dwconv_s(m, m->df_conv1, c0v, c1v, B, Tc, 2);
         }
@@ -1590,7 +1594,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     for (int g = 0; g < 2; ++g) m->lanes[g].sync_all();
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
-    else if (n == "df_ring") m->df_ring = value != 0;
+    else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
     else if (n == "gru256_pair") m->gru256_pair = (value >= 2 && value <= 4) ? value : 0;

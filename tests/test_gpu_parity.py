@@ -333,14 +333,15 @@ def test_big_batch_kernel_forms_match_small_batch_forms_and_oracle(be, sr, nb):
     m.set_chunk_frames(16)                      # several chunks: the ring's halo frames come through the state FIFO
     ref_probe = {}
     outs = {}
-    for tag, opts in (("small_forms", {"df_ring": 0, "fuse_mask": 0}), ("big_forms", {"df_ring": 1, "fuse_mask": 1}),
+    for tag, opts in (("small_forms", {"df_ring": 0, "fuse_mask": 0}), ("ring_reads_c0", {"df_ring": 1, "fuse_mask": 1}),
+                      ("big_forms", {"df_ring": 2, "fuse_mask": 1}),
                       ("ring4", {"gru256_pair": 4}), ("ring3", {"gru256_pair": 3}), ("ring2", {"gru256_pair": 2})):
         for k, v in opts.items():
             m.set_option(k, v)
         outs[tag] = m.enhance_batch(wav, 6.0)
         ref_probe[tag] = {k: m.debug_fetch(k) for k in ("c1", "coefs", "m")}
     m.set_option("gru256_pair", 0)
-    for tag in ("big_forms", "ring4", "ring3", "ring2"):
+    for tag in ("ring_reads_c0", "big_forms", "ring4", "ring3", "ring2"):
         assert rms(outs[tag] - outs["small_forms"]) < 1e-6, tag
         for k in ("c1", "coefs", "m"):
             a_, b_ = ref_probe[tag][k], ref_probe["small_forms"][k]
