@@ -38,6 +38,7 @@ MODEL, SR, NB = "dpdfnet4", 16000, 4
 CLIP_SECONDS = 10.0
 WEIGHT_SEED = 20260417
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: ~2.5 PF dense bf16 MFMA peak (only the opt-in bf16x3 line of other_configs is priced against it, / 6)
 GRU64_FLOP_PER_ROW_STEP = 2 * 3 * 64 * (64 + 64)   # r,z,n gates x 64 units x (W_ih x + W_hh h), MAC = 2 FLOP
 FLOP_PER_FRAME = 45.18e6               # algorithmic FLOP / frame, dpdfnet4
 
@@ -115,8 +116,10 @@ def other_configs() -> dict:
     out: dict = {}
     n = int(CLIP_SECONDS * SR)
 
-    def offline(nb: int, B: int, reps: int) -> float:
+    def offline(nb: int, B: int, reps: int, **opts) -> float:
         m = backend.HipModel(SR, nb, synth_blob(backend.manifest(SR, nb), WEIGHT_SEED), device=torch.cuda.current_device())
+        for k, v in opts.items():
+            m.set_option(k, v)
         wav = torch.from_numpy(synth_clips(min(B, 8), n, SR, 5000)).cuda().repeat((B + 7) // 8, 1)[:B].contiguous()
         y = torch.empty_like(wav)
         m.enhance_batch_device(wav.data_ptr(), B, n, y.data_ptr(), None); m.sync()
@@ -131,6 +134,14 @@ def other_configs() -> dict:
     for nb in (2, 8):
         fps, ms = offline(nb, 256, 2)
         out[f"dpdfnet{nb}_16k_256x10s"] = {"frames_per_s": round(fps), "ms_per_step": round(ms, 2)}
+    # OPT-IN precision mode (csrc/gru_bf16x3.h): the GRU-64 scans as three-limb bf16 products with fp32 accumulation.  NOT the
+    # headline dtype: priced against the dense bf16 MFMA peak / 6 limb products, not against the fp32 MFMA peak.
+    fps, ms = offline(NB, 256, 2, gru64_bf16x3=1)
+    out[f"{MODEL}_16k_256x10s_optin_bf16x3_gru64"] = {
+        "frames_per_s": round(fps), "ms_per_step": round(ms, 2), "dtype": "f32 emulated as 3 x bf16 limbs (GRU-64 scans only), f32 accumulate",
+        "fp32_equivalent_tflops_whole_path": round(fps * FLOP_PER_FRAME / 1e12, 1),
+        "frac_of_bf16_peak_over_6": round(fps * FLOP_PER_FRAME / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 3),
+        "note": "opt-in via dpdf_set_option('gru64_bf16x3', 1); same parity tests and tolerance as the default mode"}
     fps, ms = offline(NB, 1, 5)
     out[f"{MODEL}_16k_1x10s"] = {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5)}
     sr48, nb48, S = 48000, 8, 64

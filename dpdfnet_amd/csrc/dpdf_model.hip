@@ -29,6 +29,7 @@
 #include "resample.h"
 #include "df_ring.h"
 #include "dec_last.h"
+#include "gru_bf16x3.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -185,6 +186,7 @@ BnFold fold_bn(const Blob& B, const std::string& p, int ch) {
 struct SepConvW { size_t dw, pwfrag, bias; int nsub; };        // arena offsets
 struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs;
+                size_t wlimb;                 // opt-in bf16x3 mode: the same weights as three bf16 limbs per value (gru_bf16x3.h), in float-sized arena slots
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
 struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
 struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn; };   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
@@ -289,6 +291,7 @@ struct dpdf_model {
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
                                        // of >= 8 tiles).  Measured and left OFF: DESIGN.md section 7.
+    int gru64_bf16x3 = 0;              // OPT-IN: GRU-64 scans as three-limb bf16 products on the bf16 matrix pipe (gru_bf16x3.h); default fp32 MFMA
     int df_ring = 2;                   // big batches: 1 = df_conv1 + DF pathway conv as one time-walking pass over c0 (df_ring.h), 2 = df_conv0 in it too
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
@@ -392,6 +395,15 @@ PathW build_path(Arena& A, const Blob& B, const std::string& p) {
     PathW w; w.ps = A.add(ps); w.pb = A.add(pb);
     return w;
 }
+// float -> bf16, round to nearest even (what the device's (__bf16) conversion does), and back
+static inline uint16_t f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
 // [dir][wave][part][gate][chunk*4+kb][lane] + bias [dir][4][64]
 GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::string, std::string>>& dirs) {
     GruW64 g; g.ndirs = (int)dirs.size();
@@ -424,6 +436,27 @@ GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::str
         }
     }
     g.wfrag = A.add(frag); g.bias = A.add(bias);
+    {   // bf16x3 limbs of the same (scaled) weights: [dir][wave 4][gate 3][kblock 4][limb 3][lane 64][8] (gru_bf16x3.h)
+        std::vector<uint16_t> limbs((size_t)g.ndirs * 4 * 3 * 4 * 3 * 64 * 8);
+        for (int d = 0; d < g.ndirs; ++d) {
+            const std::string &p = dirs[d].first, &sfx = dirs[d].second;
+            const float* wih = B.get(p + ".weight_ih" + sfx); const float* whh = B.get(p + ".weight_hh" + sfx);
+            for (int w = 0; w < 4; ++w) for (int gate = 0; gate < 3; ++gate) for (int kb = 0; kb < 4; ++kb)
+                for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+                    const float* W = kb < 2 ? wih : whh;
+                    const int k = 32 * (kb & 1) + 8 * (lane >> 4) + j, col = gate * 64 + 16 * w + (lane & 15);
+                    float r = W[col * 64 + k] * gate_scale[gate];
+                    for (int t = 0; t < 3; ++t) {
+                        const uint16_t l = f2bf(r);
+                        limbs[((((((size_t)(d * 4 + w) * 3 + gate) * 4 + kb) * 3 + t) * 64) + lane) * 8 + j] = l;
+                        r -= bf2f(l);
+                    }
+                }
+        }
+        std::vector<float> packed(limbs.size() / 2);
+        memcpy(packed.data(), limbs.data(), limbs.size() * 2);
+        g.wlimb = A.add(packed);
+    }
     {   // the same W_ih (and input-side biases), scaled alike, as an ordinary GEMM operand for gru64_scan_gi_kernel
         std::vector<float> gfrag, gbias;
         for (int d = 0; d < g.ndirs; ++d) {
@@ -715,11 +748,12 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                  float* state, long S, int soff, int B, int Tc) {
     const int M = B * Tc * Fp;
     float* x = xin; float* y = xa;
-    const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0;
+    const bool bf3 = m->gru64_bf16x3 != 0;              // opt-in precision mode (gru_bf16x3.h): plain scans on the bf16 pipe, fc + LN as GEMM passes
+    const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0 && !bf3;
     const bool fuse_intra = can_fuse && (m->fuse_dprnn == 2 || (long)B * Tc >= 3072);
     const bool fuse_inter = can_fuse && (m->fuse_dprnn == 2 || (long)B * Fp >= 64 * 16);
-    const bool gi_intra = !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
-    const bool gi_inter = !fuse_inter && m->hoist_gi && Tc >= 4 && (size_t)M * 192 <= gibuf.n;
+    const bool gi_intra = !bf3 && !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
+    const bool gi_inter = !bf3 && !fuse_inter && m->hoist_gi && Tc >= 4 && (size_t)M * 192 <= gibuf.n;
     const bool df = Fp >= 48;
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         const DprnnW& w = blocks[bi];
@@ -747,6 +781,9 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                 BiasActStore<4> ep{gibuf.p, 384, 64, m->C(w.intra.ih_bias), 64, 64, ACT_NONE};
                 launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.intra.ih_frag), ep, M, 64, 6);
                 hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const float*)gibuf.p, 384);
+            } else if (bf3) {
+                ProfScope ps(m, df ? "gru64_scan_bf16x3_kernel/intra_df" : "gru64_scan_bf16x3_kernel/intra_erb");
+                hipLaunchKernelGGL(gru64_scan_bf16x3_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const __bf16*)m->C(w.intra.wlimb));
             } else {
                 ProfScope ps(m, df ? "gru64_scan_kernel/intra_df" : "gru64_scan_kernel/intra_erb");
                 hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai);
@@ -780,6 +817,9 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                 BiasActStore<4> ep{gibuf.p, 192, 64, m->C(w.inter.ih_bias), 64, 64, ACT_NONE};
                 launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.inter.ih_frag), ep, M, 64, 3);
                 hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const float*)gibuf.p, 192);
+            } else if (bf3) {
+                ProfScope ps(m, df ? "gru64_scan_bf16x3_kernel/inter_df" : "gru64_scan_bf16x3_kernel/inter_erb");
+                hipLaunchKernelGGL(gru64_scan_bf16x3_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const __bf16*)m->C(w.inter.wlimb));
             } else {
                 ProfScope ps(m, df ? "gru64_scan_kernel/inter_df" : "gru64_scan_kernel/inter_erb");
                 hipLaunchKernelGGL(gru64_scan_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae);
@@ -1594,6 +1634,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     for (int g = 0; g < 2; ++g) m->lanes[g].sync_all();
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
+    else if (n == "gru64_bf16x3") m->gru64_bf16x3 = value != 0;
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;

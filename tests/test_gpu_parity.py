@@ -350,3 +350,33 @@ def test_big_batch_kernel_forms_match_small_batch_forms_and_oracle(be, sr, nb):
     for b in (0, 41, 191):
         assert rms(outs["big_forms"][b] - o.enhance(wav[b], 6.0)) < WAVE_TOL, b
     m.close()
+
+
+@pytest.mark.parametrize("tag", ["16k_nb4", "48k_nb2"])
+def test_optin_bf16x3_gru64_mode_keeps_fp32_parity(tag, be):
+    """OPT-IN precision mode (`dpdf_set_option("gru64_bf16x3", 1)`, csrc/gru_bf16x3.h): the GRU-64 scans as three-limb bf16
+    products with fp32 accumulation.  Same bar as the default fp32-MFMA mode: reference golden waveform within 2e-6 RMS,
+    stage tensors and state within the stage tolerances -- on one clip (small forms) and on a 192-clip batch (big forms)."""
+    g, meta = load_golden(tag)
+    sr, nb = meta["sample_rate"], meta["nb"]
+    blob = golden_blob(meta)
+    m = be.HipModel(sr, nb, blob, 0)
+    o = make_oracle(meta, blob)
+    m.set_option("gru64_bf16x3", 1)
+    out = m.enhance_batch(g["wav"][None])[0]
+    assert rms(out - g["enhanced"]) < WAVE_TOL, rms(out - g["enhanced"])
+    spec = o.stft(g["wav"])
+    ref, st_ref = o.run_frames(spec)
+    got, st = m.run_frames(spec, m.initial_state())
+    scale = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() < STAGE_REL_TOL * scale and rms(got - ref) < 1e-5 * scale
+    assert np.abs(st - st_ref).max() < 2e-4
+    B, n = 192, int(0.25 * sr) + 17
+    wav = np.stack([synth_clip(n, sr, 5000 + i) * (0.5 + (i % 5) / 5.0) for i in range(B)]).astype(np.float32)
+    big = m.enhance_batch(wav, None)
+    m.set_option("gru64_bf16x3", 0)
+    fp32 = m.enhance_batch(wav, None)
+    assert rms(big - fp32) < 1e-6
+    for b in (0, 100, 191):
+        assert rms(big[b] - o.enhance(wav[b])) < WAVE_TOL, b
+    m.close()
