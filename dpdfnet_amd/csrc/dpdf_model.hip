@@ -191,7 +191,8 @@ struct GruW64 { size_t wfrag, bias; int ndirs;
 struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
 struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn; };   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
-                size_t fci_epi, fce_epi; };   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
+                size_t fci_epi, fce_epi;
+                size_t fcl_fwd, fcl_bwd, fcl_inter; };   // opt-in bf16x3 mode: fc halves as bf16 limbs (gru_bf16x3.h)   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
 
 }  // namespace
 
@@ -291,7 +292,8 @@ struct dpdf_model {
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
                                        // of >= 8 tiles).  Measured and left OFF: DESIGN.md section 7.
-    int gru64_bf16x3 = 0;              // OPT-IN: GRU-64 scans as three-limb bf16 products on the bf16 matrix pipe (gru_bf16x3.h); default fp32 MFMA
+    int gru64_bf16x3 = 0;              // OPT-IN: GRU-64 scans as three-limb bf16 products on the bf16 matrix pipe (gru_bf16x3.h); default 0 = fp32 MFMA;
+                                       // 1 = on, 2 = on without the fused fc + LN forms
     int df_ring = 2;                   // big batches: 1 = df_conv1 + DF pathway conv as one time-walking pass over c0 (df_ring.h), 2 = df_conv0 in it too
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
@@ -551,6 +553,25 @@ std::vector<DprnnW> build_dprnn(Arena& A, const Blob& B, const std::string& p, i
             w.fci_epi = A.add(fi);
             w.fce_epi = A.add(pack_epi(B.get(q + ".fc_inter.weight"), 64, 0));
         }
+        {   // bf16x3 limbs of the fc halves: [wave 4][kblock 2][limb 3][lane 64][8], element = W[16 wave + (lane&15)][koff + 32 kblock + 8 (lane>>4) + j]
+            auto pack_limbs = [&](const float* W, int ld, int koff) {
+                std::vector<uint16_t> limbs((size_t)4 * 2 * 3 * 64 * 8);
+                for (int wv = 0; wv < 4; ++wv) for (int kb = 0; kb < 2; ++kb) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+                    float r = W[(size_t)(16 * wv + (lane & 15)) * ld + koff + 32 * kb + 8 * (lane >> 4) + j];
+                    for (int t = 0; t < 3; ++t) {
+                        const uint16_t l = f2bf(r);
+                        limbs[((((size_t)wv * 2 + kb) * 3 + t) * 64 + lane) * 8 + j] = l;
+                        r -= bf2f(l);
+                    }
+                }
+                std::vector<float> packed(limbs.size() / 2);
+                memcpy(packed.data(), limbs.data(), limbs.size() * 2);
+                return packed;
+            };
+            w.fcl_fwd = A.add(pack_limbs(B.get(q + ".fc_intra.weight"), 128, 0));
+            w.fcl_bwd = A.add(pack_limbs(B.get(q + ".fc_intra.weight"), 128, 64));
+            w.fcl_inter = A.add(pack_limbs(B.get(q + ".fc_inter.weight"), 64, 0));
+        }
         v.push_back(w);
     }
     return v;
@@ -748,8 +769,8 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                  float* state, long S, int soff, int B, int Tc) {
     const int M = B * Tc * Fp;
     float* x = xin; float* y = xa;
-    const bool bf3 = m->gru64_bf16x3 != 0;              // opt-in precision mode (gru_bf16x3.h): plain scans on the bf16 pipe, fc + LN as GEMM passes
-    const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0 && !bf3;
+    const bool bf3 = m->gru64_bf16x3 != 0;              // opt-in precision mode (gru_bf16x3.h): the scans on the bf16 pipe as three-limb products
+    const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0 && (!bf3 || m->gru64_bf16x3 == 1);
     const bool fuse_intra = can_fuse && (m->fuse_dprnn == 2 || (long)B * Tc >= 3072);
     const bool fuse_inter = can_fuse && (m->fuse_dprnn == 2 || (long)B * Fp >= 64 * 16);
     const bool gi_intra = !bf3 && !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
@@ -761,7 +782,18 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
         ai.x = x; ai.wfrag = m->C(w.intra.wfrag); ai.bias = m->C(w.intra.bias); ai.hstate = nullptr;
         ai.nrows = B * Tc; ai.nsteps = Fp; ai.rdiv = 1;
         ai.x_hi = (long)Fp * 64; ai.x_lo = 0; ai.x_step = 64;
-        if (fuse_intra) {
+        if (fuse_intra && bf3) {
+            {   // forward direction + forward half of fc_intra: pf -> `hin` scratch [rows][Fp][64]
+                ProfScope ps(m, df ? "gru64_epi_bf16x3_kernel<0>/intra_fwd_df" : "gru64_epi_bf16x3_kernel<0>/intra_fwd_erb");
+                Gru64EpiBf3Args ea{ai, (const __bf16*)m->C(w.intra.wlimb), (const __bf16*)m->C(w.fcl_fwd), nullptr, nullptr, nullptr, nullptr, hin};
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_bf16x3_kernel<0>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
+            }
+            {   // backward direction + backward half of fc_intra + pf + ln_intra + residual
+                ProfScope ps(m, df ? "gru64_epi_bf16x3_kernel<2>/intra_bwd_df" : "gru64_epi_bf16x3_kernel<2>/intra_bwd_erb");
+                Gru64EpiBf3Args ea{ai, (const __bf16*)m->C(w.intra.wlimb), (const __bf16*)m->C(w.fcl_bwd), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b), hin, y};
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_bf16x3_kernel<2>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
+            }
+        } else if (fuse_intra) {
             {   // forward direction: plain scan, hf -> `hin` scratch [rows][Fp][64]
                 ProfScope ps(m, df ? "gru64_scan_kernel/intra_fwd_df" : "gru64_scan_kernel/intra_fwd_erb");
                 ai.out = hin; ai.ndirs = 1; ai.o_hi = (long)Fp * 64; ai.o_lo = 0; ai.o_step = 64; ai.o_dir_off = 0;
@@ -804,7 +836,12 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
         ae.x_hi = (long)Tc * Fp * 64; ae.x_lo = 64; ae.x_step = (long)Fp * 64;
         ae.o_hi = ae.x_hi; ae.o_lo = 64; ae.o_step = ae.x_step; ae.o_dir_off = 0;
         ae.h_hi = S; ae.h_lo = 64;
-        if (fuse_inter) {   // inter scan + fc_inter + ln_inter + residual
+        if (fuse_inter && bf3) {
+            ProfScope ps(m, df ? "gru64_epi_bf16x3_kernel<1>/inter_df" : "gru64_epi_bf16x3_kernel<1>/inter_erb");
+            ae.out = nullptr;
+            Gru64EpiBf3Args ea{ae, (const __bf16*)m->C(w.inter.wlimb), (const __bf16*)m->C(w.fcl_inter), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_bf16x3_kernel<1>), dim3((ae.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
+        } else if (fuse_inter) {   // inter scan + fc_inter + ln_inter + residual
             ProfScope ps(m, df ? "gru64_epi_kernel<1>/inter_df" : "gru64_epi_kernel<1>/inter_erb");
             ae.out = nullptr;
             Gru64EpiArgs ea{ae, m->C(w.fce_epi), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
@@ -1634,7 +1671,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     for (int g = 0; g < 2; ++g) m->lanes[g].sync_all();
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
-    else if (n == "gru64_bf16x3") m->gru64_bf16x3 = value != 0;
+    else if (n == "gru64_bf16x3") m->gru64_bf16x3 = value < 0 ? 0 : (value > 2 ? 2 : value);   // 1: on (fc + LN fused into the scans for big batches), 2: plain scans + fp32 GEMM fc/LN passes only (A/B)
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;

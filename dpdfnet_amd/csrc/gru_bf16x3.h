@@ -142,3 +142,180 @@ __global__ __launch_bounds__(256, 2) void gru64_scan_bf16x3_kernel(Gru64Args a, 
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// gru64_epi_bf16x3_kernel<EPI>: the bf16x3 scan with the DPRNN block's Linear (+ LayerNorm + residual) fused in, the
+// counterpart of gru64_epi_kernel (gru_scan.h) -- without it the opt-in mode pays 29 ms per step for the fc + LN GEMM
+// passes over HBM.  The fc product of step s-1 shares the A limbs of h'(s-1) with the h-part of step s (12 more bf16
+// MFMAs), lands in an LDS tile in C layout and is finished one barrier later by the row-contiguous lanes.
+//   EPI 0  intra-band FORWARD:   writes pf(p) = W_fc[:, 0:64] hf(p)  (the forward half of fc_intra, no bias) instead of hf
+//   EPI 2  intra-band BACKWARD:  y(p) = x(p) + LN(W_fc[:, 64:128] hb(p) + pf(p) + b)      (pf read back as fp32: no split)
+//   EPI 1  inter-band:           y(s) = x(s) + LN(W_fc h'(s) + b)
+// (the fp32 kernel keeps both fc halves in the backward kernel; here that would not fit 256 registers beside the limbs)
+// The residual x(s-2) is rebuilt exactly from its three limbs, which stay in a 4-slot LDS ring.
+struct Gru64EpiBf3Args {
+    Gru64Args g;            // g.out unused
+    const __bf16* wlimb;    // GRU weights (layout above)
+    const __bf16* fclimb;   // [wave 4][kblock 2][limb 3][lane 64][8]: W_fc[col = 16 wave + cl][k = 32 kblock + 8 q + j] of the half that h' feeds
+    const float* fc_bias; const float* ln_g; const float* ln_b;   // [64] (unused by EPI 0)
+    const float* extra;     // EPI 2: pf tensor, addressed like x
+    float* y;               // output, addressed like x
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gru64_epi_bf16x3_kernel(Gru64EpiBf3Args ea) {
+    const Gru64Args& a = ea.g;
+    __shared__ __attribute__((aligned(16))) __bf16 Hl[2][3][16][72];
+    __shared__ __attribute__((aligned(16))) __bf16 Xl[4][3][16][72];          // ring: the limbs of x(s-2) are the residual
+    __shared__ __attribute__((aligned(16))) float Ys[2][16][68];
+    __shared__ __attribute__((aligned(16))) float Es[EPI == 2 ? 4 : 1][EPI == 2 ? 16 : 1][EPI == 2 ? 68 : 4];
+    __shared__ __attribute__((aligned(16))) float Lp[3][64];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dir = EPI == 2 ? 1 : 0;
+    const int row0 = blockIdx.x * 16;
+    const int cl = lane & 15, q = lane >> 4;
+    bf16x8 wb[3][4][3], wfc[2][3];
+    {
+        const bf16x8* wp = (const bf16x8*)ea.wlimb + ((size_t)(dir * 4 + w) * 3 * 4 * 3) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int l = 0; l < 3; ++l) wb[g][kb][l] = wp[(size_t)((g * 4 + kb) * 3 + l) * 64];
+        const bf16x8* fp = (const bf16x8*)ea.fclimb + ((size_t)w * 2 * 3) * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) wfc[kb][l] = fp[(size_t)(kb * 3 + l) * 64];
+    }
+    const float* bp = a.bias + (size_t)dir * 256 + 16 * w + cl;
+    const float b_r = bp[0], b_z = bp[64], b_in = bp[128], b_hn = bp[192];
+    if (EPI != 0 && tid < 64) { Lp[0][tid] = ea.fc_bias[tid]; Lp[1][tid] = ea.ln_g[tid]; Lp[2][tid] = ea.ln_b[tid]; }
+    if (EPI == 0 && tid < 64) { Lp[0][tid] = 0.f; Lp[1][tid] = 1.f; Lp[2][tid] = 0.f; }
+
+    const int hi0 = row0 / a.rdiv, lo0 = row0 - hi0 * a.rdiv;
+    const float* xbase = a.x + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
+    const float* ebase = EPI == 2 ? ea.extra + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo : nullptr;
+    float* ybase = ea.y + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
+    const int srow = 4 * w + q, scol = 4 * cl;
+    unsigned sx_off; bool so_ok;
+    {
+        int rs = row0 + srow;
+        so_ok = rs < a.nrows;
+        if (rs >= a.nrows) rs = a.nrows - 1;
+        sx_off = (unsigned)((long)(rs / a.rdiv - hi0) * a.x_hi + (long)(rs % a.rdiv - lo0) * a.x_lo) + scol;
+    }
+    auto put_limbs = [&](__bf16 (*T)[16][72], int r, int c, const float4& v4) __attribute__((always_inline)) {
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        bf16x4 l1, l2, l3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { __bf16 p1, p2, p3; split3(v[j], p1, p2, p3); l1[j] = p1; l2[j] = p2; l3[j] = p3; }
+        *(bf16x4*)&T[0][r][c] = l1; *(bf16x4*)&T[1][r][c] = l2; *(bf16x4*)&T[2][r][c] = l3;
+    };
+    float h_own[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int rc = row0 + q * 4 + i;
+        if (rc >= a.nrows) rc = a.nrows - 1;
+        const float hv = a.hstate ? a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] : 0.f;
+        h_own[i] = hv;
+        __bf16 p1, p2, p3; split3(hv, p1, p2, p3);
+        Hl[1][0][q * 4 + i][16 * w + cl] = p1; Hl[1][1][q * 4 + i][16 * w + cl] = p2; Hl[1][2][q * 4 + i][16 * w + cl] = p3;
+    }
+    const int n = a.nsteps;
+    auto pos_of = [&](int s) { s = s < n ? s : n - 1; return dir ? n - 1 - s : s; };
+    {
+        put_limbs(Xl[0], srow, scol, *(const float4*)((xbase + (long)pos_of(0) * a.x_step) + sx_off));
+        if (EPI == 2) *(float4*)&Es[0][srow][scol] = *(const float4*)((ebase + (long)pos_of(0) * a.x_step) + sx_off);
+    }
+    __syncthreads();
+
+    for (int s = 0; s < n + 2; ++s) {
+        const int hb = s & 1;
+        // ---- finalize step s-2 on the row-contiguous pieces
+        if (s >= 2) {
+            float4 yv = *(const float4*)&Ys[hb][srow][scol];                       // fc(s-2) (+ bias), written during step s-1
+            if (EPI == 2) { const float4 pv = *(const float4*)&Es[(s - 2) & 3][srow][scol]; yv.x += pv.x; yv.y += pv.y; yv.z += pv.z; yv.w += pv.w; }
+            float4 o;
+            if (EPI == 0) {
+                o = yv;
+            } else {
+                const bf16x4 r1 = *(const bf16x4*)&Xl[(s - 2) & 3][0][srow][scol], r2 = *(const bf16x4*)&Xl[(s - 2) & 3][1][srow][scol],
+                             r3 = *(const bf16x4*)&Xl[(s - 2) & 3][2][srow][scol];
+                const float rx = ((float)r1[0] + (float)r2[0]) + (float)r3[0], ry = ((float)r1[1] + (float)r2[1]) + (float)r3[1];
+                const float rz = ((float)r1[2] + (float)r2[2]) + (float)r3[2], rw = ((float)r1[3] + (float)r2[3]) + (float)r3[3];
+                const float mean = row16_allreduce_sum(yv.x + yv.y + yv.z + yv.w) * (1.0f / 64.0f);
+                const float d0 = yv.x - mean, d1 = yv.y - mean, d2 = yv.z - mean, d3 = yv.w - mean;
+                const float s2 = row16_allreduce_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+                const float inv = rsqrtf(s2 * (1.0f / 64.0f) + 1e-5f);
+                const float4 gg = *(const float4*)&Lp[1][scol], bb = *(const float4*)&Lp[2][scol];
+                o.x = rx + d0 * inv * gg.x + bb.x; o.y = ry + d1 * inv * gg.y + bb.y;
+                o.z = rz + d2 * inv * gg.z + bb.z; o.w = rw + d3 * inv * gg.w + bb.w;
+            }
+            if (so_ok) *(float4*)((ybase + (long)pos_of(s - 2) * a.x_step) + sx_off) = o;
+        }
+        // ---- loads for step s+1
+        const float4 xnext = *(const float4*)((xbase + (long)pos_of(s + 1) * a.x_step) + sx_off);
+        float4 enext = xnext;
+        if (EPI == 2) enext = *(const float4*)((ebase + (long)pos_of(s + 1) * a.x_step) + sx_off);
+        f32x4 ar = {b_r, b_r, b_r, b_r}, az = {b_z, b_z, b_z, b_z};
+        f32x4 axn = {b_in, b_in, b_in, b_in}, ahn = {b_hn, b_hn, b_hn, b_hn};
+        f32x4 ay = {0.f, 0.f, 0.f, 0.f};
+#define DPDF_LIMB6(acc, W)                                                                   \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[2], (W)[0], acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], (W)[1], acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], (W)[2], acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[1], (W)[0], acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], (W)[1], acc, 0, 0, 0);           \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[0], (W)[0], acc, 0, 0, 0);
+        if (s < n) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 al[3];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) al[l] = *(const bf16x8*)&Xl[s & 3][l][cl][32 * kb + 8 * q];
+                DPDF_LIMB6(ar, wb[0][kb]) DPDF_LIMB6(az, wb[1][kb]) DPDF_LIMB6(axn, wb[2][kb])
+            }
+        }
+        if (s <= n) {
+            // h-part of step s and fc of step s-1 share the A limbs of h'(s-1)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 al[3];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) al[l] = *(const bf16x8*)&Hl[hb ^ 1][l][cl][32 * kb + 8 * q];
+                DPDF_LIMB6(ar, wb[0][2 + kb]) DPDF_LIMB6(az, wb[1][2 + kb]) DPDF_LIMB6(ahn, wb[2][2 + kb])
+                DPDF_LIMB6(ay, wfc[kb])
+            }
+        }
+#undef DPDF_LIMB6
+        if (s < n) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float h = gru64_cell(ar[i], az[i], axn[i], ahn[i], h_own[i]);
+                h_own[i] = h;
+                __bf16 p1, p2, p3; split3(h, p1, p2, p3);
+                Hl[hb][0][q * 4 + i][16 * w + cl] = p1; Hl[hb][1][q * 4 + i][16 * w + cl] = p2; Hl[hb][2][q * 4 + i][16 * w + cl] = p3;
+            }
+        }
+        if (s >= 1 && s <= n) {
+            const float fb = Lp[0][16 * w + cl];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Ys[hb ^ 1][q * 4 + i][16 * w + cl] = ay[i] + fb;    // fc(s-1): read at step s+1 from Ys[(s+1)&1]
+        }
+        if (s + 1 < n) {
+            put_limbs(Xl[(s + 1) & 3], srow, scol, xnext);
+            if (EPI == 2) *(float4*)&Es[(s + 1) & 3][srow][scol] = enext;
+        }
+        __syncthreads();
+    }
+    if (a.hstate) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rc = row0 + q * 4 + i;
+            if (rc < a.nrows)
+                a.hstate[(long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + 16 * w + cl] = h_own[i];
+        }
+    }
+}

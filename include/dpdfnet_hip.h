@@ -124,9 +124,10 @@ int dpdf_set_overlap(dpdf_model* m, int mask);
 int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
 /* Further A/B switches by name (measurement only; results equal to rounding): "fuse_mask" (1: the mask head's 64->1
  * contraction runs in the last decoder GEMM's epilogue, 0: stand-alone kernel), "df_ring" (df_conv1 + DF pathway conv as one time-walking pass over c0 for
- * big batches, 0: two time-parallel GEMM launches), "gru64_bf16x3" (OPT-IN precision mode, default 0: the GRU-64 scans as three-limb bf16
- * products with fp32 accumulation on the bf16 matrix pipe -- fp32-accurate to rounding, a different instruction mix,
- * never what the headline figure is measured on), "hoist_gi" (small-batch GRU-64 input
+ * big batches, 0: two time-parallel GEMM launches), "gru64_bf16x3" (OPT-IN precision mode, default 0; 1 = the GRU-64 scans (and, for big
+ * batches, the fc + LayerNorm fused into them) as three-limb bf16 products with fp32 accumulation on the bf16 matrix
+ * pipe -- fp32-accurate to rounding, a different instruction mix, never what the headline figure is measured on;
+ * 2 = the same without the fused forms), "hoist_gi" (small-batch GRU-64 input
  * GEMM hoisting), "gru256_cluster" (0: single-workgroup GRU-256 scan), "gru256_pair" (0 off (default) / 2 / 3 / 4 round-robin tiles per
  * GRU-256 cluster, gru256_ring_kernel, for launches of >= 8 tiles).  Unknown name -> DPDF_E_INVALID. */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);

@@ -352,8 +352,9 @@ def test_big_batch_kernel_forms_match_small_batch_forms_and_oracle(be, sr, nb):
     m.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("tag", ["16k_nb4", "48k_nb2"])
-def test_optin_bf16x3_gru64_mode_keeps_fp32_parity(tag, be):
+def test_optin_bf16x3_gru64_mode_keeps_fp32_parity(tag, mode, be):
     """OPT-IN precision mode (`dpdf_set_option("gru64_bf16x3", 1)`, csrc/gru_bf16x3.h): the GRU-64 scans as three-limb bf16
     products with fp32 accumulation.  Same bar as the default fp32-MFMA mode: reference golden waveform within 2e-6 RMS,
     stage tensors and state within the stage tolerances -- on one clip (small forms) and on a 192-clip batch (big forms)."""
@@ -362,7 +363,7 @@ def test_optin_bf16x3_gru64_mode_keeps_fp32_parity(tag, be):
     blob = golden_blob(meta)
     m = be.HipModel(sr, nb, blob, 0)
     o = make_oracle(meta, blob)
-    m.set_option("gru64_bf16x3", 1)
+    m.set_option("gru64_bf16x3", mode)          # 1: on (fc + LN fused into the scans for big batches); 2: plain bf16x3 scans + fp32 fc/LN GEMM passes
     out = m.enhance_batch(g["wav"][None])[0]
     assert rms(out - g["enhanced"]) < WAVE_TOL, rms(out - g["enhanced"])
     spec = o.stft(g["wav"])
@@ -374,6 +375,10 @@ def test_optin_bf16x3_gru64_mode_keeps_fp32_parity(tag, be):
     B, n = 192, int(0.25 * sr) + 17
     wav = np.stack([synth_clip(n, sr, 5000 + i) * (0.5 + (i % 5) / 5.0) for i in range(B)]).astype(np.float32)
     big = m.enhance_batch(wav, None)
+    m.set_fuse_dprnn("always")                  # the fused kernels also on the one-clip shapes
+    out1 = m.enhance_batch(g["wav"][None])[0]
+    assert rms(out1 - g["enhanced"]) < WAVE_TOL, rms(out1 - g["enhanced"])
+    m.set_fuse_dprnn("auto")
     m.set_option("gru64_bf16x3", 0)
     fp32 = m.enhance_batch(wav, None)
     assert rms(big - fp32) < 1e-6
