@@ -131,17 +131,7 @@ def other_configs() -> dict:
         T = m.num_frames(n); m.close()
         return B * T / dt, 1e3 * dt
 
-    for nb in (2, 8):
-        fps, ms = offline(nb, 256, 2)
-        out[f"dpdfnet{nb}_16k_256x10s"] = {"frames_per_s": round(fps), "ms_per_step": round(ms, 2)}
-    # OPT-IN precision mode (csrc/gru_bf16x3.h): the GRU-64 scans as three-limb bf16 products with fp32 accumulation.  NOT the
-    # headline dtype: priced against the dense bf16 MFMA peak / 6 limb products, not against the fp32 MFMA peak.
-    fps, ms = offline(NB, 256, 2, gru64_bf16x3=1)
-    out[f"{MODEL}_16k_256x10s_optin_bf16x3_gru64"] = {
-        "frames_per_s": round(fps), "ms_per_step": round(ms, 2), "dtype": "f32 emulated as 3 x bf16 limbs (GRU-64 scans only), f32 accumulate",
-        "fp32_equivalent_tflops_whole_path": round(fps * FLOP_PER_FRAME / 1e12, 1),
-        "frac_of_bf16_peak_over_6": round(fps * FLOP_PER_FRAME / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 3),
-        "note": "opt-in via dpdf_set_option('gru64_bf16x3', 1); same parity tests and tolerance as the default mode"}
+    # latency-bound configurations first (short kernels: measured before the long throughput runs heat the chip)
     fps, ms = offline(NB, 1, 5)
     out[f"{MODEL}_16k_1x10s"] = {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5)}
     sr48, nb48, S = 48000, 8, 64
@@ -161,6 +151,17 @@ def other_configs() -> dict:
     st.close(); m.close()
     out["dpdfnet8_48khz_hr_64_streams_1_hop"] = {"us_per_call": round(1e6 * dt, 1), "frames_per_s": round(S / dt),
                                                   "rtf": round(dt / (hop / sr48), 4)}
+    for nb in (2, 8):
+        fps, ms = offline(nb, 256, 2)
+        out[f"dpdfnet{nb}_16k_256x10s"] = {"frames_per_s": round(fps), "ms_per_step": round(ms, 2)}
+    # OPT-IN precision mode (csrc/gru_bf16x3.h): the GRU-64 scans as three-limb bf16 products with fp32 accumulation.  NOT the
+    # headline dtype: priced against the dense bf16 MFMA peak / 6 limb products, not against the fp32 MFMA peak.
+    fps, ms = offline(NB, 256, 2, gru64_bf16x3=1)
+    out[f"{MODEL}_16k_256x10s_optin_bf16x3_gru64"] = {
+        "frames_per_s": round(fps), "ms_per_step": round(ms, 2), "dtype": "f32 emulated as 3 x bf16 limbs (GRU-64 scans only), f32 accumulate",
+        "fp32_equivalent_tflops_whole_path": round(fps * FLOP_PER_FRAME / 1e12, 1),
+        "frac_of_bf16_peak_over_6": round(fps * FLOP_PER_FRAME / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 3),
+        "note": "opt-in via dpdf_set_option('gru64_bf16x3', 1); same parity tests and tolerance as the default mode"}
     return out
 
 

@@ -359,6 +359,17 @@ __global__ __launch_bounds__(1024) void gru256_scan_kernel(Gru256Args a) {
 // Guideline 16 recipe R2): placement-independent, no fences, no separate flag.  Epochs grow
 // monotonically across launches (host-supplied base), so the granule buffer is never re-zeroed.
 // Two slots (step parity) suffice: a peer can only be one step ahead.
+// Spin-wait bookkeeping of the cluster scans.  A sweep that is still stale after ~1 s of polling (2^20 rounds) gives
+// up: it raises the device error flag and the workgroup stops waiting for the rest of the launch (`dead`), and every
+// other workgroup polls the flag every 256 rounds and does the same -- a lost peer turns into DPDF_E_RUNTIME within
+// about a second instead of ~10 s per remaining step (the host reads the flag at the next synchronisation point).
+__device__ __forceinline__ bool cluster_spin_expired(unsigned& spins, int* err, bool& dead) {
+    ++spins;
+    if ((spins & 255u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { dead = true; return true; }
+    if (spins > (1u << 20)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; return true; }
+    return false;
+}
+
 struct Gru256CArgs {
     const float* gi;       // [B*Tc][768]
     float* out;            // [B*Tc][256]
@@ -421,6 +432,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
         gr[i] = g[0]; gz[i] = g[256]; gn[i] = g[512];
     }
     int cur = 0;
+    bool dead = false;             // a sweep timed out (or another workgroup's did): stop waiting, the host reports DPDF_E_RUNTIME
     for (int t = 0; t < a.Tc; ++t) {
         f32x4 ar = {gr[0], gr[1], gr[2], gr[3]}, az = {gz[0], gz[1], gz[2], gz[3]};
         f32x4 axn = {gn[0], gn[1], gn[2], gn[3]}, ahn = {bhn, bhn, bhn, bhn};
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster_kernel(Gru256CArgs a) {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) all_in &= (unsigned)(xv[k] >> 32) == epoch;
                 if (all_in) break;
-                if (++spins > (1u << 22)) { *a.err = 1; break; }
+                if (dead || cluster_spin_expired(spins, a.err, dead)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
@@ -587,6 +599,7 @@ __global__ __launch_bounds__(256, 1) void gru256_ring_kernel(Gru256CArgs a) {
     // sweep geometry: granule k = 4 s + rr of this lane sits at row 4 rr + w, unit 64 ((j + 1 + s) & 3) + lane
     const unsigned lane_b8 = (unsigned)lane * 8u;      // unsigned 32-bit BYTE lane offsets: (scalar base) + zext(vgpr) addressing
     unsigned long long xv[12];     // the sweep in flight (issued at the previous block boundary)
+    bool dead = false;             // a sweep timed out (or another workgroup's did): stop waiting, the host reports DPDF_E_RUNTIME
     auto sweep_issue = [&](int tile, int t) __attribute__((always_inline)) {
         const unsigned long long* slot = a.xbuf + ((size_t)(tile0 + tile) * 2 + (t & 1)) * 16 * 256;     // uniform
 #pragma unroll
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void gru256_ring_kernel(Gru256CArgs a) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) all_in &= (unsigned)(xv[k] >> 32) == epoch;
             if (__builtin_expect(all_in, 1)) break;
-            if (++spins > (1u << 22)) { *a.err = 1; break; }
+            if (dead || cluster_spin_expired(spins, a.err, dead)) break;
             __builtin_amdgcn_s_sleep(1);
             sweep_issue(tile, t);
         }
@@ -761,6 +774,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster8_kernel(Gru256CArgs a) 
         gr[e] = g[0]; gz[e] = g[256]; gn[e] = g[512];
     }
     int cur = 0;
+    bool dead = false;             // a sweep timed out (or another workgroup's did): stop waiting, the host reports DPDF_E_RUNTIME
     for (int t = 0; t < a.Tc; ++t) {
         f32x4 pr = {0.f, 0.f, 0.f, 0.f}, pz = pr, pn = pr;
         const float* hrow = &Hs[cur][cl][128 * kh + 4 * q];
@@ -831,7 +845,7 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster8_kernel(Gru256CArgs a) 
 #pragma unroll
                 for (int k = 0; k < 14; ++k) all_in &= (unsigned)(xv[k] >> 32) == epoch;
                 if (all_in) break;
-                if (++spins > (1u << 22)) { *a.err = 1; break; }
+                if (dead || cluster_spin_expired(spins, a.err, dead)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
@@ -847,6 +861,124 @@ __global__ __launch_bounds__(256, 1) void gru256_cluster8_kernel(Gru256CArgs a) 
 #pragma unroll
     for (int e = 0; e < 2; ++e)
         if (ok[e]) a.hstate[(long)rc[e] * a.h_stride + u0 + cl] = h_own[e];
+}
+
+// ---------------------------------------------------------------------------------------------
+// gru256_cluster16_kernel: SIXTEEN workgroups per 16-row tile, for launches of one or two tiles (a single clip through
+// enhance(), <= 32 streams): there the step is pure latency and the cross-CU exchange (~2 us) is a fixed price, so the
+// dependent MFMA chain is cut as short as the tile shape allows.  Workgroup j owns 16 hidden units (one MFMA column
+// tile); its four waves split K four ways -- 48 MFMAs per wave per step (0.64 us) instead of 96 (cluster8) or 192
+// (cluster) -- the four partial sums are combined through LDS, wave w finishing C-layout row w of the 16x16 block.
+// Same granule protocol, exchange buffer layout and W_hh packing as gru256_cluster_kernel.
+__global__ __launch_bounds__(256, 1) void gru256_cluster16_kernel(Gru256CArgs a) {
+    __shared__ __attribute__((aligned(16))) float Hs[2][16][260];
+    __shared__ float Ps[4][3][4][64];            // per wave: partial pre-activations [gate][C-layout row i][lane]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int cl = lane & 15, q = lane >> 4;
+    const int rt = blockIdx.x >> 4, j = blockIdx.x & 15;
+    const int row0 = rt * 16;
+    const int u0 = 16 * j;                      // the workgroup's hidden units
+
+    float wr[16], wz[16], wn[16];               // K quarter w: chunks [4 w, 4 w + 4)
+    {
+        const float* wf = a.whh_frag + ((size_t)j * 3) * 64 * 64 + (size_t)(16 * w) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            wr[k] = wf[(size_t)(0 * 64 + k) * 64];
+            wz[k] = wf[(size_t)(1 * 64 + k) * 64];
+            wn[k] = wf[(size_t)(2 * 64 + k) * 64];
+        }
+    }
+    const float bhn = a.b_hn[u0 + cl];
+    // this wave finalises C-layout row i = w of the block: tile row q*4 + w
+    const int r_own = row0 + q * 4 + w;
+    const bool ok = r_own < a.B;
+    const int rc = ok ? r_own : a.B - 1;
+    float h_own = a.hstate[(long)rc * a.h_stride + u0 + cl];
+    for (int idx = tid; idx < 16 * 256; idx += 256) {
+        int r = idx >> 8, u = idx & 255;
+        int rr = row0 + r < a.B ? row0 + r : a.B - 1;
+        Hs[0][r][u] = a.hstate[(long)rr * a.h_stride + u];
+    }
+    __syncthreads();
+
+    unsigned long long* xb = a.xbuf + (size_t)rt * 2 * 16 * 256;
+    float gr, gz, gn;
+    {
+        const float* g = a.gi + ((size_t)rc * a.Tc) * 768 + u0 + cl;
+        gr = g[0]; gz = g[256]; gn = g[512];
+    }
+    int cur = 0;
+    bool dead = false;             // a sweep timed out (or another workgroup's did): stop waiting, the host reports DPDF_E_RUNTIME
+    for (int t = 0; t < a.Tc; ++t) {
+        f32x4 pr = {0.f, 0.f, 0.f, 0.f}, pz = pr, pn = pr;
+        const float* hrow = &Hs[cur][cl][64 * w + 4 * q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 h4 = *(const float4*)(hrow + 16 * c);
+            const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                pr = mfma16(hv[kb], wr[c * 4 + kb], pr);
+                pz = mfma16(hv[kb], wz[c * 4 + kb], pz);
+                pn = mfma16(hv[kb], wn[c * 4 + kb], pn);
+            }
+        }
+        // every wave's K-quarter partials through LDS (its own row too: the quarters are then added in the SAME order for
+        // every row, so that identical clips in different batch slots stay bit-identical)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { Ps[w][0][i][lane] = pr[i]; Ps[w][1][i][lane] = pz[i]; Ps[w][2][i][lane] = pn[i]; }
+        const float xr = gr, xz = gz, xn = gn;
+        if (t + 1 < a.Tc) {        // prefetch next step's input projections (independent of h)
+            const float* g = a.gi + ((size_t)rc * a.Tc + t + 1) * 768 + u0 + cl;
+            gr = g[0]; gz = g[256]; gn = g[512];
+        }
+        __syncthreads();
+        const int nxt = cur ^ 1;
+        const unsigned epoch = a.epoch_base + (unsigned)t + 1u;
+        unsigned long long* slot = xb + (size_t)(t & 1) * 16 * 256;
+        {
+            float sr = Ps[0][0][w][lane], sz = Ps[0][1][w][lane], sn = Ps[0][2][w][lane];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) { sr += Ps[k][0][w][lane]; sz += Ps[k][1][w][lane]; sn += Ps[k][2][w][lane]; }
+            const float r = sigmoid_f(xr + sr);
+            const float z = sigmoid_f(xz + sz);
+            const float n = gru_candidate(r, bhn + sn, xn);
+            h_own = gru_blend(z, n, h_own);
+        }
+        __hip_atomic_store(slot + (q * 4 + w) * 256 + u0 + cl,
+                           ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(h_own),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Hs[nxt][q * 4 + w][u0 + cl] = h_own;
+        if (ok) a.out[((size_t)rc * a.Tc + t) * 256 + u0 + cl] = h_own;
+        // sweep the fifteen peers' slices (15 x 16 rows x 16 units = 15 granules per thread), all loads in one batch;
+        // also after the LAST step (see gru256_cluster_kernel)
+        {
+            unsigned long long xv[15];
+            unsigned spins = 0;
+            for (;;) {
+                bool all_in = true;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) {
+                    const int r = tid >> 4, u = 16 * ((j + 1 + k) & 15) + (tid & 15);
+                    xv[k] = __hip_atomic_load(slot + r * 256 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < 15; ++k) all_in &= (unsigned)(xv[k] >> 32) == epoch;
+                if (all_in) break;
+                if (dead || cluster_spin_expired(spins, a.err, dead)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+                const int r = tid >> 4, u = 16 * ((j + 1 + k) & 15) + (tid & 15);
+                Hs[nxt][r][u] = __uint_as_float((unsigned)xv[k]);
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+    if (ok) a.hstate[(long)rc * a.h_stride + u0 + cl] = h_own;
 }
 
 // ---------------------------------------------------------------------------------------------
