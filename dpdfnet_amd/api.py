@@ -238,6 +238,21 @@ def _read_audio(path: Path):
     return x, int(sr)
 
 
+def _probe_audio(path: Path):
+    """(sample_rate, frames) from the file header only -- lets enhance_dir bucket a directory by length without
+    decoding it into RAM first."""
+    try:
+        import soundfile as sf  # type: ignore
+        info = sf.info(str(path))
+        return int(info.samplerate), int(info.frames)
+    except ImportError:
+        pass
+    if path.suffix.lower() != ".wav":
+        raise ValueError(f"Unsupported audio format {path.suffix!r} for file: {path} (only .wav without soundfile)")
+    with wave.open(str(path), "rb") as w:
+        return int(w.getframerate()), int(w.getnframes())
+
+
 def _write_pcm16(path: Path, audio: np.ndarray, sr: int) -> None:
     from .audio import pcm16_safe
     path.parent.mkdir(parents=True, exist_ok=True)
@@ -272,8 +287,13 @@ def enhance_file(
 # directory batch (reference cli.py:222-311 `_run_enhance_dir`): the reference fans files out over a CPU thread pool,
 # one ORT session per thread; here the files are read, brought to the model rate, bucketed by length and each bucket
 # goes through the GPU as ONE ragged call (`dpdf_enhance_batch_ragged`).  Same discovery rules, output naming and
-# error aggregation.  Files are decoded bucket-independent but results are written as soon as their bucket is done.
+# error aggregation.  Lengths come from the file headers; files are decoded, enhanced and written bucket by bucket.
 SUPPORTED_EXTENSIONS = frozenset({".wav"})            # stdlib reader; soundfile (optional) widens this at run time
+
+
+def backend_resample_len(n: int, sr_in: int, sr_out: int) -> int:
+    """Length of `n` samples after ensure_sample_rate (dpdf_resample_len: ceil(n * sr_out / sr_in))."""
+    return n if sr_in == sr_out else -(-int(n) * int(sr_out) // int(sr_in))
 
 
 def _supported_extensions() -> frozenset:
@@ -313,40 +333,55 @@ def enhance_dir(
     out_dir.mkdir(parents=True, exist_ok=True)
 
     errors: List = []
+    # pass 1: headers only -> lengths at the model rate -> buckets.  pass 2: decode, enhance and write bucket by bucket, so
+    # that the decoded audio held in RAM is bounded by one bucket (MAX_BATCH_SAMPLES), not by the directory.
     good: List[Path] = []
-    monos: List[np.ndarray] = []
-    rates: List[int] = []
-    model_clips: List[np.ndarray] = []
+    est_len: List[int] = []
     for p in files:
         try:
-            audio, sr = _read_audio(p)
-            mono = to_mono(audio)
-            mc = ensure_sample_rate(mono, int(sr), msr)
-            good.append(p); monos.append(mono); rates.append(int(sr)); model_clips.append(mc)
+            sr, n = _probe_audio(p)
+            good.append(p)
+            est_len.append(int(backend_resample_len(n, sr, msr)))
         except Exception as exc:  # one bad file must not stop the directory (cli.py:296-305)
             errors.append((p, exc))
 
     written: Dict[Path, Path] = {}
     import threading
     wlock = threading.Lock()
+    buckets = _length_buckets(est_len)
+    empties = [i for i, n in enumerate(est_len) if n == 0]
+    for bucket in buckets + ([empties] if empties else []):
+        paths = [good[i] for i in bucket]
+        monos: List[np.ndarray] = []
+        rates: List[int] = []
+        model_clips: List[np.ndarray] = []
+        kept: List[Path] = []
+        for p in paths:
+            try:
+                audio, sr = _read_audio(p)
+                mono = to_mono(audio)
+                mc = ensure_sample_rate(mono, int(sr), msr)
+                kept.append(p); monos.append(mono); rates.append(int(sr)); model_clips.append(mc)
+            except Exception as exc:
+                errors.append((p, exc))
 
-    def _emit(i: int, enhanced_model_sr: np.ndarray) -> None:
-        p, mono, sr = good[i], monos[i], rates[i]
-        y = fit_length(ensure_sample_rate(enhanced_model_sr, msr, sr), mono.shape[0])
-        dst = out_dir / f"{p.stem}_enhanced.wav"
-        _write_pcm16(dst, y, sr)
-        with wlock:
-            written[p] = dst
-        if file_callback is not None:
-            file_callback(p, dst)
+        def _emit(i: int, enhanced_model_sr: np.ndarray, kept=kept, monos=monos, rates=rates) -> None:
+            p, mono, sr = kept[i], monos[i], rates[i]
+            y = fit_length(ensure_sample_rate(enhanced_model_sr, msr, sr), mono.shape[0])
+            dst = out_dir / f"{p.stem}_enhanced.wav"
+            _write_pcm16(dst, y, sr)
+            with wlock:
+                written[p] = dst
+            if file_callback is not None:
+                file_callback(p, dst)
 
-    try:
-        res = _enhance_model_rate_clips(runtimes, model_clips, attn, on_done=_emit)
-        for i, r in enumerate(res):
-            if r is None:                       # empty file: the reference returns the (empty) waveform itself
-                _emit(i, monos[i].copy())
-    except Exception as exc:
-        errors.extend((p, exc) for p in good if p not in written)
+        try:
+            res = _enhance_model_rate_clips(runtimes, model_clips, attn, on_done=_emit)
+            for i, r in enumerate(res):
+                if r is None:                   # empty file: the reference returns the (empty) waveform itself
+                    _emit(i, monos[i].copy())
+        except Exception as exc:
+            errors.extend((p, exc) for p in kept if p not in written)
     if errors:
         msgs = "\n".join(f"  {p}: {e}" for p, e in errors)
         raise RuntimeError(f"Errors during processing:\n{msgs}")

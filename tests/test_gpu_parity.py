@@ -385,3 +385,31 @@ def test_optin_bf16x3_gru64_mode_keeps_fp32_parity(tag, mode, be):
     for b in (0, 100, 191):
         assert rms(big[b] - o.enhance(wav[b])) < WAVE_TOL, b
     m.close()
+
+
+def test_every_gru256_scan_form_agrees(be):
+    """The five forms of the GRU-256 recurrence -- single-workgroup scan (`gru256_cluster` = 0), 4-workgroup cluster, 8- and
+    16-workgroup clusters for small launches, round-robin ring (opt-in) -- on the same input: equal to rounding, state included."""
+    g, meta = load_golden("16k_nb1")
+    blob = golden_blob(meta)
+    m = be.HipModel(meta["sample_rate"], meta["nb"], blob, 0)
+    o = make_oracle(meta, blob)
+    spec = np.stack([o.stft(synth_clip(3000, 16000, 900 + i)) for i in range(40)])      # 40 streams = 3 tiles
+    st0 = np.tile(m.initial_state(), (40, 1))
+    outs = {}
+    for tag, opts, ov in (("cluster", {"gru256_c16_tiles": 0, "gru256_cluster": 1}, 27 & ~16),
+                          ("cluster8", {"gru256_c16_tiles": 0}, 27), ("cluster16", {"gru256_c16_tiles": 4}, 27),
+                          ("single_wg", {"gru256_cluster": 0}, 27)):
+        for k, v in opts.items():
+            m.set_option(k, v)
+        m.set_overlap(ov)
+        outs[tag] = m.run_frames(spec, st0)
+    m.set_option("gru256_cluster", 1); m.set_option("gru256_c16_tiles", 4); m.set_overlap(27)
+    ref, st_ref = outs["cluster"]
+    scale = float(np.abs(ref).max())
+    for tag, (out, st) in outs.items():
+        assert np.abs(out - ref).max() < 2e-5 * scale, tag
+        assert np.abs(st - st_ref).max() < 5e-5, tag
+    r0, s0 = o.run_frames(spec[7])
+    assert np.abs(ref[7] - r0).max() < STAGE_REL_TOL * scale and np.abs(st_ref[7] - s0).max() < 2e-4
+    m.close()
