@@ -32,6 +32,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before torch / HIP initialise: see dpdfnet_amd/__init__.py
 
 METRIC = "frames/s (10 ms hop) per MI355X, dpdfnet4@16 kHz; PESQ Δ vs ref ≤0.001"
 MODEL, SR, NB = "dpdfnet4", 16000, 4

@@ -4,7 +4,13 @@ Drop-in for the reference package's hot path (reference package/src/dpdfnet/__in
 same five public names, executed by hand-written gfx950 HIP kernels through a C ABI
 (include/dpdfnet_hip.h) instead of a per-frame onnxruntime CPU session.
 """
+import os as _os
 from typing import TYPE_CHECKING
+
+# The engine drives four HIP streams per handle concurrently; HIP's default of four hardware queues per process makes them
+# share queues (and serialise) as soon as anything else owns a stream.  Must be set before the HIP runtime initialises;
+# an application that sets it itself wins (csrc/dpdf_model.hip: dpdf_default_hw_queues).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 __all__ = [
     "enhance",

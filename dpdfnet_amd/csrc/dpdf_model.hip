@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -30,6 +31,17 @@
 #include "df_ring.h"
 #include "dec_last.h"
 #include "gru_bf16x3.h"
+
+// ------------------------------------------------------------------------------------------------
+// HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
+// streams per handle concurrently (stage 1, ERB branch, stage 2, DF decoder), so with the default a second handle --
+// even an idle one -- or any other stream user makes two of them share a queue and serialise: one 10 s clip 11.4 ms
+// alone, 16.0 ms beside a second handle; with 8 queues 11.4 ms in both cases (tools/clock_probe.py).  The variable is
+// read when the HIP runtime initialises, so it is set when this library is loaded, unless the host application has
+// chosen a value itself (it has no effect if HIP was already initialised: dpdfnet_amd/__init__.py and bench.py also set
+// it before anything touches the GPU).
+// ------------------------------------------------------------------------------------------------
+__attribute__((constructor)) static void dpdf_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -290,7 +302,7 @@ struct dpdf_model {
     int overlap = 27;                  // bit 5 (sub-stage pipeline of stage 2 for <= 64 streams) is OFF by default: measured slower (run_stage2_pipe)
     int pipe_chunk = 128;              // automatic chunk length (frames) of the sub-stage pipeline for small batches
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
-    int gru256_c16_tiles = 4;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
+    int gru256_c16_tiles = 2;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
                                        // of >= 8 tiles).  Measured and left OFF: DESIGN.md section 7.
     int gru64_bf16x3 = 0;              // OPT-IN: GRU-64 scans as three-limb bf16 products on the bf16 matrix pipe (gru_bf16x3.h); default 0 = fp32 MFMA;
@@ -350,6 +362,41 @@ static int check_device_err(dpdf_model* m) {
     return set_err(DPDF_E_RUNTIME, "GRU-256 cluster exchange timed out (peer workgroups were not co-resident); the results of "
                                    "this call are invalid -- retry, or run the engine on a GPU it does not share");
 }
+
+// streams + events of one lane; `pipe` adds the three extra streams of the sub-stage pipeline (run_stage2_pipe)
+static int init_lane(Lane& L, bool pipe) {
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (!L.sA) {
+        HIP_TRY(hipStreamCreateWithFlags(&L.sA, hipStreamNonBlocking));
+        // stage 2 is latency-bound (GRU-256 cluster scans): give its workgroups dispatch priority
+        HIP_TRY(hipStreamCreateWithPriority(&L.sB, hipStreamNonBlocking, hi));
+        HIP_TRY(hipStreamCreateWithFlags(&L.sC, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithPriority(&L.sD, hipStreamNonBlocking, hi));
+        for (int p = 0; p < NRING; ++p) {
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_a[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_be[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_bd[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_cd[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_s1[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_s2[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_fk[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_jn[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_dfk[p], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.ev_djn[p], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+    }
+    if (pipe && !L.sE) {
+        HIP_TRY(hipStreamCreateWithPriority(&L.sE, hipStreamNonBlocking, hi));
+        HIP_TRY(hipStreamCreateWithPriority(&L.sF, hipStreamNonBlocking, hi));
+        HIP_TRY(hipStreamCreateWithPriority(&L.sG, hipStreamNonBlocking, hi));
+    }
+    return DPDF_OK;
+}
+
 
 namespace {
 
@@ -1333,6 +1380,7 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     int rc;
     for (int g = 0; g < G; ++g) {
         m->ln = &m->lanes[g];
+        if ((rc = init_lane(m->lanes[g], pipe2))) { m->ln = &m->lanes[0]; return rc; }
         if ((rc = ensure_ws(m, Bg[g], chunk))) { m->ln = &m->lanes[0]; return rc; }
         if (pipe2 && (rc = ensure_pipe_ws(m, Bg[g], chunk))) { m->ln = &m->lanes[0]; return rc; }
     }
@@ -1508,44 +1556,12 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
         m->istft_frag = A.add(frag);
     }
 
-    // ---- upload ----
-    for (int g = 0; g < 2; ++g) {
-        Lane& L = m->lanes[g];
-        HIP_TRY(hipStreamCreateWithFlags(&L.sA, hipStreamNonBlocking));
-        {   // stage 2 is latency-bound (GRU-256 cluster scans): give its workgroups dispatch priority
-            int lo = 0, hi = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIP_TRY(hipStreamCreateWithPriority(&L.sB, hipStreamNonBlocking, hi));
-        }
-        HIP_TRY(hipStreamCreateWithFlags(&L.sC, hipStreamNonBlocking));
-        {
-            int lo = 0, hi = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIP_TRY(hipStreamCreateWithPriority(&L.sD, hipStreamNonBlocking, hi));
-        }
-        {
-            int lo = 0, hi = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIP_TRY(hipStreamCreateWithPriority(&L.sE, hipStreamNonBlocking, hi));
-            HIP_TRY(hipStreamCreateWithPriority(&L.sF, hipStreamNonBlocking, hi));
-            HIP_TRY(hipStreamCreateWithPriority(&L.sG, hipStreamNonBlocking, hi));
-        }
-        for (int p = 0; p < NRING; ++p) {
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_a[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_be[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_bd[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_cd[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_s1[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_s2[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_fk[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_jn[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_dfk[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_djn[p], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
-    }
+    // ---- streams: lane 0 now; the second lane and the sub-stage pipeline's streams only when first used (init_lane):
+    // HIP multiplexes streams onto a handful of hardware queues, and streams that merely exist still take part in that
+    // mapping -- with 14 streams per handle the four active ones of a second handle ended up sharing queues (one
+    // 10 s clip 11.5 -> 14.6 ms, one streaming hop 1.33 -> 2.1 ms when measured beside another live handle)
+    HIP_TRY(hipSetDevice(device));
+    { int rc_ = init_lane(m->lanes[0], false); if (rc_) return rc_; }
     m->stream = m->lanes[0].sA;
     m->cur = m->stream;
     m->ln = &m->lanes[0];
