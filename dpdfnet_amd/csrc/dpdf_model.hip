@@ -302,6 +302,7 @@ struct dpdf_model {
     int overlap = 27;                  // bit 5 (sub-stage pipeline of stage 2 for <= 64 streams) is OFF by default: measured slower (run_stage2_pipe)
     int pipe_chunk = 128;              // automatic chunk length (frames) of the sub-stage pipeline for small batches
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
+    int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
     int gru256_c16_tiles = 2;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
                                        // of >= 8 tiles).  Measured and left OFF: DESIGN.md section 7.
@@ -786,7 +787,7 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
             // two interleaved tiles per cluster from 8 tiles (128 streams) on: the launch is throughput-relevant there (it
             // pins CUs the GRU-64 kernels want) and stage 2 has slack; below that the step latency matters
             if ((m->overlap & 16) && ntiles <= m->gru256_c16_tiles) hipLaunchKernelGGL(gru256_cluster16_kernel, dim3(ntiles * 16), dim3(256), 0, m->cur, a);
-            else if ((m->overlap & 16) && ntiles <= 4) hipLaunchKernelGGL(gru256_cluster8_kernel, dim3(ntiles * 8), dim3(256), 0, m->cur, a);
+            else if ((m->overlap & 16) && ntiles <= m->gru256_c8_tiles) hipLaunchKernelGGL(gru256_cluster8_kernel, dim3(ntiles * 8), dim3(256), 0, m->cur, a);
             else if (m->gru256_pair && ntiles >= 8 && ntiles % m->gru256_pair == 0) {
                 const int nt = m->gru256_pair;
                 if (nt == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(gru256_ring_kernel<4>), dim3(ntiles), dim3(256), 0, m->cur, a);
@@ -1693,6 +1694,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
+    else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_c16_tiles") m->gru256_c16_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_pair") m->gru256_pair = (value >= 2 && value <= 4) ? value : 0;
     else if (n == "gru256_cluster") m->use_gru256_cluster = value != 0;
