@@ -31,6 +31,7 @@
 #include "df_ring.h"
 #include "dec_last.h"
 #include "gru_bf16x3.h"
+#include "gru_stack.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -201,7 +202,7 @@ struct GruW64 { size_t wfrag, bias; int ndirs;
                 size_t wlimb;                 // opt-in bf16x3 mode: the same weights as three bf16 limbs per value (gru_bf16x3.h), in float-sized arena slots
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
 struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
-struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn; };   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
+struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn, ih_as_hh; };   // ih_as_hh: W_ih packed like hh_frag (second cell of a stacked pair, gru_stack.h)   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
                 size_t fci_epi, fce_epi;
                 size_t fcl_fwd, fcl_bwd, fcl_inter; };   // opt-in bf16x3 mode: fc halves as bf16 limbs (gru_bf16x3.h)   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
@@ -284,6 +285,8 @@ struct Lane {
     // GRU-256 cluster exchange granules: [0] embedding + ERB-decoder cells, [1] DF-decoder cells (they may run concurrently)
     // (the sub-stage pipeline runs all five cells concurrently: [2] ERB-decoder cell 0, [3] cell 1, [4] DF-decoder cell 1)
     unsigned long long* gru_xbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int gru_xbuf_tiles[5] = {0, 0, 0, 0, 0}; unsigned gru_epoch[5] = {0, 0, 0, 0, 0};
+    // stacked decoder pairs (gru256_stack16_kernel): per pair [tiles][Tcap + 2][16][256] granules = cell A's per-frame ring + cell B's two slots
+    unsigned long long* gru_sbuf[2] = {nullptr, nullptr}; int gru_sbuf_tiles[2] = {0, 0}, gru_sbuf_T[2] = {0, 0}; unsigned gru_sepoch[2] = {0, 0};
     const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; const float* dbg_emb = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
 };
 
@@ -302,6 +305,7 @@ struct dpdf_model {
     int overlap = 27;                  // bit 5 (sub-stage pipeline of stage 2 for <= 64 streams) is OFF by default: measured slower (run_stage2_pipe)
     int pipe_chunk = 128;              // automatic chunk length (frames) of the sub-stage pipeline for small batches
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
+    int gru256_stack = 1;              // one or two tiles: the two cells of each decoder stack as one wavefront launch (gru_stack.h)
     int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
     int gru256_c16_tiles = 2;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
@@ -567,6 +571,15 @@ Gru256W build_gru256(Arena& A, const Blob& B, const std::string& p) {
                         hh[((((size_t)w * 3 + gate) * 16 + c) * 4 + kb) * 64 + lane] = whh[(size_t)j * 256 + k];
                     }
     g.hh_frag = A.add(hh);
+    for (int w = 0; w < 16; ++w)
+        for (int gate = 0; gate < 3; ++gate)
+            for (int c = 0; c < 16; ++c)
+                for (int kb = 0; kb < 4; ++kb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        int k = kperm(c, lane >> 4, kb), j = gate * 256 + 16 * w + (lane & 15);
+                        hh[((((size_t)w * 3 + gate) * 16 + c) * 4 + kb) * 64 + lane] = wih[(size_t)j * 256 + k];
+                    }
+    g.ih_as_hh = A.add(hh);
     return g;
 }
 std::vector<DprnnW> build_dprnn(Arena& A, const Blob& B, const std::string& p, int nb) {
@@ -749,23 +762,60 @@ void run_gl_auto(dpdf_model* m, const GlW& g, const float* in, size_t lda, float
 // handful of workgroups walking all K panels one after the other; narrower column blocks multiply the workgroups.
 constexpr int SMALL_M_ROWS = 512;
 // which: 0 = embedding / ERB-decoder cells (scratch ws.gi, granules [0]); 1 = DF-decoder cells (ws.gi2, granules [1])
+void run_gru256_proj(dpdf_model* m, const Gru256W& g, const float* x, float* gi, int M) {
+    ProfScope ps(m, "gru256_proj");
+    PlainA<64> ap{x, 256, 0, 256};
+    if (M <= SMALL_M_ROWS) {
+        BiasActStore<2> ep{gi, 768, 32, m->C(g.ih_bias), 32, 32, ACT_NONE};
+        launch_gemm_rows<2, 64, false>(m->cur, ap, m->C(g.ih_frag_s), ep, M, 256, 24);
+    } else {
+        // many rows: waves split over columns (same 32-column packing, 6 quadruples of column groups): a quarter
+        // of the B-fragment loads of the row-split form, 7.3 -> 5.6 ms per step of the headline workload
+        BiasActStore<2> ep{gi, 768, 32, m->C(g.ih_bias), 32, 32, ACT_NONE};
+        launch_gemm_rows_wn<2, 64>(m->cur, ap, m->C(g.ih_frag_s), ep, M, 256, 6);
+    }
+}
+
+// Two stacked cells (g0 -> g1, the second one's input is the first one's hidden state) as one wavefront launch
+// (gru_stack.h) when the launch is one or two tiles; false = not eligible, run the cells one after the other.
+bool run_gru256_stack(dpdf_model* m, const Gru256W& g0, const Gru256W& g1, const float* x, float* out0, float* out1, float* state, long S,
+                      int hoff, int B, int Tc, int which) {
+    const int ntiles = (B + 15) / 16;
+    if (!m->gru256_stack || !(m->overlap & 16) || !m->use_gru256_cluster || ntiles > m->gru256_c16_tiles || which < 0 || which > 1) return false;
+    Lane& L = *m->ln;
+    if (ntiles > L.gru_sbuf_tiles[which] || Tc > L.gru_sbuf_T[which] || !L.gru_sbuf[which] || !m->d_err) {
+        if (L.gru_sbuf[which]) { L.sync_all(); (void)hipFree(L.gru_sbuf[which]); L.gru_sbuf[which] = nullptr; }
+        const int nt = std::max(ntiles, L.gru_sbuf_tiles[which]), T = std::max(Tc, L.gru_sbuf_T[which]);
+        const size_t bytes = (size_t)nt * (T + 2) * 16 * 256 * 8;
+        if (hipMalloc((void**)&L.gru_sbuf[which], bytes) != hipSuccess) { L.gru_sbuf_tiles[which] = L.gru_sbuf_T[which] = 0; return false; }
+        (void)hipMemsetAsync(L.gru_sbuf[which], 0, bytes, m->cur);
+        L.gru_sepoch[which] = 0; L.gru_sbuf_tiles[which] = nt; L.gru_sbuf_T[which] = T;
+        if (!m->d_err) {
+            if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return false;
+            (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->cur);
+        }
+    }
+    if (L.gru_sepoch[which] > 0xF0000000u) {     // epoch wrap: re-zero the granules
+        (void)hipMemsetAsync(L.gru_sbuf[which], 0, (size_t)L.gru_sbuf_tiles[which] * (L.gru_sbuf_T[which] + 2) * 16 * 256 * 8, m->cur);
+        L.gru_sepoch[which] = 0;
+    }
+    float* gi = which ? L.ws.gi2.p : L.ws.gi.p;
+    run_gru256_proj(m, g0, x, gi, B * Tc);
+    ProfScope ps(m, "gru256_scan");
+    unsigned long long* ring = L.gru_sbuf[which];
+    unsigned long long* xb = ring + (size_t)ntiles * Tc * 16 * 256;      // cell B's two slots behind this launch's rings
+    Gru256SArgs a{gi, out0, out1, m->C(g0.hh_frag), m->C(g0.b_hn), m->C(g1.ih_as_hh), m->C(g1.hh_frag), m->C(g1.ih_bias), m->C(g1.b_hn),
+                  state + hoff, state + hoff + 256, S, B, Tc, ring, xb, L.gru_sepoch[which], m->d_err};
+    L.gru_sepoch[which] += (unsigned)Tc;
+    hipLaunchKernelGGL(gru256_stack16_kernel, dim3(ntiles * 32), dim3(256), 0, m->cur, a);
+    return true;
+}
+
 void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int Tc, int which = 0,
                 float* gi_buf = nullptr) {
     const int M = B * Tc;
     float* gi = gi_buf ? gi_buf : (which ? m->ln->ws.gi2.p : m->ln->ws.gi.p);
-    {
-        ProfScope ps(m, "gru256_proj");
-        PlainA<64> ap{x, 256, 0, 256};
-        if (M <= SMALL_M_ROWS) {
-            BiasActStore<2> ep{gi, 768, 32, m->C(g.ih_bias), 32, 32, ACT_NONE};
-            launch_gemm_rows<2, 64, false>(m->cur, ap, m->C(g.ih_frag_s), ep, M, 256, 24);
-        } else {
-            // many rows: waves split over columns (same 32-column packing, 6 quadruples of column groups): a quarter
-            // of the B-fragment loads of the row-split form, 7.3 -> 5.6 ms per step of the headline workload
-            BiasActStore<2> ep{gi, 768, 32, m->C(g.ih_bias), 32, 32, ACT_NONE};
-            launch_gemm_rows_wn<2, 64>(m->cur, ap, m->C(g.ih_frag_s), ep, M, 256, 6);
-        }
-    }
+    run_gru256_proj(m, g, x, gi, M);
     {
         ProfScope ps(m, "gru256_scan");
         const int ntiles = (B + 15) / 16;
@@ -1164,8 +1214,10 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
             ProfScope ps(m, "grouped_linear");
             run_gl_auto(m, m->df_lin_in, w.emb.p, 512, ga, 256, BT, ACT_RELU);
         }
-        run_gru256(m, m->df_gru0, ga, gb, state, S, L.df_dec_gru, B, Tc, which);
-        run_gru256(m, m->df_gru1, gb, gc, state, S, L.df_dec_gru + 256, B, Tc, which);
+        if (!run_gru256_stack(m, m->df_gru0, m->df_gru1, ga, gb, gc, state, S, L.df_dec_gru, B, Tc, which)) {
+            run_gru256(m, m->df_gru0, ga, gb, state, S, L.df_dec_gru, B, Tc, which);
+            run_gru256(m, m->df_gru1, gb, gc, state, S, L.df_dec_gru + 256, B, Tc, which);
+        }
         {
             ProfScope ps(m, "grouped_linear");
             run_gl_auto(m, m->df_skip, w.emb.p, 512, ga, 256, BT, ACT_NONE);   // c = df_gru(emb) + df_skip(emb)
@@ -1194,8 +1246,10 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->ed_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
     }
-    run_gru256(m, m->ed_gru0, w.g256a.p, w.g256b.p, state, S, L.erb_dec_gru, B, Tc);
-    run_gru256(m, m->ed_gru1, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc);
+    if (!run_gru256_stack(m, m->ed_gru0, m->ed_gru1, w.g256a.p, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru, B, Tc, 0)) {
+        run_gru256(m, m->ed_gru0, w.g256a.p, w.g256b.p, state, S, L.erb_dec_gru, B, Tc);
+        run_gru256(m, m->ed_gru1, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc);
+    }
     float* dembp = w.demb.p;
     {
         ProfScope ps(m, "grouped_linear");
@@ -1605,6 +1659,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
         L.sync_all();
         L.ws.release();
         for (int k = 0; k < 5; ++k) if (L.gru_xbuf[k]) (void)hipFree(L.gru_xbuf[k]);
+        for (int k = 0; k < 2; ++k) if (L.gru_sbuf[k]) (void)hipFree(L.gru_sbuf[k]);
     }
     DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state};
     for (DevBuf* b : bufs) b->release();
@@ -1694,6 +1749,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
+    else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_c16_tiles") m->gru256_c16_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_pair") m->gru256_pair = (value >= 2 && value <= 4) ? value : 0;

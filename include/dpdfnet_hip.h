@@ -130,7 +130,8 @@ int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
  * 2 = the same without the fused forms), "hoist_gi" (small-batch GRU-64 input
  * GEMM hoisting), "gru256_cluster" (0: single-workgroup GRU-256 scan), "gru256_pair" (0 off (default) / 2 / 3 / 4 round-robin tiles per
  * GRU-256 cluster, gru256_ring_kernel, for launches of >= 8 tiles), "gru256_c8_tiles" / "gru256_c16_tiles" (launches of at most this many 16-row
- * tiles run the GRU-256 scans on 8 / 16 workgroups per tile; defaults 4 / 2), "pipe_chunk".  Unknown name -> DPDF_E_INVALID. */
+ * tiles run the GRU-256 scans on 8 / 16 workgroups per tile; defaults 4 / 2), "gru256_stack" (1 (default): launches of at most
+ * gru256_c16_tiles tiles run the two cells of each decoder stack as one wavefront launch, gru_stack.h), "pipe_chunk".  Unknown name -> DPDF_E_INVALID. */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);
 
 /* Rational polyphase resampler on the device, for `ensure_sample_rate` when the caller's rate differs from the
