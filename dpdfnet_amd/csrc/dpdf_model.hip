@@ -201,7 +201,7 @@ struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs;
                 size_t wlimb;                 // opt-in bf16x3 mode: the same weights as three bf16 limbs per value (gru_bf16x3.h), in float-sized arena slots
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
-struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
+struct GlW { size_t frag, bias, raw; int G, Og, Ig, NT; };   // raw: the reference's [G][Og][Ig] weight as is (gru256_chain16_kernel)
 struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn, ih_as_hh; };   // ih_as_hh: W_ih packed like hh_frag (second cell of a stacked pair, gru_stack.h)   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
                 size_t fci_epi, fce_epi;
@@ -286,6 +286,8 @@ struct Lane {
     // (the sub-stage pipeline runs all five cells concurrently: [2] ERB-decoder cell 0, [3] cell 1, [4] DF-decoder cell 1)
     unsigned long long* gru_xbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int gru_xbuf_tiles[5] = {0, 0, 0, 0, 0}; unsigned gru_epoch[5] = {0, 0, 0, 0, 0};
     // stacked decoder pairs (gru256_stack16_kernel): per pair [tiles][Tcap + 2][16][256] granules = cell A's per-frame ring + cell B's two slots
+    // all five cells as one launch (gru256_chain16_kernel): 7 per-frame rings [tiles][Tcap][16][256]
+    unsigned long long* gru_cbuf = nullptr; int gru_cbuf_tiles = 0, gru_cbuf_T = 0; unsigned gru_cepoch = 0;
     unsigned long long* gru_sbuf[2] = {nullptr, nullptr}; int gru_sbuf_tiles[2] = {0, 0}, gru_sbuf_T[2] = {0, 0}; unsigned gru_sepoch[2] = {0, 0};
     const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; const float* dbg_emb = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
 };
@@ -305,6 +307,9 @@ struct dpdf_model {
     int overlap = 27;                  // bit 5 (sub-stage pipeline of stage 2 for <= 64 streams) is OFF by default: measured slower (run_stage2_pipe)
     int pipe_chunk = 128;              // automatic chunk length (frames) of the sub-stage pipeline for small batches
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
+    // OPT-IN (measured, no gain: DESIGN.md section 7): at most gru256_chain_tiles tiles -> all five GRU-256 cells of stage 2
+    // as one wavefront launch (gru_stack.h: gru256_chain16_kernel)
+    int gru256_chain = 0, gru256_chain_tiles = 2;
     int gru256_stack = 1;              // one or two tiles: the two cells of each decoder stack as one wavefront launch (gru_stack.h)
     int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
     int gru256_c16_tiles = 2;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
@@ -539,6 +544,7 @@ GlW build_gl(Arena& A, const Blob& B, const std::string& p, int G, int Og, int I
     }
     g.frag = A.add(frag);
     g.bias = A.add(std::vector<float>(b, b + (size_t)G * Og));
+    g.raw = A.add(std::vector<float>(w, w + (size_t)G * Og * Ig));
     return g;
 }
 Gru256W build_gru256(Arena& A, const Blob& B, const std::string& p) {
@@ -808,6 +814,52 @@ bool run_gru256_stack(dpdf_model* m, const Gru256W& g0, const Gru256W& g1, const
                   state + hoff, state + hoff + 256, S, B, Tc, ring, xb, L.gru_sepoch[which], m->d_err};
     L.gru_sepoch[which] += (unsigned)Tc;
     hipLaunchKernelGGL(gru256_stack16_kernel, dim3(ntiles * 32), dim3(256), 0, m->cur, a);
+    return true;
+}
+
+// All five GRU-256 cells of stage 2 as one wavefront launch (gru_stack.h: gru256_chain16_kernel) when the launch is one or
+// two tiles.  x: the embedding cell's input [B*Tc][256]; out_e / out_erb / out_df: hidden sequences of the embedding cell
+// and of the second cell of each decoder.  false = not eligible.
+bool run_gru256_chain(dpdf_model* m, const float* x, float* out_e, float* out_erb, float* out_df, float* state, long S, int B, int Tc) {
+    const int ntiles = (B + 15) / 16;
+    if (!m->gru256_chain || !(m->overlap & 16) || !m->use_gru256_cluster || ntiles > m->gru256_chain_tiles) return false;
+    const dpdf_state_layout& SL = m->L;
+    Lane& L = *m->ln;
+    if (ntiles > L.gru_cbuf_tiles || Tc > L.gru_cbuf_T || !L.gru_cbuf || !m->d_err) {
+        if (L.gru_cbuf) { L.sync_all(); (void)hipFree(L.gru_cbuf); L.gru_cbuf = nullptr; }
+        const int nt = std::max(ntiles, L.gru_cbuf_tiles), T = std::max(Tc, L.gru_cbuf_T);
+        const size_t bytes = (size_t)7 * nt * T * 16 * 256 * 8;
+        if (hipMalloc((void**)&L.gru_cbuf, bytes) != hipSuccess) { L.gru_cbuf_tiles = L.gru_cbuf_T = 0; return false; }
+        (void)hipMemsetAsync(L.gru_cbuf, 0, bytes, m->cur);
+        L.gru_cepoch = 0; L.gru_cbuf_tiles = nt; L.gru_cbuf_T = T;
+        if (!m->d_err) {
+            if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return false;
+            (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->cur);
+        }
+    }
+    if (L.gru_cepoch > 0xF0000000u) {
+        (void)hipMemsetAsync(L.gru_cbuf, 0, (size_t)7 * L.gru_cbuf_tiles * L.gru_cbuf_T * 16 * 256 * 8, m->cur);
+        L.gru_cepoch = 0;
+    }
+    run_gru256_proj(m, m->enc_gru, x, L.ws.gi.p, B * Tc);
+    ProfScope ps(m, "gru256_scan");
+    const size_t rsz = (size_t)ntiles * Tc * 16 * 256;
+    unsigned long long* R = L.gru_cbuf;     // rings: 0 E, 1 ERB cell 0, 2 ERB cell 1, 3 DF cell 0, 4 DF cell 1, 5 x ERB, 6 x DF
+    const Gru256W* gw[5] = {&m->enc_gru, &m->ed_gru0, &m->ed_gru1, &m->df_gru0, &m->df_gru1};
+    const int hoff[5] = {SL.emb_gru, SL.erb_dec_gru, SL.erb_dec_gru + 256, SL.df_dec_gru, SL.df_dec_gru + 256};
+    float* outs[5] = {out_e, nullptr, out_erb, nullptr, out_df};
+    const unsigned long long* ups[5] = {nullptr, R + 5 * rsz, R + 1 * rsz, R + 6 * rsz, R + 3 * rsz};
+    Gru256ChainArgs a{};
+    for (int k = 0; k < 5; ++k)
+        a.c[k] = Gru256ChainCell{m->C(gw[k]->hh_frag), m->C(gw[k]->ih_as_hh), m->C(gw[k]->ih_bias), m->C(gw[k]->b_hn), state + hoff[k], outs[k], R + k * rsz, ups[k]};
+    a.gi = L.ws.gi.p;
+    a.w_out = m->C(m->enc_lin_out.raw); a.b_out = m->C(m->enc_lin_out.bias);
+    a.w_ine = m->C(m->ed_lin_in.raw); a.b_ine = m->C(m->ed_lin_in.bias);
+    a.w_ind = m->C(m->df_lin_in.raw); a.b_ind = m->C(m->df_lin_in.bias);
+    a.xr_e = R + 5 * rsz; a.xr_d = R + 6 * rsz;
+    a.h_stride = S; a.B = B; a.Tc = Tc; a.epoch_base = L.gru_cepoch; a.err = m->d_err;
+    L.gru_cepoch += (unsigned)Tc;
+    hipLaunchKernelGGL(gru256_chain16_kernel, dim3(ntiles * 80), dim3(256), 0, m->cur, a);
     return true;
 }
 
@@ -1195,7 +1247,9 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
                                       hipMemcpyDeviceToDevice, st));
         run_gl_auto(m, m->enc_lin_in, w.embin.p, 1024, w.g256a.p, 256, BT, ACT_RELU);
     }
-    run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc);
+    // one or two tiles: all five cells as one wavefront launch (the decoders' linear_in layers are computed in it)
+    const bool chained = run_gru256_chain(m, w.g256a.p, w.g256b.p, w.g256c.p, w.g256f.p, state, S, B, Tc);
+    if (!chained) run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc);
     {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->enc_lin_out, w.g256b.p, 256, w.emb.p, 512, BT, ACT_RELU);
@@ -1208,13 +1262,14 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     // ---- DF decoder (dpdfnet.py:486-519) ----
     {
         m->cur = sd;
-        float* ga = fork ? w.g256d.p : w.g256a.p; float* gb = fork ? w.g256e.p : w.g256b.p; float* gc = fork ? w.g256f.p : w.g256c.p;
+        float* ga = fork ? w.g256d.p : w.g256a.p; float* gb = fork ? w.g256e.p : w.g256b.p; float* gc = (fork || chained) ? w.g256f.p : w.g256c.p;
         const int which = fork ? 1 : 0;
-        {
+        if (!chained) {
             ProfScope ps(m, "grouped_linear");
             run_gl_auto(m, m->df_lin_in, w.emb.p, 512, ga, 256, BT, ACT_RELU);
         }
-        if (!run_gru256_stack(m, m->df_gru0, m->df_gru1, ga, gb, gc, state, S, L.df_dec_gru, B, Tc, which)) {
+        if (chained) {}
+        else if (!run_gru256_stack(m, m->df_gru0, m->df_gru1, ga, gb, gc, state, S, L.df_dec_gru, B, Tc, which)) {
             run_gru256(m, m->df_gru0, ga, gb, state, S, L.df_dec_gru, B, Tc, which);
             run_gru256(m, m->df_gru1, gb, gc, state, S, L.df_dec_gru + 256, B, Tc, which);
         }
@@ -1242,11 +1297,12 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         m->cur = st;
     }
     // ---- ERB decoder (dpdfnet.py:343-368; 48k hr.py:405-432) ----
-    {
+    if (!chained) {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->ed_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
     }
-    if (!run_gru256_stack(m, m->ed_gru0, m->ed_gru1, w.g256a.p, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru, B, Tc, 0)) {
+    if (chained) {}
+    else if (!run_gru256_stack(m, m->ed_gru0, m->ed_gru1, w.g256a.p, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru, B, Tc, 0)) {
         run_gru256(m, m->ed_gru0, w.g256a.p, w.g256b.p, state, S, L.erb_dec_gru, B, Tc);
         run_gru256(m, m->ed_gru1, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc);
     }
@@ -1287,11 +1343,11 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
 // chunk i+2, which waits for ev_s2 of chunk i; per-cell scratch is private to its stream; every cell has its own
 // granule buffer.  coefs / xm are single buffers: sG's write of chunk i+1 waits for the end of chunk i on sF.
 // For <= 64 streams (four GRU-256 tiles: 5 cells x 32 workgroups leave the chip to stage 1); bit 5 of `overlap`.
-// MEASURED AND LEFT OFF (tools/pipe_sweep.py, tools/trace_model.sh): 1 clip x 10 s 13.3 ms two-stage vs 16.4 / 20.3 / 32.2
-// ms here at 256- / 128- / 64-frame chunks.  The kernel trace shows why: with one clip a chunk is ~120 launches of
-// 5-60 us kernels, stage 1 alone leaves ~1.8 ms of gaps per chunk on its stream (the host enqueues the ERB branch's
-// ~55 launches before the DF branch's), and a deeper pipeline needs MORE, shorter chunks -- the call becomes bound by
-// the host's launch rate, not by the three-deep scan chain.  It would take the whole call as one hipGraph to cash in.
+// MEASURED AND LEFT OFF (tools/pipe_sweep.py): 1 clip x 10 s 10.3 ms two-stage vs 13.3 / 17.0 / 26.8 ms here at 256- /
+// 128- / 64-frame chunks.  Not the host (it enqueues a whole 10 s call, ~480 launches, in 1.2 ms: tools/enqueue_probe.py):
+// a chunk is ~120 launches of 5-60 us kernels that sit on dependency chains, each chunk costs ~0.4 ms of such latency on
+// the GPU whatever its length, and a deeper pipeline needs MORE, shorter chunks to fill.  The wavefront inside ONE launch
+// (gru_stack.h) is what this became.
 // ------------------------------------------------------------------------------------------------
 int ensure_pipe_ws(dpdf_model* m, int B, int Tc) {
     Workspace& w = m->ln->ws;
@@ -1660,6 +1716,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
         L.ws.release();
         for (int k = 0; k < 5; ++k) if (L.gru_xbuf[k]) (void)hipFree(L.gru_xbuf[k]);
         for (int k = 0; k < 2; ++k) if (L.gru_sbuf[k]) (void)hipFree(L.gru_sbuf[k]);
+        if (L.gru_cbuf) (void)hipFree(L.gru_cbuf);
     }
     DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state};
     for (DevBuf* b : bufs) b->release();
@@ -1749,6 +1806,8 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
+    else if (n == "gru256_chain") m->gru256_chain = value != 0;
+    else if (n == "gru256_chain_tiles") m->gru256_chain_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_c16_tiles") m->gru256_c16_tiles = value < 0 ? 0 : value;

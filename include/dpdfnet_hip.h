@@ -114,7 +114,7 @@ int dpdf_set_chunk_frames(dpdf_model* m, int frames);
 /* Execution-shape mask (default 27 = 1|2|8|16): bit 0 stage 2 of chunk i (GRU-256 scans, decoders) on its own HIP stream
  * underneath stage 1 of chunk i+1; bit 1 the ERB encoder branch on its own stream; bit 2 split the batch over two lanes
  * (measured slower, off); bit 3 the DF decoder beside the ERB decoder inside stage 2; bit 4 eight (not four) workgroups per
- * tile in the GRU-256 cluster scans of small launches; bit 5 (off: measured slower, host-launch-bound) for <= 64
+ * tile in the GRU-256 cluster scans of small launches; bit 5 (off: measured slower -- every chunk is a chain of ~120 dependent small launches) for <= 64
  * streams stage 2 as a pipeline of sub-stages across chunks (the five GRU-256 cells on five streams).  0: everything
  * serial on one stream (A/B timing). */
 int dpdf_set_overlap(dpdf_model* m, int mask);
@@ -131,7 +131,8 @@ int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
  * GEMM hoisting), "gru256_cluster" (0: single-workgroup GRU-256 scan), "gru256_pair" (0 off (default) / 2 / 3 / 4 round-robin tiles per
  * GRU-256 cluster, gru256_ring_kernel, for launches of >= 8 tiles), "gru256_c8_tiles" / "gru256_c16_tiles" (launches of at most this many 16-row
  * tiles run the GRU-256 scans on 8 / 16 workgroups per tile; defaults 4 / 2), "gru256_stack" (1 (default): launches of at most
- * gru256_c16_tiles tiles run the two cells of each decoder stack as one wavefront launch, gru_stack.h), "pipe_chunk".  Unknown name -> DPDF_E_INVALID. */
+ * gru256_c16_tiles tiles run the two cells of each decoder stack as one wavefront launch, gru_stack.h), "gru256_chain" /
+ * "gru256_chain_tiles" (opt-in, default 0 / 2: all five GRU-256 cells as one wavefront launch), "pipe_chunk".  Unknown name -> DPDF_E_INVALID. */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);
 
 /* Rational polyphase resampler on the device, for `ensure_sample_rate` when the caller's rate differs from the

@@ -389,8 +389,8 @@ def test_optin_bf16x3_gru64_mode_keeps_fp32_parity(tag, mode, be):
 
 def test_every_gru256_scan_form_agrees(be):
     """The forms of the GRU-256 recurrence -- single-workgroup scan (`gru256_cluster` = 0), 4-workgroup cluster, 8- and
-    16-workgroup clusters for small launches, the two cells of a decoder stack as one wavefront launch (gru_stack.h) -- on
-    the same input: equal to rounding, state included."""
+    16-workgroup clusters for small launches, the two cells of a decoder stack / all five cells as one wavefront launch
+    (gru_stack.h) -- on the same input: equal to rounding, state included."""
     g, meta = load_golden("16k_nb1")
     blob = golden_blob(meta)
     m = be.HipModel(meta["sample_rate"], meta["nb"], blob, 0)
@@ -398,16 +398,18 @@ def test_every_gru256_scan_form_agrees(be):
     spec = np.stack([o.stft(synth_clip(3000, 16000, 900 + i)) for i in range(40)])      # 40 streams = 3 tiles
     st0 = np.tile(m.initial_state(), (40, 1))
     outs = {}
-    for tag, opts, ov in (("cluster", {"gru256_c16_tiles": 0, "gru256_cluster": 1, "gru256_stack": 0}, 27 & ~16),
+    for tag, opts, ov in (("cluster", {"gru256_c16_tiles": 0, "gru256_cluster": 1, "gru256_stack": 0, "gru256_chain": 0}, 27 & ~16),
                           ("cluster8", {"gru256_c16_tiles": 0}, 27), ("cluster16", {"gru256_c16_tiles": 4}, 27),
                           ("stack16", {"gru256_c16_tiles": 4, "gru256_stack": 1}, 27), ("stack16_serial", {}, 16),
+                          ("chain16", {"gru256_chain": 1, "gru256_chain_tiles": 4}, 27), ("chain16_serial", {}, 16),
                           ("single_wg", {"gru256_cluster": 0}, 27)):
         for k, v in opts.items():
             m.set_option(k, v)
         m.set_overlap(ov)
         outs[tag] = m.run_frames(spec, st0)
-    m.set_option("gru256_cluster", 1); m.set_option("gru256_c16_tiles", 2); m.set_overlap(27)
+    m.set_option("gru256_cluster", 1); m.set_option("gru256_c16_tiles", 2); m.set_option("gru256_chain_tiles", 2); m.set_option("gru256_chain", 0); m.set_overlap(27)
     assert not np.array_equal(outs["stack16"][0], outs["cluster16"][0])         # the stacked form really ran
+    assert not np.array_equal(outs["chain16"][0], outs["stack16"][0])           # ... and the five-cell chain
     ref, st_ref = outs["cluster"]
     scale = float(np.abs(ref).max())
     for tag, (out, st) in outs.items():
