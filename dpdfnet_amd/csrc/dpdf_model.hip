@@ -1479,7 +1479,7 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     int Bg[2] = {B, 0};
     if (two) { Bg[0] = ((B / 2 + 15) / 16) * 16; Bg[1] = B - Bg[0]; }
     m->two_lanes_active = two;
-    // chunk_frames: >0 explicit, <0 whole sequence, 0 auto: ~48k frame rows per chunk, but never more than 256 frames per
+    // chunk_frames: >0 explicit, <0 whole sequence, 0 auto (below); small batches: 256 frames per
     // chunk -- a small batch is latency-bound and wants several chunks so that stage 2 of one runs under stage 1 of the
     // next (tools/latency_bench.py --chunks: 1 clip x 10 s 22.0 -> 18.2 ms, 32 clips 39.3 -> 29.7 ms)
     // <= 64 streams: stage 2 as a pipeline of sub-stages across chunks (run_stage2_pipe); its fill and drain are two
@@ -1487,10 +1487,16 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     const bool pipe2 = (m->overlap & 32) && (m->overlap & 1) && !two && B <= 64 && m->use_gru256_cluster;
     int chunk = T;
     if (m->chunk_frames > 0) chunk = std::min(m->chunk_frames, T);
-    // The intra-band launches have streams x frames / 16 workgroups, and the GRU-64 kernels are resident three (scan, <1>)
-    // or two (<2>) to a CU: 49152 frame rows per chunk = 3072 workgroups = 4 x 768 = 6 x 512 fills whole rounds of both
-    // (256 clips: 192 frames, 107.8 ms/step; 128 frames = 2.67 rounds, 108.7; 168 = 3.5 rounds, 109.6).
-    else if (m->chunk_frames == 0) chunk = std::min(T, std::min(pipe2 ? m->pipe_chunk : 256, std::max(64, (49152 + Bg[0] - 1) / Bg[0])));
+    // Throughput regime (>= 96 streams): 192 frames.  The intra-band launches have streams x frames / 16 workgroups and the
+    // GRU-64 kernels are resident three (scan, <1>) or two (<2>) to a CU: at 256 clips 192 frames = 3072 workgroups =
+    // 4 x 768 = 6 x 512 fills whole rounds of both (107.8 ms/step; 128 frames = 2.67 rounds, 108.7; 168 = 3.5 rounds, 109.6);
+    // 128 clips 58.9 ms at 192 vs 60.1 at 256, 512 clips 207.3 vs 211.3 at 96 -- as long as a chunk stays below 128k frame
+    // rows (~33 GB of workspace).  Fewer streams: 256 frames (latency regime, above).
+    else if (m->chunk_frames == 0) {
+        if (pipe2) chunk = std::min(T, m->pipe_chunk);
+        else if (Bg[0] < 96) chunk = std::min(T, 256);
+        else chunk = std::min(T, std::min(192, std::max(64, 131072 / Bg[0])));
+    }
     int rc;
     for (int g = 0; g < G; ++g) {
         m->ln = &m->lanes[g];
