@@ -311,6 +311,7 @@ struct dpdf_model {
     // as one wavefront launch (gru_stack.h: gru256_chain16_kernel)
     int gru256_chain = 0, gru256_chain_tiles = 2;
     int gru256_stack = 1;              // one or two tiles: the two cells of each decoder stack as one wavefront launch (gru_stack.h)
+    int tail_frames = 32;              // throughput regime: frames of the short chunk split off a long last chunk (pipeline drain; 0 = off)
     int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
     int gru256_c16_tiles = 2;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
@@ -1511,6 +1512,15 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     // (Measured and dropped: ending on a quarter-size chunk to shorten the pipeline drain -- 115.0 vs 114.6 ms/step.)
     std::vector<int> sizes;
     for (int rem = T; rem > 0; rem -= std::min(chunk, rem)) sizes.push_back(std::min(chunk, rem));
+    // Pipeline drain: stage 2 of the LAST chunk has no stage 1 to run under -- its latency-bound GRU-256 scans (three deep,
+    // 64 CUs) cost ~15 us per frame of that chunk with the rest of the chip idle, while an extra chunk costs ~0.6 ms.  So
+    // in the throughput regime a last chunk of 96 frames or more gives up a short tail chunk (1003 frames = 5 x 192 + 43
+    // stays as it is; 703 = 3 x 192 + 127 becomes ... + 95 + 32).
+    if (m->tail_frames > 0 && m->chunk_frames == 0 && B >= 96 && sizes.size() > 1 && sizes.back() >= 96) {
+        const int last = sizes.back();
+        sizes.back() = last - m->tail_frames;
+        sizes.push_back(m->tail_frames);
+    }
     int i = 0, t0 = 0;
     for (size_t ci = 0; ci < sizes.size(); t0 += sizes[ci], ++ci, ++i) {
         int b0 = 0;
@@ -1818,6 +1828,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "gru256_chain") m->gru256_chain = value != 0;
     else if (n == "gru256_chain_tiles") m->gru256_chain_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
+    else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_c16_tiles") m->gru256_c16_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_pair") m->gru256_pair = (value >= 2 && value <= 4) ? value : 0;

@@ -132,7 +132,8 @@ int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
  * GRU-256 cluster, gru256_ring_kernel, for launches of >= 8 tiles), "gru256_c8_tiles" / "gru256_c16_tiles" (launches of at most this many 16-row
  * tiles run the GRU-256 scans on 8 / 16 workgroups per tile; defaults 4 / 2), "gru256_stack" (1 (default): launches of at most
  * gru256_c16_tiles tiles run the two cells of each decoder stack as one wavefront launch, gru_stack.h), "gru256_chain" /
- * "gru256_chain_tiles" (opt-in, default 0 / 2: all five GRU-256 cells as one wavefront launch), "pipe_chunk".  Unknown name -> DPDF_E_INVALID. */
+ * "gru256_chain_tiles" (opt-in, default 0 / 2: all five GRU-256 cells as one wavefront launch), "tail_frames" (default 32:
+ * >= 96 streams, automatic chunking: a last chunk of >= 96 frames gives up a tail chunk of this many frames; 0 off), "pipe_chunk".  Unknown name -> DPDF_E_INVALID. */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);
 
 /* Rational polyphase resampler on the device, for `ensure_sample_rate` when the caller's rate differs from the

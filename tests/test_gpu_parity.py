@@ -318,6 +318,33 @@ def test_models_in_concurrent_host_threads(be):
         np.testing.assert_array_equal(got_shared[i], want[i])
 
 
+def test_throughput_regime_chunk_schedule_matches_whole_sequence_and_oracle(be):
+    """>= 96 streams: 192-frame chunks, and a last chunk of >= 96 frames gives up a 32-frame tail chunk (pipeline drain).
+    300 frames = 192 + 76 + 32 here; the result must equal the whole sequence run as one chunk, and the oracle."""
+    g, meta = load_golden("16k_nb1")
+    blob = golden_blob(meta)
+    m = be.HipModel(meta["sample_rate"], meta["nb"], blob, 0)
+    o = make_oracle(meta, blob)
+    B, T = 96, 300
+    spec = np.stack([o.stft(synth_clip(T * 160, 16000, 4000 + (i % 7)))[:T] * (0.5 + (i % 3) / 2.0) for i in range(B)]).astype(np.float32)
+    st0 = np.tile(m.initial_state(), (B, 1))
+    out, st = m.run_frames(spec, st0)                    # automatic schedule
+    m.set_option("tail_frames", 0)
+    out_nt, st_nt = m.run_frames(spec, st0)              # 192 + 108
+    m.set_option("tail_frames", 32)
+    m.set_chunk_frames(-1)
+    ref, st_ref = m.run_frames(spec, st0)                # one chunk
+    m.set_chunk_frames(0)
+    scale = float(np.abs(ref).max())
+    for a, sa in ((out, st), (out_nt, st_nt)):
+        assert np.abs(a - ref).max() < 2e-5 * scale
+        np.testing.assert_allclose(sa, st_ref, rtol=5e-6, atol=2e-5)
+    np.testing.assert_array_equal(out[0], out[21])       # identical clips (seed i % 7, scale i % 3) in different slots and tiles
+    r0, s0 = o.run_frames(spec[5])
+    assert np.abs(out[5] - r0).max() < STAGE_REL_TOL * scale and np.abs(st[5] - s0).max() < 2e-4
+    m.close()
+
+
 @pytest.mark.parametrize("sr,nb", [(16000, 2), (48000, 1)])
 def test_big_batch_kernel_forms_match_small_batch_forms_and_oracle(be, sr, nb):
     """Launch shapes that only big batches select -- the time-walking DF pass over c0 (df_ring_kernel: df_conv1 + pathway
