@@ -32,6 +32,7 @@
 #include "dec_last.h"
 #include "gru_bf16x3.h"
 #include "gru_stack.h"
+#include "fcln_gi.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -312,6 +313,8 @@ struct dpdf_model {
     int gru256_chain = 0, gru256_chain_tiles = 2;
     int gru256_stack = 1;              // one or two tiles: the two cells of each decoder stack as one wavefront launch (gru_stack.h)
     int tail_frames = 32;              // throughput regime: frames of the short chunk split off a long last chunk (pipeline drain; 0 = off)
+    int hop_glue = 1;                  // single-hop streaming: one glue launch per DPRNN block between the intra-band scans (fcln_gi.h)
+    int fcln_gi = 1;                   // small batches: fc + LayerNorm GEMMs of the DPRNN also produce the next recurrence's input projection (fcln_gi.h)
     int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
     int gru256_c16_tiles = 2;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
     int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
@@ -929,8 +932,14 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
     const bool gi_intra = !bf3 && !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
     const bool gi_inter = !bf3 && !fuse_inter && m->hoist_gi && Tc >= 4 && (size_t)M * 192 <= gibuf.n;
     const bool df = Fp >= 48;
+    // small batches: each fc + LayerNorm GEMM also computes the input projection of the recurrence that follows it
+    // (fcln_gi.h) -- two dependent launches per block fewer
+    const bool chain_gi = m->fcln_gi != 0;
+    const bool hop_glue = m->hop_glue && Tc == 1 && gi_intra;      // one frame per stream: everything between two intra scans in one launch
+    bool intra_gi_ready = false;
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         const DprnnW& w = blocks[bi];
+        bool inter_gi_ready = false;
         Gru64Args ai{};     // intra-band bi-GRU over frequency, h0 = 0: rows = frames, steps = band positions
         ai.x = x; ai.wfrag = m->C(w.intra.wfrag); ai.bias = m->C(w.intra.bias); ai.hstate = nullptr;
         ai.nrows = B * Tc; ai.nsteps = Fp; ai.rdiv = 1;
@@ -962,9 +971,11 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
             ai.o_hi = (long)Fp * 128; ai.o_lo = 0; ai.o_step = 128; ai.o_dir_off = 64;
             if (gi_intra) {     // W_ih x for every (frame, band) in one GEMM, then the h-only scan
                 ProfScope ps(m, df ? "gru64_scan_gi_kernel/intra_df" : "gru64_scan_gi_kernel/intra_erb");
-                PlainA<64> ap{x, 64, 0, 64};
-                BiasActStore<4> ep{gibuf.p, 384, 64, m->C(w.intra.ih_bias), 64, 64, ACT_NONE};
-                launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.intra.ih_frag), ep, M, 64, 6);
+                if (!intra_gi_ready) {
+                    PlainA<64> ap{x, 64, 0, 64};
+                    BiasActStore<4> ep{gibuf.p, 384, 64, m->C(w.intra.ih_bias), 64, 64, ACT_NONE};
+                    launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.intra.ih_frag), ep, M, 64, 6);
+                }
                 hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const float*)gibuf.p, 384);
             } else if (bf3) {
                 ProfScope ps(m, df ? "gru64_scan_bf16x3_kernel/intra_df" : "gru64_scan_bf16x3_kernel/intra_erb");
@@ -973,13 +984,37 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                 ProfScope ps(m, df ? "gru64_scan_kernel/intra_df" : "gru64_scan_kernel/intra_erb");
                 hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai);
             }
-            {   // fc_intra + ln_intra + residual
+            if (hop_glue) {
+                // single-hop streaming: fc_intra + LN, the inter-band GRUCell step, fc_inter + LN and the next block's
+                // intra input projection as ONE launch (fcln_gi.h); the block output goes to y, x0 becomes the free buffer
+                ProfScope ps(m, "dprnn_hop_glue");
+                const bool next = bi + 1 < blocks.size();
+                HopGlueArgs ha{hcat, x, y, m->C(w.fci_frag), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b),
+                               m->C(w.inter.wfrag), m->C(w.inter.bias), state + soff + (long)bi * Fp * 64, S, 64, Fp,
+                               m->C(w.fce_frag), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b),
+                               gibuf.p, next ? m->C(blocks[bi + 1].intra.ih_frag) : nullptr, next ? m->C(blocks[bi + 1].intra.ih_bias) : nullptr, M};
+                if (next) hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue_kernel<true>), dim3((M + 15) / 16), dim3(256), 0, m->cur, ha);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue_kernel<false>), dim3((M + 15) / 16), dim3(256), 0, m->cur, ha);
+                intra_gi_ready = next;
+                float* freed = x == xin ? xb : x;
+                x = y; y = freed;
+                continue;
+            }
+            {   // fc_intra + ln_intra + residual (+ the inter-band cell's input projection)
                 ProfScope ps(m, "dprnn_fc_ln");
-                PlainA<128> ap{hcat, 128, 0, 128};
-                LnResStore ep{y, x, m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b)};
-                launch_gemm_rows<4, 128, true>(m->cur, ap, m->C(w.fci_frag), ep, M, 128, 1);
+                if (chain_gi && gi_inter) {
+                    FclnGiArgs fa{hcat, 128, x, y, m->C(w.fci_frag), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b), gibuf.p, 192,
+                                  m->C(w.inter.ih_frag), m->C(w.inter.ih_bias), M};
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(fcln_gi_kernel<128, 3>), dim3((M + 15) / 16), dim3(256), 0, m->cur, fa);
+                    inter_gi_ready = true;
+                } else {
+                    PlainA<128> ap{hcat, 128, 0, 128};
+                    LnResStore ep{y, x, m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b)};
+                    launch_gemm_rows<4, 128, true>(m->cur, ap, m->C(w.fci_frag), ep, M, 128, 1);
+                }
             }
         }
+        intra_gi_ready = false;
         std::swap(x, y);
         if (y == xin) y = xb;
         Gru64Args ae{};     // inter-band GRUCell over time, one hidden state per band position
@@ -1003,9 +1038,11 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
             ae.out = hin;
             if (gi_inter) {
                 ProfScope ps(m, df ? "gru64_scan_gi_kernel/inter_df" : "gru64_scan_gi_kernel/inter_erb");
-                PlainA<64> ap{x, 64, 0, 64};
-                BiasActStore<4> ep{gibuf.p, 192, 64, m->C(w.inter.ih_bias), 64, 64, ACT_NONE};
-                launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.inter.ih_frag), ep, M, 64, 3);
+                if (!inter_gi_ready) {
+                    PlainA<64> ap{x, 64, 0, 64};
+                    BiasActStore<4> ep{gibuf.p, 192, 64, m->C(w.inter.ih_bias), 64, 64, ACT_NONE};
+                    launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.inter.ih_frag), ep, M, 64, 3);
+                }
                 hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const float*)gibuf.p, 192);
             } else if (bf3) {
                 ProfScope ps(m, df ? "gru64_scan_bf16x3_kernel/inter_df" : "gru64_scan_bf16x3_kernel/inter_erb");
@@ -1014,11 +1051,19 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                 ProfScope ps(m, df ? "gru64_scan_kernel/inter_df" : "gru64_scan_kernel/inter_erb");
                 hipLaunchKernelGGL(gru64_scan_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae);
             }
-            {
+            {   // fc_inter + ln_inter + residual (+ the next block's intra-band input projection)
                 ProfScope ps(m, "dprnn_fc_ln");
-                PlainA<64> ap{hin, 64, 0, 64};
-                LnResStore ep{y, x, m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b)};
-                launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.fce_frag), ep, M, 64, 1);
+                if (chain_gi && gi_intra && bi + 1 < blocks.size()) {
+                    const DprnnW& wn = blocks[bi + 1];
+                    FclnGiArgs fa{hin, 64, x, y, m->C(w.fce_frag), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), gibuf.p, 384,
+                                  m->C(wn.intra.ih_frag), m->C(wn.intra.ih_bias), M};
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(fcln_gi_kernel<64, 6>), dim3((M + 15) / 16), dim3(256), 0, m->cur, fa);
+                    intra_gi_ready = true;
+                } else {
+                    PlainA<64> ap{hin, 64, 0, 64};
+                    LnResStore ep{y, x, m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b)};
+                    launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.fce_frag), ep, M, 64, 1);
+                }
             }
         }
         std::swap(x, y);
@@ -1829,6 +1874,8 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "gru256_chain_tiles") m->gru256_chain_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
+    else if (n == "hop_glue") m->hop_glue = value != 0;
+    else if (n == "fcln_gi") m->fcln_gi = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_c16_tiles") m->gru256_c16_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_pair") m->gru256_pair = (value >= 2 && value <= 4) ? value : 0;
