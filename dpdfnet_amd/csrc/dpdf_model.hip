@@ -347,7 +347,8 @@ struct dpdf_model {
     size_t convp_frag, convp_bias;
     size_t window, stft_frag_s, istft_frag;
     int stft_groups_s, istft_groups, istft_K;
-    DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state;
+    DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state, stft_part;
+    int stft_ksplit = 1;               // few-frame STFT split five ways over K (stft_small)
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;
@@ -1782,7 +1783,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
         for (int k = 0; k < 2; ++k) if (L.gru_sbuf[k]) (void)hipFree(L.gru_sbuf[k]);
         if (L.gru_cbuf) (void)hipFree(L.gru_cbuf);
     }
-    DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state};
+    DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state, &m->stft_part};
     for (DevBuf* b : bufs) b->release();
     if (m->consts) (void)hipFree(m->consts);
     if (m->iconsts) (void)hipFree(m->iconsts);
@@ -1874,6 +1875,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "gru256_chain_tiles") m->gru256_chain_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
+    else if (n == "stft_ksplit") m->stft_ksplit = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
@@ -1925,6 +1927,27 @@ extern "C" size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap) {
     }
     if (buf && cap) { size_t n = std::min(cap - 1, s.size()); memcpy(buf, s.data(), n); buf[n] = 0; }
     return s.size();
+}
+
+// Analysis STFT of a FEW frames (streaming hops, tiny clips): one 64-row tile per column group, so the K loop -- win / 64
+// panels, each a round of B-fragment and PCM loads -- is a chain of latencies (one hop of 64 x 48 kHz streams: 118 us of a
+// 1.2 ms hop).  Split five ways over K: the partial sums of every split land side by side and are added in a fixed order.
+static int stft_small(dpdf_model* m, const StftA<64>& ap, float* spec, int M) {
+    const dpdf_dims& d = m->d;
+    // (16 kHz: 5 panels -- the extra summing launch costs what the split saves; 48 kHz: 15 panels, 1222 -> 1175 us per hop)
+    const int npan = d.win / 64, ks = (m->stft_ksplit && npan >= 10 && npan % 5 == 0) ? 5 : 1, W = m->stft_groups_s * 32;
+    if (ks == 1) {
+        BiasActStore<2> ep{spec, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
+        ep.ncol_total = 2 * d.F;
+        launch_gemm_rows<2, 64, false>(m->stream, ap, m->C(m->stft_frag_s), ep, M, d.win, m->stft_groups_s);
+        return DPDF_OK;
+    }
+    int rc = m->stft_part.ensure((size_t)M * ks * W); if (rc) return rc;
+    BiasActStore<2> ep{m->stft_part.p, (size_t)ks * W, 32, nullptr, 0, 32, ACT_NONE};
+    launch_gemm_rows<2, 64, false>(m->stream, ap, m->C(m->stft_frag_s), ep, M, d.win, m->stft_groups_s, 2048, ks);
+    const size_t n = (size_t)M * 2 * d.F;
+    hipLaunchKernelGGL(ksplit_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, (const float*)m->stft_part.p, spec, M, ks, W, 2 * d.F, (const float*)nullptr);
+    return DPDF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2003,9 +2026,7 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         ProfScope ps(m, "stft");
         StftA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window), 0, d_lens};
         if (B * T <= SMALL_M_ROWS) {
-            BiasActStore<2> ep{m->raw_spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
-            ep.ncol_total = 2 * d.F;
-            launch_gemm_rows<2, 64, false>(m->stream, ap, m->C(m->stft_frag_s), ep, B * T, d.win, m->stft_groups_s);
+            if ((rc = stft_small(m, ap, m->raw_spec.p, B * T))) return rc;
         } else {
             BiasActStore<2> ep{m->raw_spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
             ep.ncol_total = 2 * d.F;
@@ -2135,9 +2156,7 @@ extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_
     {   // causal analysis (stream.py:119-126): frame j = xbuf[j*hop : j*hop+win] * window -> rfft.
                 StftA<64> ap{xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
         if (S * T <= SMALL_M_ROWS) {
-            BiasActStore<2> ep{s->spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
-            ep.ncol_total = 2 * d.F;
-            launch_gemm_rows<2, 64, false>(m->stream, ap, m->C(m->stft_frag_s), ep, S * T, d.win, m->stft_groups_s);
+            if ((rc = stft_small(m, ap, s->spec.p, S * T))) return rc;
         } else {
             BiasActStore<2> ep{s->spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
             ep.ncol_total = 2 * d.F;

@@ -550,12 +550,17 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(AProd ap, const float* _
     // b % 8), each with a private L2.  Row tiles that are neighbours in (clip, frame, band) order share input rows
     // through the time/frequency halos of the conv producers (up to 5x for the DF pathway conv), so each sweep of
     // gridDim.x tiles is cut into 8 contiguous slabs, one per XCD, instead of being interleaved across all of them.
-    int tile = blockIdx.x, panel = 0, cur = 0;
+    // K split (gridDim.z > 1: few-row launches whose K loop is a chain of load latencies, e.g. the STFT of one streaming hop):
+    // block z accumulates panels [z, z + 1) * npanels / gridDim.z and hands its partial sums to the epilogue under the virtual
+    // group index grp + z * gridDim.y; a follow-up kernel adds the partials in a fixed order (ksplit_sum_kernel).
+    const int pper = npanels / (int)gridDim.z, p0 = (int)blockIdx.z * pper, p1 = p0 + pper;
+    const int vgrp = grp + (int)blockIdx.z * (int)gridDim.y;
+    int tile = blockIdx.x, panel = p0, cur = 0;
     if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (tile >= ntiles) return;
     typename AProd::Regs R;
-    ap.load(R, tile * GEMM_BM, 0, grp, M);
-    ap.store(As[0], R, tile * GEMM_BM, 0, grp, M);
+    ap.load(R, tile * GEMM_BM, p0 * KP, grp, M);
+    ap.store(As[0], R, tile * GEMM_BM, p0 * KP, grp, M);
     __syncthreads();
     f32x4 acc[NT];
 #pragma unroll
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(AProd ap, const float* _
     while (true) {
         // next (tile, panel) in the flattened sequence
         int ntile = tile, npanel = panel + 1;
-        if (npanel == npanels) { npanel = 0; ntile = tile + gridDim.x; }
+        if (npanel == p1) { npanel = p0; ntile = tile + gridDim.x; }
         const bool has_next = ntile < ntiles;
         if (!PERSIST_B) {
             // this panel's B fragments first: vmcnt retires in order, so the A prefetch issued after
@@ -574,8 +579,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(AProd ap, const float* _
         }
         if (has_next) ap.load(R, ntile * GEMM_BM, npanel * KP, grp, M);
         typename Epi::Pref P;
-        const bool last_panel = panel == npanels - 1;
-        if (last_panel) ep.prefetch(P, tile * GEMM_BM + wave * 16, lane, grp, M);
+        const bool last_panel = panel == p1 - 1;
+        if (last_panel) ep.prefetch(P, tile * GEMM_BM + wave * 16, lane, vgrp, M);
         const float* arow = &As[cur][wave * 16 + (lane & 15)][(lane >> 4) * 4];
 #pragma unroll
         for (int c = 0; c < KP / 16; ++c) {
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(AProd ap, const float* _
             }
         }
         if (last_panel) {
-            ep.call(acc, P, tile * GEMM_BM + wave * 16, lane, grp, M);
+            ep.call(acc, P, tile * GEMM_BM + wave * 16, lane, vgrp, M);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -685,10 +690,22 @@ static inline void launch_gemm_rows_wn(hipStream_t st, const AProd& ap, const fl
 
 template <int NT, int KP, bool PERSIST_B, class AProd, class Epi>
 static inline void launch_gemm_rows(hipStream_t st, const AProd& ap, const float* wfrag, const Epi& ep,
-                                    int M, int K, int groups, int max_blocks_x = 2048) {
+                                    int M, int K, int groups, int max_blocks_x = 2048, int ksplit = 1) {
     int ntiles = (M + GEMM_BM - 1) / GEMM_BM;
     if (ntiles <= 0) return;
     int gx = ntiles < max_blocks_x ? ntiles : max_blocks_x;
-    dim3 grid(gx, groups, 1);
+    dim3 grid(gx, groups, ksplit);      // ksplit must divide K / KP
     hipLaunchKernelGGL((gemm_rows_kernel<NT, KP, PERSIST_B, AProd, Epi>), grid, dim3(256), 0, st, ap, wfrag, ep, M, K);
+}
+
+// out[r][c] = (sum over z (in order) of part[r][z][c]) [* colscale[c]], c < ncol: the second half of a K-split launch
+__global__ __launch_bounds__(256) void ksplit_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int M, int ks, int W, int ncol,
+                                                         const float* __restrict__ colscale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * ncol) return;
+    const int r = (int)(i / ncol), c = (int)(i % ncol);
+    const float* p = part + (size_t)r * ks * W + c;
+    float s = p[0];
+    for (int z = 1; z < ks; ++z) s += p[(size_t)z * W];
+    out[i] = colscale ? s * colscale[c] : s;
 }
