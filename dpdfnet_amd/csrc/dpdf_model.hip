@@ -289,6 +289,7 @@ struct Lane {
     // stacked decoder pairs (gru256_stack16_kernel): per pair [tiles][Tcap + 2][16][256] granules = cell A's per-frame ring + cell B's two slots
     // all five cells as one launch (gru256_chain16_kernel): 7 per-frame rings [tiles][Tcap][16][256]
     unsigned long long* gru_cbuf = nullptr; int gru_cbuf_tiles = 0, gru_cbuf_T = 0; unsigned gru_cepoch = 0;
+    unsigned* arrive[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int arrive_tiles[5] = {0, 0, 0, 0, 0}; unsigned arrive_count[5] = {0, 0, 0, 0, 0};   // gru256_step_kernel
     unsigned long long* gru_sbuf[2] = {nullptr, nullptr}; int gru_sbuf_tiles[2] = {0, 0}, gru_sbuf_T[2] = {0, 0}; unsigned gru_sepoch[2] = {0, 0};
     const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; const float* dbg_emb = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
 };
@@ -313,6 +314,7 @@ struct dpdf_model {
     int gru256_chain = 0, gru256_chain_tiles = 2;
     int gru256_stack = 1;              // one or two tiles: the two cells of each decoder stack as one wavefront launch (gru_stack.h)
     int tail_frames = 32;              // throughput regime: frames of the short chunk split off a long last chunk (pipeline drain; 0 = off)
+    int gru256_step = 1;               // single-hop streaming: input projection + GRUCell(256) step as one launch per cell
     int hop_glue = 1;                  // single-hop streaming: one glue launch per DPRNN block between the intra-band scans (fcln_gi.h)
     int fcln_gi = 1;                   // small batches: fc + LayerNorm GEMMs of the DPRNN also produce the next recurrence's input projection (fcln_gi.h)
     int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
@@ -792,6 +794,7 @@ void run_gru256_proj(dpdf_model* m, const Gru256W& g, const float* x, float* gi,
 bool run_gru256_stack(dpdf_model* m, const Gru256W& g0, const Gru256W& g1, const float* x, float* out0, float* out1, float* state, long S,
                       int hoff, int B, int Tc, int which) {
     const int ntiles = (B + 15) / 16;
+    if (Tc == 1 && m->gru256_step) return false;       // one frame: a step kernel per cell (run_gru256)
     if (!m->gru256_stack || !(m->overlap & 16) || !m->use_gru256_cluster || ntiles > m->gru256_c16_tiles || which < 0 || which > 1) return false;
     Lane& L = *m->ln;
     if (ntiles > L.gru_sbuf_tiles[which] || Tc > L.gru_sbuf_T[which] || !L.gru_sbuf[which] || !m->d_err) {
@@ -827,6 +830,7 @@ bool run_gru256_stack(dpdf_model* m, const Gru256W& g0, const Gru256W& g1, const
 // and of the second cell of each decoder.  false = not eligible.
 bool run_gru256_chain(dpdf_model* m, const float* x, float* out_e, float* out_erb, float* out_df, float* state, long S, int B, int Tc) {
     const int ntiles = (B + 15) / 16;
+    if (Tc == 1 && m->gru256_step) return false;
     if (!m->gru256_chain || !(m->overlap & 16) || !m->use_gru256_cluster || ntiles > m->gru256_chain_tiles) return false;
     const dpdf_state_layout& SL = m->L;
     Lane& L = *m->ln;
@@ -868,8 +872,36 @@ bool run_gru256_chain(dpdf_model* m, const float* x, float* out_e, float* out_er
     return true;
 }
 
+// One frame per stream: input projection + cell step as ONE launch (gru_stack.h: gru256_step_kernel)
+bool run_gru256_step(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int which) {
+    if (!m->gru256_step || !m->use_gru256_cluster || which < 0 || which > 4) return false;
+    Lane& L = *m->ln;
+    const int ntiles = (B + 15) / 16;
+    if (ntiles > L.arrive_tiles[which] || !L.arrive[which] || !m->d_err) {
+        if (L.arrive[which]) { L.sync_all(); (void)hipFree(L.arrive[which]); L.arrive[which] = nullptr; }
+        if (hipMalloc((void**)&L.arrive[which], (size_t)ntiles * sizeof(unsigned)) != hipSuccess) { L.arrive_tiles[which] = 0; return false; }
+        (void)hipMemsetAsync(L.arrive[which], 0, (size_t)ntiles * sizeof(unsigned), m->cur);
+        L.arrive_tiles[which] = ntiles; L.arrive_count[which] = 0;
+        if (!m->d_err) {
+            if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return false;
+            (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->cur);
+        }
+    }
+    if (L.arrive_count[which] > 0xF0000000u) {
+        (void)hipMemsetAsync(L.arrive[which], 0, (size_t)L.arrive_tiles[which] * sizeof(unsigned), m->cur);
+        L.arrive_count[which] = 0;
+    }
+    L.arrive_count[which] += 16;
+    ProfScope ps(m, "gru256_scan");
+    Gru256StepArgs a{x, out, m->C(g.ih_as_hh), m->C(g.hh_frag), m->C(g.ih_bias), m->C(g.b_hn), state + hoff, S, B,
+                     L.arrive[which], L.arrive_count[which], m->d_err};
+    hipLaunchKernelGGL(gru256_step_kernel, dim3(ntiles * 16), dim3(256), 0, m->cur, a);
+    return true;
+}
+
 void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int Tc, int which = 0,
                 float* gi_buf = nullptr) {
+    if (Tc == 1 && !gi_buf && run_gru256_step(m, g, x, out, state, S, hoff, B, which)) return;
     const int M = B * Tc;
     float* gi = gi_buf ? gi_buf : (which ? m->ln->ws.gi2.p : m->ln->ws.gi.p);
     run_gru256_proj(m, g, x, gi, M);
@@ -1782,6 +1814,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
         for (int k = 0; k < 5; ++k) if (L.gru_xbuf[k]) (void)hipFree(L.gru_xbuf[k]);
         for (int k = 0; k < 2; ++k) if (L.gru_sbuf[k]) (void)hipFree(L.gru_sbuf[k]);
         if (L.gru_cbuf) (void)hipFree(L.gru_cbuf);
+        for (int k = 0; k < 5; ++k) if (L.arrive[k]) (void)hipFree(L.arrive[k]);
     }
     DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state, &m->stft_part};
     for (DevBuf* b : bufs) b->release();
@@ -1876,6 +1909,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
     else if (n == "stft_ksplit") m->stft_ksplit = value != 0;
+    else if (n == "gru256_step") m->gru256_step = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;

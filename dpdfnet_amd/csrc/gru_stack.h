@@ -487,3 +487,98 @@ __global__ __launch_bounds__(256, 1) void gru256_chain16_kernel(Gru256ChainArgs 
     }
     if (ok) C.hstate[(long)rc * a.h_stride + u0 + cl] = h_own;
 }
+
+// ---------------------------------------------------------------------------------------------
+// gru256_step_kernel: ONE GRUCell(256) step for B rows -- single-hop streaming, where a "scan" is one step and the
+// hoisted input projection plus the cluster scan would be two dependent launches (~10 us each) for 0.4 MFLOP per row.
+// 16 workgroups per 16-row tile as in gru256_cluster16_kernel (16 hidden units each, K split over the four waves), but
+// with BOTH operands' quarters in registers (W_ih, W_hh: 96 VGPRs) and no exchange: every workgroup reads the full x and
+// h rows of its tile itself.  The carried state is updated in place, so a workgroup may store its slice of h' only after
+// all sixteen of the tile have read h: an arrival counter per tile (one relaxed agent-scope atomic add after the loads,
+// one poll before the stores -- by then the peers have long arrived; epochs grow monotonically, the buffer is never reset).
+struct Gru256StepArgs {
+    const float* x;             // [B][256]
+    float* out;                 // [B][256]
+    const float* wih; const float* whh;      // packed like hh_frag ([j 16][gate 3][k-chunk 64][lane 64])
+    const float* bias;          // [768]: b_ih + b_hh (r, z) | b_in (n)
+    const float* bhn;           // [256]
+    float* hstate; long h_stride;
+    int B;
+    unsigned* arrive;           // [tiles]
+    unsigned target;            // arrivals of this tile's 16 workgroups are complete at this count
+    int* err;
+};
+
+__global__ __launch_bounds__(256, 1) void gru256_step_kernel(Gru256StepArgs a) {
+    __shared__ __attribute__((aligned(16))) float Xs[16][260];
+    __shared__ __attribute__((aligned(16))) float Hs[16][260];
+    __shared__ float Ps[4][4][4][64];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int cl = lane & 15, q = lane >> 4;
+    const int rt = blockIdx.x >> 4, j = blockIdx.x & 15;
+    const int row0 = rt * 16, u0 = 16 * j;
+    for (int idx = tid; idx < 16 * 64; idx += 256) {
+        const int r = idx >> 6, c4 = (idx & 63) * 4;
+        const int rr = row0 + r < a.B ? row0 + r : a.B - 1;
+        *(float4*)&Xs[r][c4] = *(const float4*)(a.x + (size_t)rr * 256 + c4);
+        *(float4*)&Hs[r][c4] = *(const float4*)(a.hstate + (long)rr * a.h_stride + c4);
+    }
+    float xr_[16], xz_[16], xn_[16], wr[16], wz[16], wn[16];
+    {
+        const size_t o = ((size_t)j * 3) * 64 * 64 + (size_t)(16 * w) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            xr_[k] = a.wih[o + (size_t)(0 * 64 + k) * 64]; xz_[k] = a.wih[o + (size_t)(1 * 64 + k) * 64]; xn_[k] = a.wih[o + (size_t)(2 * 64 + k) * 64];
+            wr[k] = a.whh[o + (size_t)(0 * 64 + k) * 64]; wz[k] = a.whh[o + (size_t)(1 * 64 + k) * 64]; wn[k] = a.whh[o + (size_t)(2 * 64 + k) * 64];
+        }
+    }
+    const float b_r = a.bias[u0 + cl], b_z = a.bias[256 + u0 + cl], b_n = a.bias[512 + u0 + cl], bhn = a.bhn[u0 + cl];
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.arrive + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // this workgroup has read h
+    f32x4 pr = {0.f, 0.f, 0.f, 0.f}, pz = pr, px = pr, pn = pr;
+    {
+        const float* xrow = &Xs[cl][64 * w + 4 * q];
+        const float* hrow = &Hs[cl][64 * w + 4 * q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 x4 = *(const float4*)(xrow + 16 * c), h4 = *(const float4*)(hrow + 16 * c);
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                pr = mfma16(xv[kb], xr_[c * 4 + kb], pr);
+                pz = mfma16(xv[kb], xz_[c * 4 + kb], pz);
+                px = mfma16(xv[kb], xn_[c * 4 + kb], px);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                pr = mfma16(hv[kb], wr[c * 4 + kb], pr);
+                pz = mfma16(hv[kb], wz[c * 4 + kb], pz);
+                pn = mfma16(hv[kb], wn[c * 4 + kb], pn);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { Ps[w][0][i][lane] = pr[i]; Ps[w][1][i][lane] = pz[i]; Ps[w][2][i][lane] = px[i]; Ps[w][3][i][lane] = pn[i]; }
+    __syncthreads();
+    // wave w finalises C-layout row i = w of the block: tile row q*4 + w; the four K quarters are added in one fixed order
+    const int r_own = row0 + q * 4 + w;
+    const bool ok = r_own < a.B;
+    float sr = Ps[0][0][w][lane], sz = Ps[0][1][w][lane], sx = Ps[0][2][w][lane], sn = Ps[0][3][w][lane];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { sr += Ps[k][0][w][lane]; sz += Ps[k][1][w][lane]; sx += Ps[k][2][w][lane]; sn += Ps[k][3][w][lane]; }
+    const float r = sigmoid_f(b_r + sr);
+    const float z = sigmoid_f(b_z + sz);
+    const float n = gru_candidate(r, bhn + sn, b_n + sx);
+    const float h_new = gru_blend(z, n, Hs[q * 4 + w][u0 + cl]);
+    if (ok) a.out[(size_t)r_own * 256 + u0 + cl] = h_new;
+    // in-place state: wait until all sixteen workgroups of the tile have read h
+    if (tid == 0) {
+        unsigned spins = 0; bool dead = false;
+        while ((int)(__hip_atomic_load(a.arrive + rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.target) < 0) {
+            if (cluster_spin_expired(spins, a.err, dead)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    if (ok) a.hstate[(long)r_own * a.h_stride + u0 + cl] = h_new;
+}
