@@ -881,20 +881,20 @@ bool run_gru256_step(dpdf_model* m, const Gru256W& g, const float* x, float* out
         if (L.arrive[which]) { L.sync_all(); (void)hipFree(L.arrive[which]); L.arrive[which] = nullptr; }
         if (hipMalloc((void**)&L.arrive[which], (size_t)ntiles * sizeof(unsigned)) != hipSuccess) { L.arrive_tiles[which] = 0; return false; }
         (void)hipMemsetAsync(L.arrive[which], 0, (size_t)ntiles * sizeof(unsigned), m->cur);
-        L.arrive_tiles[which] = ntiles; L.arrive_count[which] = 0;
+        L.arrive_tiles[which] = ntiles; L.arrive_count[which] = 0;      // (counter wrap: 2^32 / 16 launches -- decades of hops)
         if (!m->d_err) {
             if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return false;
             (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->cur);
         }
     }
-    if (L.arrive_count[which] > 0xF0000000u) {
+    if (L.arrive_count[which] > 0xF0000000u) {       // launches since the counters were zeroed: re-zero long before a 32-bit wrap
         (void)hipMemsetAsync(L.arrive[which], 0, (size_t)L.arrive_tiles[which] * sizeof(unsigned), m->cur);
         L.arrive_count[which] = 0;
     }
     L.arrive_count[which] += 16;
     ProfScope ps(m, "gru256_scan");
     Gru256StepArgs a{x, out, m->C(g.ih_as_hh), m->C(g.hh_frag), m->C(g.ih_bias), m->C(g.b_hn), state + hoff, S, B,
-                     L.arrive[which], L.arrive_count[which], m->d_err};
+                     L.arrive[which], m->d_err};
     hipLaunchKernelGGL(gru256_step_kernel, dim3(ntiles * 16), dim3(256), 0, m->cur, a);
     return true;
 }

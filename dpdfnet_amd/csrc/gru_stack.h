@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void gru256_chain16_kernel(Gru256ChainArgs 
 // with BOTH operands' quarters in registers (W_ih, W_hh: 96 VGPRs) and no exchange: every workgroup reads the full x and
 // h rows of its tile itself.  The carried state is updated in place, so a workgroup may store its slice of h' only after
 // all sixteen of the tile have read h: an arrival counter per tile (one relaxed agent-scope atomic add after the loads,
-// one poll before the stores -- by then the peers have long arrived; epochs grow monotonically, the buffer is never reset).
+// one poll before the stores -- by then the peers have long arrived).
 struct Gru256StepArgs {
     const float* x;             // [B][256]
     float* out;                 // [B][256]
@@ -504,8 +504,7 @@ struct Gru256StepArgs {
     const float* bhn;           // [256]
     float* hstate; long h_stride;
     int B;
-    unsigned* arrive;           // [tiles]
-    unsigned target;            // arrivals of this tile's 16 workgroups are complete at this count
+    unsigned* arrive;           // [tiles] arrival counters (zeroed once; every launch adds 16 to the counters of its tiles)
     int* err;
 };
 
@@ -534,7 +533,11 @@ __global__ __launch_bounds__(256, 1) void gru256_step_kernel(Gru256StepArgs a) {
     }
     const float b_r = a.bias[u0 + cl], b_z = a.bias[256 + u0 + cl], b_n = a.bias[512 + u0 + cl], bhn = a.bhn[u0 + cl];
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(a.arrive + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // this workgroup has read h
+    // this workgroup has read h.  The tile's round is complete at the next multiple of 16 above the value found (launches
+    // that use a counter are stream-ordered, so the sixteen arrivals of one launch see 16 k ... 16 k + 15): no host-side target,
+    // tiles that take part in different numbers of launches stay consistent
+    unsigned target = 0;
+    if (tid == 0) target = (__hip_atomic_fetch_add(a.arrive + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~15u) + 16u;
     f32x4 pr = {0.f, 0.f, 0.f, 0.f}, pz = pr, px = pr, pn = pr;
     {
         const float* xrow = &Xs[cl][64 * w + 4 * q];
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void gru256_step_kernel(Gru256StepArgs a) {
     // in-place state: wait until all sixteen workgroups of the tile have read h
     if (tid == 0) {
         unsigned spins = 0; bool dead = false;
-        while ((int)(__hip_atomic_load(a.arrive + rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.target) < 0) {
+        while ((int)(__hip_atomic_load(a.arrive + rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             if (cluster_spin_expired(spins, a.err, dead)) break;
             __builtin_amdgcn_s_sleep(1);
         }

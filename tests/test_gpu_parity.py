@@ -318,6 +318,27 @@ def test_models_in_concurrent_host_threads(be):
         np.testing.assert_array_equal(got_shared[i], want[i])
 
 
+def test_single_frame_calls_with_changing_stream_counts(be):
+    """Regression (gru256_step_kernel): the per-tile arrival counters that guard the in-place state update must stay
+    consistent when consecutive one-frame calls cover different numbers of 16-row tiles (64 -> 16 -> 64 streams used to
+    leave tiles 1-3 one round behind: spin timeout)."""
+    g, meta = load_golden("16k_nb1")
+    blob = golden_blob(meta)
+    m = be.HipModel(meta["sample_rate"], meta["nb"], blob, 0)
+    o = make_oracle(meta, blob)
+    frames = o.stft(synth_clip(3000, 16000, 77))[:3]
+    for B in (64, 16, 64, 5, 40, 64):
+        spec = np.repeat(frames[None, :1], B, axis=0) * (1.0 + 0.01 * np.arange(B, dtype=np.float32))[:, None, None, None]
+        st = np.tile(m.initial_state(), (B, 1))
+        out, st1 = m.run_frames(spec, st)
+        out2, st2 = m.run_frames(np.repeat(frames[None, 1:2], B, axis=0), st1)
+        ref, s_ref = o.run_frames(np.concatenate([spec[B - 1], frames[1:2]], axis=0))
+        scale = float(np.abs(ref).max()) + 1e-9
+        assert np.abs(np.concatenate([out[B - 1], out2[B - 1]], axis=0) - ref).max() < STAGE_REL_TOL * scale, B
+        assert np.abs(st2[B - 1] - s_ref).max() < 2e-4, B
+    m.close()
+
+
 def test_throughput_regime_chunk_schedule_matches_whole_sequence_and_oracle(be):
     """>= 96 streams: 192-frame chunks, and a last chunk of >= 96 frames gives up a 32-frame tail chunk (pipeline drain).
     300 frames = 192 + 76 + 32 here; the result must equal the whole sequence run as one chunk, and the oracle."""
