@@ -350,7 +350,7 @@ struct dpdf_model {
     size_t window, stft_frag_s, istft_frag;
     int stft_groups_s, istft_groups, istft_K;
     DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state, stft_part;
-    int stft_ksplit = 1;               // few-frame STFT split five ways over K (stft_small)
+    int stft_ksplit = 3;               // few frames: bit 0 STFT split five ways over K (stft_small), bit 1 streaming iSTFT split seven ways (summed by the overlap-add kernel)
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;
@@ -1908,7 +1908,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "gru256_chain_tiles") m->gru256_chain_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
-    else if (n == "stft_ksplit") m->stft_ksplit = value != 0;
+    else if (n == "stft_ksplit") m->stft_ksplit = value & 3;
     else if (n == "gru256_step") m->gru256_step = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
@@ -1969,7 +1969,7 @@ extern "C" size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap) {
 static int stft_small(dpdf_model* m, const StftA<64>& ap, float* spec, int M) {
     const dpdf_dims& d = m->d;
     // (16 kHz: 5 panels -- the extra summing launch costs what the split saves; 48 kHz: 15 panels, 1222 -> 1175 us per hop)
-    const int npan = d.win / 64, ks = (m->stft_ksplit && npan >= 10 && npan % 5 == 0) ? 5 : 1, W = m->stft_groups_s * 32;
+    const int npan = d.win / 64, ks = ((m->stft_ksplit & 1) && npan >= 10 && npan % 5 == 0) ? 5 : 1, W = m->stft_groups_s * 32;
     if (ks == 1) {
         BiasActStore<2> ep{spec, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
         ep.ncol_total = 2 * d.F;
@@ -2202,9 +2202,20 @@ extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_
     {
         PlainA<48> ap{s->spec_e.p, (size_t)2 * d.F, 0, 2 * d.F};
         WindowStore<5> ep{m->frames.p, d.win, m->C(m->window)};
-        if (S * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups / 4);
-        else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups);
-        hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, s->ola_tail.p, dst, S, T, d.hop);
+        // few frames: the K loop (istft_K / 48 panels on win / 80 workgroups) is a chain of load latencies -- split seven
+        // ways over K, the overlap-add kernel sums the partial frames and applies the window (no extra launch)
+        const int npan = m->istft_K / 48, ks = ((m->stft_ksplit & 2) && S * T <= SMALL_M_ROWS && npan % 7 == 0) ? 7 : 1;
+        if (ks > 1) {
+            const int W = m->istft_groups * 80;
+            if ((rc = m->stft_part.ensure((size_t)S * T * ks * W))) return rc;
+            BiasActStore<5> ep7{m->stft_part.p, (size_t)ks * W, 80, nullptr, 0, 80, ACT_NONE};
+            launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep7, S * T, m->istft_K, m->istft_groups, 2048, ks);
+            hipLaunchKernelGGL(stream_ola_ksplit_kernel, dim3(S), dim3(256), 0, m->stream, (const float*)m->stft_part.p, ks, W, m->C(m->window), s->ola_tail.p, dst, S, T, d.hop);
+        } else {
+            if (S * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups / 4);
+            else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups);
+            hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, s->ola_tail.p, dst, S, T, d.hop);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (host) {

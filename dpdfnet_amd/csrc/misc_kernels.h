@@ -426,6 +426,26 @@ __global__ void stream_stage_in_kernel(const float* pcm_in, float* in_tail, floa
     for (int i = threadIdx.x; i < hop; i += blockDim.x) in_tail[(size_t)s * hop + i] = xb[n + i];
 }
 //   out hop j = (j ? frames[j-1][hop:] : ola_tail) + frames[j][:hop];  new ola_tail = frames[T-1][hop:]
+// The same on K-split partial frames: frame value (row, c) = window[c] * sum over z (in order) of part[row][z][c]
+// (the streaming iSTFT of a few frames runs split over K, gemm_rows.h; this kernel is its summing half).
+__global__ void stream_ola_ksplit_kernel(const float* part, int ks, int W, const float* window, float* ola_tail, float* pcm_out, int S, int n_hops, int hop) {
+    const int s = blockIdx.x;
+    const int win = 2 * hop;
+    auto fr = [&](int j, int c) {
+        const float* p = part + ((size_t)(s * n_hops + j) * ks) * W + c;
+        float v = p[0];
+        for (int z = 1; z < ks; ++z) v += p[(size_t)z * W];
+        return v * window[c];
+    };
+    for (int idx = threadIdx.x; idx < n_hops * hop; idx += blockDim.x) {
+        int j = idx / hop, i = idx - j * hop;
+        float prev = j ? fr(j - 1, hop + i) : ola_tail[(size_t)s * hop + i];
+        pcm_out[(size_t)s * n_hops * hop + idx] = prev + fr(j, i);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hop; i += blockDim.x) ola_tail[(size_t)s * hop + i] = fr(n_hops - 1, hop + i);
+}
+
 __global__ void stream_ola_kernel(const float* frames, float* ola_tail, float* pcm_out, int S, int n_hops, int hop) {
     const int s = blockIdx.x;
     const int win = 2 * hop;

@@ -134,7 +134,7 @@ int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
  * gru256_c16_tiles tiles run the two cells of each decoder stack as one wavefront launch, gru_stack.h), "gru256_chain" /
  * "gru256_chain_tiles" (opt-in, default 0 / 2: all five GRU-256 cells as one wavefront launch), "tail_frames" (default 32:
  * >= 96 streams, automatic chunking: a last chunk of >= 96 frames gives up a tail chunk of this many frames; 0 off), "fcln_gi" /
- * "hop_glue" / "stft_ksplit" / "gru256_step" (small-batch and single-hop launch fusions, fcln_gi.h, gru_stack.h; default 1), "pipe_chunk".  Unknown name -> DPDF_E_INVALID. */
+ * "hop_glue" / "gru256_step" (small-batch and single-hop launch fusions, fcln_gi.h, gru_stack.h; default 1), "stft_ksplit" (bit 0: STFT of a few 48 kHz frames split over K, bit 1: streaming iSTFT split over K; default 3), "pipe_chunk".  Unknown name -> DPDF_E_INVALID. */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);
 
 /* Rational polyphase resampler on the device, for `ensure_sample_rate` when the caller's rate differs from the

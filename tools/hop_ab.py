@@ -5,8 +5,8 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
 from dpdfnet_amd import backend as be
 from dpdfnet_amd.weights import synth_blob
-SETS = {"base": {"hop_glue": 0, "stft_ksplit": 0, "fcln_gi": 0, "gru256_step": 0}, "glue+ksplit": {"hop_glue": 1, "stft_ksplit": 1, "fcln_gi": 1, "gru256_step": 0},
-        "+step": {"hop_glue": 1, "stft_ksplit": 1, "fcln_gi": 1, "gru256_step": 1}}
+SETS = {"base": {"hop_glue": 0, "stft_ksplit": 0, "fcln_gi": 0, "gru256_step": 0}, "glue+stft+step": {"hop_glue": 1, "stft_ksplit": 1, "fcln_gi": 1, "gru256_step": 1},
+        "+istft": {"hop_glue": 1, "stft_ksplit": 3, "fcln_gi": 1, "gru256_step": 1}}
 for sr, nb, S in ((48000, 8, 64), (16000, 2, 1), (16000, 4, 8)):
     m = be.HipModel(sr, nb, synth_blob(be.manifest(sr, nb), 20260417), 0)
     st = be.HipStreams(m, S)
