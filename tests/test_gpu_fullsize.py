@@ -34,7 +34,7 @@ def test_baseline_batch_configs_full_size(be, nb, B, check_oracle):
     from oracle import oracle as orc
     sr, n = 16000, 160000
     m, blob = _model(be, sr, nb)
-    m.set_chunk_frames(128)
+    # AUTOMATIC chunk schedule (5 x 192 + 43 frames at 256 clips, tail-chunk rule armed): the execution shape bench.py times
     base = [synth_clip(n, sr, 9000 + i) for i in range(6)]
     # every slot holds a DIFFERENT signal (6 clips x a slot-dependent gain and circular shift), so a slot-dependent bug
     # shows up in the oracle spot checks below, not only in the bit-identity asserts
@@ -60,7 +60,11 @@ def test_baseline_batch_configs_full_size(be, nb, B, check_oracle):
     pre = m.enhance_batch(wav[:4, :n0], None)
     keep = n0 - 4 * m.win_len
     assert rms(pre[:, :keep] - out[:4, :keep]) < WAVE_TOL
-    # chunk invariance at size
+    # chunk invariance at size: forced 128- and 200-frame schedules against the automatic one
+    m.set_chunk_frames(128)
+    out1 = m.enhance_batch(wav, None)
+    assert rms(out1 - out) < 1e-6
+    assert rms(out1[255] - out[255]) < 1e-6 and rms(out1[131] - out[131]) < 1e-6
     m.set_chunk_frames(200)
     out2 = m.enhance_batch(wav[:32], None)
     assert rms(out2 - out[:32]) < 1e-6
