@@ -33,6 +33,7 @@
 #include "gru_bf16x3.h"
 #include "gru_stack.h"
 #include "fcln_gi.h"
+#include "gru_scan4.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -201,6 +202,7 @@ struct SepConvW { size_t dw, pwfrag, bias; int nsub; };        // arena offsets
 struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs;
                 size_t wlimb;                 // opt-in bf16x3 mode: the same weights as three bf16 limbs per value (gru_bf16x3.h), in float-sized arena slots
+                size_t hh4;                   // W_hh for the 4-row scan (gru_scan4.h): [dir][wave 4][k 64][lane 4u+j]: gate j of unit 16 wave + u (j = 3: zero)
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
 struct GlW { size_t frag, bias, raw; int G, Og, Ig, NT; };   // raw: the reference's [G][Og][Ig] weight as is (gru256_chain16_kernel)
 struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn, ih_as_hh; };   // ih_as_hh: W_ih packed like hh_frag (second cell of a stacked pair, gru_stack.h)   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
@@ -308,6 +310,7 @@ struct dpdf_model {
     // 0 = everything serial on the main stream (A/B timing).
     int overlap = 27;                  // bit 5 (sub-stage pipeline of stage 2 for <= 64 streams) is OFF by default: measured slower (run_stage2_pipe)
     int pipe_chunk = 128;              // automatic chunk length (frames) of the sub-stage pipeline for small batches
+    int scan4_max_wgs = 512;           // hoisted-input GRU-64 scans on 4-row tiles (gru_scan4.h) while the launch has at most this many workgroups (0 = never)
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     // OPT-IN (measured, no gain: DESIGN.md section 7): at most gru256_chain_tiles tiles -> all five GRU-256 cells of stage 2
     // as one wavefront launch (gru_stack.h: gru256_chain16_kernel)
@@ -364,6 +367,15 @@ struct dpdf_streams {
     dpdf_model* m; int S;
     DevBuf state, in_tail, ola_tail, spec, spec_e, pcm_in, pcm_out;
     std::vector<int> primed;
+    // host-pointer calls: PCM staged through pinned, GPU-visible host memory -- the first kernel of a hop reads the noisy PCM
+    // straight out of it and the last one writes the enhanced PCM (and the device error flag) straight into it: no copy
+    // commands, no second blocking read-back of the flag
+    float* pin_in = nullptr; float* pin_out = nullptr; int* pin_err = nullptr; size_t pin_cap = 0;
+    // (Measured and dropped: replaying a captured hipGraph of the hop -- ~110 launches over four streams -- instead of
+    // enqueueing them: 781 / 319 / 446 us per hop against 748 / 307 / 433 us with plain launches for 64 x 48 kHz dpdfnet8,
+    // one 16 kHz dpdfnet2 and eight dpdfnet4 streams: the hop is bound by the dependent kernels on the GPU, not by the
+    // host's 190-270 us of enqueueing (tools/hop_probe.py); and the HIP runtime bundled with torch recurses without end in
+    // hipStreamEndCapture on this four-stream fork/join pattern.)
 };
 
 // The GRU-256 cluster scans exchange h' between workgroups by spinning on granules (gru_scan.h).  A spin that times out
@@ -503,6 +515,15 @@ GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::str
         }
     }
     g.wfrag = A.add(frag); g.bias = A.add(bias);
+    {   // 4-row scan (gru_scan4.h): B operand of k-step k of wave w, lane 4u + j = scaled W_hh[gate j][unit 16w + u][k]
+        std::vector<float> f4((size_t)g.ndirs * 4 * 64 * 64, 0.f);
+        for (int d = 0; d < g.ndirs; ++d) {
+            const float* whh = B.get(dirs[d].first + ".weight_hh" + dirs[d].second);
+            for (int w = 0; w < 4; ++w) for (int k = 0; k < 64; ++k) for (int u = 0; u < 16; ++u) for (int j = 0; j < 3; ++j)
+                f4[(((size_t)(d * 4 + w) * 64) + k) * 64 + 4 * u + j] = whh[(size_t)(j * 64 + 16 * w + u) * 64 + k] * gate_scale[j];
+        }
+        g.hh4 = A.add(f4);
+    }
     {   // bf16x3 limbs of the same (scaled) weights: [dir][wave 4][gate 3][kblock 4][limb 3][lane 64][8] (gru_bf16x3.h)
         std::vector<uint16_t> limbs((size_t)g.ndirs * 4 * 3 * 4 * 3 * 64 * 8);
         for (int d = 0; d < g.ndirs; ++d) {
@@ -1009,7 +1030,10 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                     BiasActStore<4> ep{gibuf.p, 384, 64, m->C(w.intra.ih_bias), 64, 64, ACT_NONE};
                     launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.intra.ih_frag), ep, M, 64, 6);
                 }
-                hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const float*)gibuf.p, 384);
+                if (((ai.nrows + 3) / 4) * 2 <= m->scan4_max_wgs)
+                    hipLaunchKernelGGL(gru64_scan4_gi_kernel, dim3((ai.nrows + 3) / 4, 2), dim3(256), 0, m->cur, ai, m->C(w.intra.hh4), (const float*)gibuf.p, 384);
+                else
+                    hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const float*)gibuf.p, 384);
             } else if (bf3) {
                 ProfScope ps(m, df ? "gru64_scan_bf16x3_kernel/intra_df" : "gru64_scan_bf16x3_kernel/intra_erb");
                 hipLaunchKernelGGL(gru64_scan_bf16x3_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const __bf16*)m->C(w.intra.wlimb));
@@ -1076,7 +1100,10 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                     BiasActStore<4> ep{gibuf.p, 192, 64, m->C(w.inter.ih_bias), 64, 64, ACT_NONE};
                     launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.inter.ih_frag), ep, M, 64, 3);
                 }
-                hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const float*)gibuf.p, 192);
+                if ((ae.nrows + 3) / 4 <= m->scan4_max_wgs)
+                    hipLaunchKernelGGL(gru64_scan4_gi_kernel, dim3((ae.nrows + 3) / 4, 1), dim3(256), 0, m->cur, ae, m->C(w.inter.hh4), (const float*)gibuf.p, 192);
+                else
+                    hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const float*)gibuf.p, 192);
             } else if (bf3) {
                 ProfScope ps(m, df ? "gru64_scan_bf16x3_kernel/inter_df" : "gru64_scan_bf16x3_kernel/inter_erb");
                 hipLaunchKernelGGL(gru64_scan_bf16x3_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const __bf16*)m->C(w.inter.wlimb));
@@ -1904,6 +1931,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
+    else if (n == "scan4_max_wgs") m->scan4_max_wgs = value < 0 ? 0 : value;
     else if (n == "gru256_chain") m->gru256_chain = value != 0;
     else if (n == "gru256_chain_tiles") m->gru256_chain_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
@@ -2134,6 +2162,9 @@ extern "C" void dpdf_streams_destroy(dpdf_streams* s) {
     (void)hipStreamSynchronize(s->m->stream);
     DevBuf* bufs[] = {&s->state, &s->in_tail, &s->ola_tail, &s->spec, &s->spec_e, &s->pcm_in, &s->pcm_out};
     for (DevBuf* b : bufs) b->release();
+    if (s->pin_in) (void)hipHostFree(s->pin_in);
+    if (s->pin_out) (void)hipHostFree(s->pin_out);
+    if (s->pin_err) (void)hipHostFree(s->pin_err);
     delete s;
 }
 extern "C" int dpdf_streams_reset(dpdf_streams* s, int stream) {
@@ -2164,31 +2195,17 @@ extern "C" int dpdf_streams_prime(dpdf_streams* s, const float* pcm_in, int flag
     for (int i = 0; i < s->S; ++i) s->primed[i] = 1;
     return DPDF_OK;
 }
-extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, int flags) {
-    if (!s || !pcm_in || !pcm_out) return set_err(DPDF_E_INVALID, "null argument");
-    if (n_hops <= 0) return set_err(DPDF_E_INVALID, "n_hops must be positive");
+// One streaming call on device buffers: src [S][T*hop] -> dst [S][T*hop], everything enqueued on the engine's streams and
+// joined back into m->stream.  host_err (pinned host memory, may be null): the last kernel mirrors the device error flag into it.
+static int streams_enqueue(dpdf_streams* s, const float* src, int T, float* dst, int* host_err) {
     dpdf_model* m = s->m;
-    for (int i = 0; i < s->S; ++i)
-        if (!s->primed[i]) return set_err(DPDF_E_STATE, "stream %d not primed: call dpdf_streams_prime with its first hop", i);
-    std::lock_guard<std::mutex> lk(m->mu);
-    HIP_TRY(hipSetDevice(m->device));
     const dpdf_dims& d = m->d;
-    const int S = s->S, T = n_hops;
-    const size_t npcm = (size_t)S * T * d.hop, nspec = (size_t)S * T * d.F * 2;
-    const bool host = !(flags & DPDF_DEVICE_PTRS);
+    const int S = s->S;
     int rc;
-    if ((rc = s->spec.ensure(nspec)) || (rc = s->spec_e.ensure(nspec)) || (rc = m->frames.ensure((size_t)S * T * d.win)) ||
-        (rc = s->pcm_in.ensure((size_t)S * (T + 1) * d.hop + npcm)) || (rc = s->pcm_out.ensure(npcm))) return rc;
     float* xbuf = s->pcm_in.p;                       // [S][(T+1)*hop]
-    float* d_in = s->pcm_in.p + (size_t)S * (T + 1) * d.hop;
-    const float* src = pcm_in; float* dst = pcm_out;
-    if (host) {
-        HIP_TRY(hipMemcpyAsync(d_in, pcm_in, npcm * sizeof(float), hipMemcpyHostToDevice, m->stream));
-        src = d_in; dst = s->pcm_out.p;
-    }
     hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, s->in_tail.p, xbuf, S, T, d.hop);
     {   // causal analysis (stream.py:119-126): frame j = xbuf[j*hop : j*hop+win] * window -> rfft.
-                StftA<64> ap{xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
+        StftA<64> ap{xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
         if (S * T <= SMALL_M_ROWS) {
             if ((rc = stft_small(m, ap, s->spec.p, S * T))) return rc;
         } else {
@@ -2210,19 +2227,53 @@ extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_
             if ((rc = m->stft_part.ensure((size_t)S * T * ks * W))) return rc;
             BiasActStore<5> ep7{m->stft_part.p, (size_t)ks * W, 80, nullptr, 0, 80, ACT_NONE};
             launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep7, S * T, m->istft_K, m->istft_groups, 2048, ks);
-            hipLaunchKernelGGL(stream_ola_ksplit_kernel, dim3(S), dim3(256), 0, m->stream, (const float*)m->stft_part.p, ks, W, m->C(m->window), s->ola_tail.p, dst, S, T, d.hop);
+            hipLaunchKernelGGL(stream_ola_ksplit_kernel, dim3(S), dim3(256), 0, m->stream, (const float*)m->stft_part.p, ks, W, m->C(m->window), s->ola_tail.p, dst, S, T, d.hop,
+                               (const int*)m->d_err, host_err);
         } else {
             if (S * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups / 4);
             else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups);
-            hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, s->ola_tail.p, dst, S, T, d.hop);
+            hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, s->ola_tail.p, dst, S, T, d.hop, (const int*)m->d_err, host_err);
         }
     }
     HIP_TRY(hipGetLastError());
-    if (host) {
-        HIP_TRY(hipMemcpyAsync(pcm_out, dst, npcm * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    return DPDF_OK;
+}
+
+extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, int flags) {
+    if (!s || !pcm_in || !pcm_out) return set_err(DPDF_E_INVALID, "null argument");
+    if (n_hops <= 0) return set_err(DPDF_E_INVALID, "n_hops must be positive");
+    dpdf_model* m = s->m;
+    for (int i = 0; i < s->S; ++i)
+        if (!s->primed[i]) return set_err(DPDF_E_STATE, "stream %d not primed: call dpdf_streams_prime with its first hop", i);
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    const dpdf_dims& d = m->d;
+    const int S = s->S, T = n_hops;
+    const size_t npcm = (size_t)S * T * d.hop, nspec = (size_t)S * T * d.F * 2;
+    const bool host = !(flags & DPDF_DEVICE_PTRS);
+    int rc;
+    if ((rc = s->spec.ensure(nspec)) || (rc = s->spec_e.ensure(nspec)) || (rc = m->frames.ensure((size_t)S * T * d.win)) ||
+        (rc = s->pcm_in.ensure((size_t)S * (T + 1) * d.hop)) || (rc = s->pcm_out.ensure(1))) return rc;
+    if (!host) return streams_enqueue(s, pcm_in, T, pcm_out, nullptr);
+    // ---- host pointers: pinned staging both ways ----
+    if (npcm > s->pin_cap) {
         HIP_TRY(hipStreamSynchronize(m->stream));
+        if (s->pin_in) (void)hipHostFree(s->pin_in);
+        if (s->pin_out) (void)hipHostFree(s->pin_out);
+        s->pin_in = s->pin_out = nullptr; s->pin_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&s->pin_in, npcm * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&s->pin_out, npcm * sizeof(float), hipHostMallocDefault));
+        s->pin_cap = npcm;
+    }
+    if (!s->pin_err) { HIP_TRY(hipHostMalloc((void**)&s->pin_err, sizeof(int), hipHostMallocDefault)); *s->pin_err = 0; }
+    memcpy(s->pin_in, pcm_in, npcm * sizeof(float));
+    if ((rc = streams_enqueue(s, s->pin_in, T, s->pin_out, s->pin_err))) return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (*s->pin_err) {
+        *s->pin_err = 0;
         return check_device_err(m);
     }
+    memcpy(pcm_out, s->pin_out, npcm * sizeof(float));
     return DPDF_OK;
 }
 extern "C" int dpdf_streams_get_state(dpdf_streams* s, int stream, float* state_host) {

@@ -428,8 +428,11 @@ __global__ void stream_stage_in_kernel(const float* pcm_in, float* in_tail, floa
 //   out hop j = (j ? frames[j-1][hop:] : ola_tail) + frames[j][:hop];  new ola_tail = frames[T-1][hop:]
 // The same on K-split partial frames: frame value (row, c) = window[c] * sum over z (in order) of part[row][z][c]
 // (the streaming iSTFT of a few frames runs split over K, gemm_rows.h; this kernel is its summing half).
-__global__ void stream_ola_ksplit_kernel(const float* part, int ks, int W, const float* window, float* ola_tail, float* pcm_out, int S, int n_hops, int hop) {
+// dev_err / host_err: the last kernel of a streaming call mirrors the device error flag into pinned host memory (null: no mirror)
+__global__ void stream_ola_ksplit_kernel(const float* part, int ks, int W, const float* window, float* ola_tail, float* pcm_out, int S, int n_hops, int hop,
+                                         const int* dev_err, int* host_err) {
     const int s = blockIdx.x;
+    if (host_err && s == 0 && threadIdx.x == 0) *host_err = *dev_err;
     const int win = 2 * hop;
     auto fr = [&](int j, int c) {
         const float* p = part + ((size_t)(s * n_hops + j) * ks) * W + c;
@@ -446,8 +449,9 @@ __global__ void stream_ola_ksplit_kernel(const float* part, int ks, int W, const
     for (int i = threadIdx.x; i < hop; i += blockDim.x) ola_tail[(size_t)s * hop + i] = fr(n_hops - 1, hop + i);
 }
 
-__global__ void stream_ola_kernel(const float* frames, float* ola_tail, float* pcm_out, int S, int n_hops, int hop) {
+__global__ void stream_ola_kernel(const float* frames, float* ola_tail, float* pcm_out, int S, int n_hops, int hop, const int* dev_err, int* host_err) {
     const int s = blockIdx.x;
+    if (host_err && s == 0 && threadIdx.x == 0) *host_err = *dev_err;
     const int win = 2 * hop;
     const float* fr = frames + (size_t)s * n_hops * win;
     for (int idx = threadIdx.x; idx < n_hops * hop; idx += blockDim.x) {
