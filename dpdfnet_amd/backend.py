@@ -48,7 +48,8 @@ EXPORTED_SYMBOLS = (
     "dpdf_streams_get_state", "dpdf_sync", "dpdf_profile_enable", "dpdf_profile_report",
     "dpdf_set_chunk_frames", "dpdf_set_overlap", "dpdf_set_fuse_dprnn", "dpdf_debug_fetch",
     "dpdf_resample_len", "dpdf_resample", "dpdf_enhance_batch_ragged", "dpdf_debug_raise_device_error",
-    "dpdf_set_option",
+    "dpdf_set_option", "dpdf_streams_process_masked", "dpdf_streams_set_state", "dpdf_streams_get_tails",
+    "dpdf_streams_prime_one", "dpdf_streams_is_primed", "dpdf_recovery_count",
 )
 
 
@@ -104,6 +105,13 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_streams_prime.argtypes = [vp, vp, ctypes.c_int]
         L.dpdf_streams_process.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int]
         L.dpdf_streams_get_state.argtypes = [vp, ctypes.c_int, fp]
+        L.dpdf_streams_process_masked.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_char_p, ctypes.c_int]
+        L.dpdf_streams_set_state.argtypes = [vp, ctypes.c_int, vp, vp, vp]
+        L.dpdf_streams_get_tails.argtypes = [vp, ctypes.c_int, vp, vp]
+        L.dpdf_streams_prime_one.argtypes = [vp, ctypes.c_int, vp]
+        L.dpdf_streams_is_primed.argtypes = [vp, ctypes.c_int]
+        L.dpdf_recovery_count.argtypes = [vp]
+        L.dpdf_recovery_count.restype = ctypes.c_long
         L.dpdf_profile_enable.argtypes = [vp, ctypes.c_int]
         L.dpdf_profile_report.restype = ctypes.c_size_t
         L.dpdf_profile_report.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
@@ -276,6 +284,11 @@ class HipModel:
     def sync(self) -> None:
         _check(self._L.dpdf_sync(self._h))
 
+    @property
+    def recovery_count(self) -> int:
+        """Host-pointer calls that were re-run on the non-spinning GRU-256 kernels after a cluster exchange timed out."""
+        return int(self._L.dpdf_recovery_count(self._h))
+
     def debug_raise_device_error(self) -> None:
         """Test hook: make the next synchronisation point report the device-side failure path."""
         _check(self._L.dpdf_debug_raise_device_error(self._h))
@@ -355,7 +368,42 @@ class HipStreams:
         _check(self.model._L.dpdf_streams_process(self._h, pcm.ctypes.data, n_hops, out.ctypes.data, DPDF_HOST_PTRS))
         return out
 
+    def process_masked(self, pcm: np.ndarray, active) -> np.ndarray:
+        """One device call that advances only the streams with active[i] true; rows of the others are returned as zeros
+        and their state / tails are untouched (`dpdf_streams_process_masked`)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32).reshape(self.n, -1)
+        if pcm.shape[1] % self.model.hop:
+            raise ValueError("streams.process needs a whole number of hops per stream")
+        act = np.ascontiguousarray(np.asarray(active).astype(bool).astype(np.uint8)).reshape(self.n)
+        out = np.zeros_like(pcm)
+        _check(self.model._L.dpdf_streams_process_masked(self._h, pcm.ctypes.data, pcm.shape[1] // self.model.hop, out.ctypes.data,
+                                                         act.tobytes(), DPDF_HOST_PTRS))
+        return out
+
+    def prime_one(self, stream: int, pcm_hop: np.ndarray) -> None:
+        pcm_hop = np.ascontiguousarray(pcm_hop, dtype=np.float32).reshape(self.model.hop)
+        _check(self.model._L.dpdf_streams_prime_one(self._h, int(stream), pcm_hop.ctypes.data))
+
+    def is_primed(self, stream: int) -> bool:
+        return bool(self.model._L.dpdf_streams_is_primed(self._h, int(stream)))
+
     def get_state(self, stream: int) -> np.ndarray:
         st = np.empty(self.model.state_size, dtype=np.float32)
         _check(self.model._L.dpdf_streams_get_state(self._h, int(stream), _fp(st)))
         return st
+
+    def get_tails(self, stream: int):
+        """(analysis tail, overlap-add tail) of one stream, hop floats each (reference stream.py:62-72 buffers)."""
+        a = np.empty(self.model.hop, dtype=np.float32); b = np.empty(self.model.hop, dtype=np.float32)
+        _check(self.model._L.dpdf_streams_get_tails(self._h, int(stream), a.ctypes.data, b.ctypes.data))
+        return a, b
+
+    def set_state(self, stream: int, state=None, in_tail=None, ola_tail=None) -> None:
+        """Resume a stream from a saved reference-layout state vector and (optionally) its two hop-sized buffers."""
+        def ptr(x, n):
+            if x is None:
+                return None, None
+            x = np.ascontiguousarray(x, dtype=np.float32).reshape(n)
+            return x, x.ctypes.data
+        ks, ps = ptr(state, self.model.state_size); ki, pi = ptr(in_tail, self.model.hop); ko, po = ptr(ola_tail, self.model.hop)
+        _check(self.model._L.dpdf_streams_set_state(self._h, int(stream), ps, pi, po))

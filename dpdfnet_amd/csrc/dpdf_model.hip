@@ -340,6 +340,7 @@ struct dpdf_model {
     int* d_err = nullptr;
     int* d_lens = nullptr; size_t d_lens_cap = 0; std::vector<int> h_lens;   // per-clip lengths of a ragged batch
     int use_gru256_cluster = 1;
+    long recoveries = 0;               // calls re-run on the non-spinning GRU-256 kernels after a cluster exchange timed out (dpdf_recovery_count)
     // prepared weights (arena offsets)
     size_t conv0_w, conv0_b;
     SepConvW erb_conv1, erb_conv2, erb_conv3, df_conv1, convt3, convt2, convt1;
@@ -371,6 +372,13 @@ struct dpdf_streams {
     // straight out of it and the last one writes the enhanced PCM (and the device error flag) straight into it: no copy
     // commands, no second blocking read-back of the flag
     float* pin_in = nullptr; float* pin_out = nullptr; int* pin_err = nullptr; size_t pin_cap = 0;
+    // masked calls (dpdf_streams_process_masked): the active streams packed into a dense batch
+    DevBuf cstate, cin, cola, cpcm_in, cpcm_out; int* pin_idx = nullptr;
+    // pre-call copy of the state and the tails, taken at the start of every host-pointer call: a GRU-256 exchange that timed out
+    // leaves the in-place state half advanced -- the call is then restored from here and re-run on the kernels that
+    // do not spin (recover_and_rerun)
+    DevBuf snap_state, snap_in, snap_ola;
+    hipEvent_t ev_snap = nullptr;
     // (Measured and dropped: replaying a captured hipGraph of the hop -- ~110 launches over four streams -- instead of
     // enqueueing them: 781 / 319 / 446 us per hop against 748 / 307 / 433 us with plain launches for 64 x 48 kHz dpdfnet8,
     // one 16 kHz dpdfnet2 and eight dpdfnet4 streams: the hop is bound by the dependent kernels on the GPU, not by the
@@ -388,8 +396,35 @@ static int check_device_err(dpdf_model* m) {
     HIP_TRY(hipMemcpy(&flag, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
     if (!flag) return DPDF_OK;
     HIP_TRY(hipMemset(m->d_err, 0, sizeof(int)));
-    return set_err(DPDF_E_RUNTIME, "GRU-256 cluster exchange timed out (peer workgroups were not co-resident); the results of "
-                                   "this call are invalid -- retry, or run the engine on a GPU it does not share");
+    return set_err(DPDF_E_RUNTIME, "GRU-256 cluster exchange timed out (peer workgroups were not co-resident) in an asynchronous "
+                                   "(device-pointer) call: its results are invalid and a state updated in place is half advanced -- "
+                                   "streams must be reset (dpdf_streams_reset) or restored (dpdf_streams_set_state), batch calls "
+                                   "re-issued; host-pointer calls recover by themselves (dpdf_recovery_count)");
+}
+
+// Host-pointer calls of the batch entry points recover from a timed-out exchange by themselves: their state starts from the
+// host's copy (or the initial state), so the whole call simply runs again with every GRU-256 recurrence on the single-
+// workgroup scan, which has no cross-workgroup waits.  DPDF_RETRY is the internal "flag was set" code of the call bodies.
+constexpr int DPDF_RETRY = -1000;
+static int device_err_or_retry(dpdf_model* m) {
+    if (!m->d_err) return DPDF_OK;
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (!flag) return DPDF_OK;
+    HIP_TRY(hipMemset(m->d_err, 0, sizeof(int)));
+    return DPDF_RETRY;
+}
+template <class Body>
+static int with_recovery(dpdf_model* m, Body body) {
+    int rc = body();
+    if (rc != DPDF_RETRY) return rc;
+    const int saved = m->use_gru256_cluster;
+    m->use_gru256_cluster = 0;
+    rc = body();
+    m->use_gru256_cluster = saved;
+    ++m->recoveries;
+    if (rc == DPDF_RETRY) return set_err(DPDF_E_RUNTIME, "device error flag raised again on the non-spinning path");
+    return rc;
 }
 
 // streams + events of one lane; `pipe` adds the three extra streams of the sub-stage pipeline (run_stage2_pipe)
@@ -1902,6 +1937,7 @@ extern "C" int dpdf_sample_rate(const dpdf_model* m) { return m ? m->d.sr : 0; }
 extern "C" int dpdf_num_frames(const dpdf_model* m, int n) { return m ? 1 + (n + m->d.win) / m->d.hop : 0; }
 extern "C" int dpdf_set_chunk_frames(dpdf_model* m, int frames) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
+    std::lock_guard<std::mutex> lk(m->mu);
     m->chunk_frames = frames;
     return DPDF_OK;
 }
@@ -1949,6 +1985,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
 }
 extern "C" int dpdf_sync(dpdf_model* m) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
+    std::lock_guard<std::mutex> lk(m->mu);     // the flag read-and-clear below must not interleave with another thread's call
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return check_device_err(m);      // device-pointer calls surface a failed GRU-256 exchange here
@@ -2021,6 +2058,7 @@ extern "C" int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, f
     if (T == 0) return DPDF_OK;
     std::lock_guard<std::mutex> lk(m->mu);
     HIP_TRY(hipSetDevice(m->device));
+    return with_recovery(m, [&]() -> int {
     const size_t nspec = (size_t)B * T * m->d.F * 2, nstate = (size_t)B * m->d.state_size;
     const float* d_spec = spec; float* d_state = state; float* d_out = spec_e;
     const bool host = !(flags & DPDF_DEVICE_PTRS);
@@ -2036,12 +2074,15 @@ extern "C" int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, f
         if (rc) return rc;
     }
     if (host) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        int er = device_err_or_retry(m);       // before the state is copied back: a retry starts from the caller's state again
+        if (er) return er;
         HIP_TRY(hipMemcpyAsync(spec_e, d_out, nspec * sizeof(float), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipMemcpyAsync(state, d_state, nstate * sizeof(float), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
-        return check_device_err(m);
     }
     return DPDF_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2059,6 +2100,7 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
     if (N == 0) return DPDF_OK;
     std::lock_guard<std::mutex> lk(m->mu);
     HIP_TRY(hipSetDevice(m->device));
+    return with_recovery(m, [&]() -> int {
     const dpdf_dims& d = m->d;
     const int T = 1 + (N + d.win) / d.hop;
     const int* d_lens = nullptr;
@@ -2121,9 +2163,10 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
     if (host) {
         HIP_TRY(hipMemcpyAsync(out, d_out, nw * sizeof(float), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
-        return check_device_err(m);
+        return device_err_or_retry(m);
     }
     return DPDF_OK;
+    });
 }
 
 extern "C" int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N, float attn_limit_db, float* out, int flags) {
@@ -2160,8 +2203,11 @@ extern "C" void dpdf_streams_destroy(dpdf_streams* s) {
     if (!s) return;
     (void)hipSetDevice(s->m->device);
     (void)hipStreamSynchronize(s->m->stream);
-    DevBuf* bufs[] = {&s->state, &s->in_tail, &s->ola_tail, &s->spec, &s->spec_e, &s->pcm_in, &s->pcm_out};
+    DevBuf* bufs[] = {&s->state, &s->in_tail, &s->ola_tail, &s->spec, &s->spec_e, &s->pcm_in, &s->pcm_out,
+                      &s->cstate, &s->cin, &s->cola, &s->cpcm_in, &s->cpcm_out, &s->snap_state, &s->snap_in, &s->snap_ola};
     for (DevBuf* b : bufs) b->release();
+    if (s->pin_idx) (void)hipHostFree(s->pin_idx);
+    if (s->ev_snap) (void)hipEventDestroy(s->ev_snap);
     if (s->pin_in) (void)hipHostFree(s->pin_in);
     if (s->pin_out) (void)hipHostFree(s->pin_out);
     if (s->pin_err) (void)hipHostFree(s->pin_err);
@@ -2197,13 +2243,15 @@ extern "C" int dpdf_streams_prime(dpdf_streams* s, const float* pcm_in, int flag
 }
 // One streaming call on device buffers: src [S][T*hop] -> dst [S][T*hop], everything enqueued on the engine's streams and
 // joined back into m->stream.  host_err (pinned host memory, may be null): the last kernel mirrors the device error flag into it.
-static int streams_enqueue(dpdf_streams* s, const float* src, int T, float* dst, int* host_err) {
+// (S, state, in_tail, ola_tail): the stream set itself, or the packed active subset of a masked call.
+struct StreamView { int S; float* state; float* in_tail; float* ola_tail; };
+static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* src, int T, float* dst, int* host_err) {
     dpdf_model* m = s->m;
     const dpdf_dims& d = m->d;
-    const int S = s->S;
+    const int S = v.S;
     int rc;
     float* xbuf = s->pcm_in.p;                       // [S][(T+1)*hop]
-    hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, s->in_tail.p, xbuf, S, T, d.hop);
+    hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, v.in_tail, xbuf, S, T, d.hop);
     {   // causal analysis (stream.py:119-126): frame j = xbuf[j*hop : j*hop+win] * window -> rfft.
         StftA<64> ap{xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
         if (S * T <= SMALL_M_ROWS) {
@@ -2214,7 +2262,7 @@ static int streams_enqueue(dpdf_streams* s, const float* src, int T, float* dst,
             launch_gemm_rows_wn<2, 64>(m->stream, ap, m->C(m->stft_frag_s), ep, S * T, d.win, m->stft_groups_s / 4);
         }
     }
-    rc = run_chunks(m, s->spec.p, (size_t)T * d.F * 2, S, T, s->state.p, s->spec_e.p, nullptr, 0.f);
+    rc = run_chunks(m, s->spec.p, (size_t)T * d.F * 2, S, T, v.state, s->spec_e.p, nullptr, 0.f);
     if (rc) return rc;
     {
         PlainA<48> ap{s->spec_e.p, (size_t)2 * d.F, 0, 2 * d.F};
@@ -2227,35 +2275,89 @@ static int streams_enqueue(dpdf_streams* s, const float* src, int T, float* dst,
             if ((rc = m->stft_part.ensure((size_t)S * T * ks * W))) return rc;
             BiasActStore<5> ep7{m->stft_part.p, (size_t)ks * W, 80, nullptr, 0, 80, ACT_NONE};
             launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep7, S * T, m->istft_K, m->istft_groups, 2048, ks);
-            hipLaunchKernelGGL(stream_ola_ksplit_kernel, dim3(S), dim3(256), 0, m->stream, (const float*)m->stft_part.p, ks, W, m->C(m->window), s->ola_tail.p, dst, S, T, d.hop,
+            hipLaunchKernelGGL(stream_ola_ksplit_kernel, dim3(S), dim3(256), 0, m->stream, (const float*)m->stft_part.p, ks, W, m->C(m->window), v.ola_tail, dst, S, T, d.hop,
                                (const int*)m->d_err, host_err);
         } else {
             if (S * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups / 4);
             else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups);
-            hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, s->ola_tail.p, dst, S, T, d.hop, (const int*)m->d_err, host_err);
+            hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, v.ola_tail, dst, S, T, d.hop, (const int*)m->d_err, host_err);
         }
     }
     HIP_TRY(hipGetLastError());
     return DPDF_OK;
 }
 
-extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, int flags) {
+// The body of a streaming call on device-visible buffers (src / dst: device memory or pinned host memory), all streams or
+// the n_act packed ones listed in idx (device-visible).
+static int streams_run(dpdf_streams* s, const float* src, int T, float* dst, int n_act, const int* idx, int* host_err) {
+    dpdf_model* m = s->m;
+    const dpdf_dims& d = m->d;
+    if (n_act == s->S) return streams_enqueue(s, StreamView{s->S, s->state.p, s->in_tail.p, s->ola_tail.p}, src, T, dst, host_err);
+    const int npcm = T * d.hop;
+    StreamPackArgs pa{s->state.p, s->in_tail.p, s->ola_tail.p, s->cstate.p, s->cin.p, s->cola.p, src, s->cpcm_in.p, s->cpcm_out.p, dst,
+                      idx, (long)d.state_size, d.hop, npcm, (const int*)m->d_err, host_err};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(stream_pack_kernel<false>), dim3(n_act, 16), dim3(256), 0, m->stream, pa);
+    int rc = streams_enqueue(s, StreamView{n_act, s->cstate.p, s->cin.p, s->cola.p}, s->cpcm_in.p, T, s->cpcm_out.p, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(stream_pack_kernel<true>), dim3(n_act, 16), dim3(256), 0, m->stream, pa);
+    HIP_TRY(hipGetLastError());
+    return DPDF_OK;
+}
+
+// A GRU-256 cluster / step kernel whose exchange timed out has left the in-place state half advanced.  Host-pointer calls
+// recover by themselves: state and tails go back to the copy taken at the start of the call, the device flag is cleared and
+// the call runs again with every GRU-256 recurrence on the single-workgroup scan (no cross-workgroup waits, so it cannot
+// time out) -- same results to rounding.  Counted in dpdf_recovery_count.
+static int streams_recover_and_rerun(dpdf_streams* s, const float* src, int T, float* dst, int n_act, const int* idx) {
+    dpdf_model* m = s->m;
+    const dpdf_dims& d = m->d;
+    HIP_TRY(hipMemsetAsync(m->d_err, 0, sizeof(int), m->stream));
+    const size_t ns = (size_t)s->S * d.state_size, nt = (size_t)s->S * d.hop;
+    hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((ns / 4 + 256) / 256)), dim3(256), 0, m->stream, s->state.p, (const float*)s->snap_state.p, ns);
+    hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((nt / 4 + 256) / 256)), dim3(256), 0, m->stream, s->in_tail.p, (const float*)s->snap_in.p, nt);
+    hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((nt / 4 + 256) / 256)), dim3(256), 0, m->stream, s->ola_tail.p, (const float*)s->snap_ola.p, nt);
+    const int saved = m->use_gru256_cluster;
+    m->use_gru256_cluster = 0;
+    *s->pin_err = 0;
+    int rc = streams_run(s, src, T, dst, n_act, idx, s->pin_err);
+    m->use_gru256_cluster = saved;
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    ++m->recoveries;
+    if (*s->pin_err) { *s->pin_err = 0; return check_device_err(m); }
+    return DPDF_OK;
+}
+
+extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, const unsigned char* active, int flags) {
     if (!s || !pcm_in || !pcm_out) return set_err(DPDF_E_INVALID, "null argument");
     if (n_hops <= 0) return set_err(DPDF_E_INVALID, "n_hops must be positive");
     dpdf_model* m = s->m;
-    for (int i = 0; i < s->S; ++i)
+    int n_act = 0;
+    for (int i = 0; i < s->S; ++i) {
+        if (active && !active[i]) continue;
         if (!s->primed[i]) return set_err(DPDF_E_STATE, "stream %d not primed: call dpdf_streams_prime with its first hop", i);
+        ++n_act;
+    }
+    if (n_act == 0) return DPDF_OK;
     std::lock_guard<std::mutex> lk(m->mu);
     HIP_TRY(hipSetDevice(m->device));
     const dpdf_dims& d = m->d;
     const int S = s->S, T = n_hops;
-    const size_t npcm = (size_t)S * T * d.hop, nspec = (size_t)S * T * d.F * 2;
+    const size_t npcm = (size_t)S * T * d.hop, nspec = (size_t)n_act * T * d.F * 2;
     const bool host = !(flags & DPDF_DEVICE_PTRS);
     int rc;
-    if ((rc = s->spec.ensure(nspec)) || (rc = s->spec_e.ensure(nspec)) || (rc = m->frames.ensure((size_t)S * T * d.win)) ||
-        (rc = s->pcm_in.ensure((size_t)S * (T + 1) * d.hop)) || (rc = s->pcm_out.ensure(1))) return rc;
-    if (!host) return streams_enqueue(s, pcm_in, T, pcm_out, nullptr);
-    // ---- host pointers: pinned staging both ways ----
+    if ((rc = s->spec.ensure(nspec)) || (rc = s->spec_e.ensure(nspec)) || (rc = m->frames.ensure((size_t)n_act * T * d.win)) ||
+        (rc = s->pcm_in.ensure((size_t)n_act * (T + 1) * d.hop))) return rc;
+    if (!s->pin_idx) HIP_TRY(hipHostMalloc((void**)&s->pin_idx, (size_t)S * sizeof(int), hipHostMallocDefault));
+    if (n_act < S) {
+        HIP_TRY(hipStreamSynchronize(m->stream));      // an earlier asynchronous masked call may still be reading pin_idx
+        int k = 0;
+        for (int i = 0; i < S; ++i) if (active[i]) s->pin_idx[k++] = i;
+        if ((rc = s->cstate.ensure((size_t)n_act * d.state_size)) || (rc = s->cin.ensure((size_t)n_act * d.hop)) || (rc = s->cola.ensure((size_t)n_act * d.hop)) ||
+            (rc = s->cpcm_in.ensure((size_t)n_act * T * d.hop)) || (rc = s->cpcm_out.ensure((size_t)n_act * T * d.hop))) return rc;
+    }
+    if (!host) return streams_run(s, pcm_in, T, pcm_out, n_act, s->pin_idx, nullptr);
+    // ---- host pointers: pinned staging both ways, pre-call snapshot, self-recovery ----
     if (npcm > s->pin_cap) {
         HIP_TRY(hipStreamSynchronize(m->stream));
         if (s->pin_in) (void)hipHostFree(s->pin_in);
@@ -2266,16 +2368,76 @@ extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_
         s->pin_cap = npcm;
     }
     if (!s->pin_err) { HIP_TRY(hipHostMalloc((void**)&s->pin_err, sizeof(int), hipHostMallocDefault)); *s->pin_err = 0; }
-    memcpy(s->pin_in, pcm_in, npcm * sizeof(float));
-    if ((rc = streams_enqueue(s, s->pin_in, T, s->pin_out, s->pin_err))) return rc;
+    if (n_act == S) memcpy(s->pin_in, pcm_in, npcm * sizeof(float));
+    else for (int k = 0; k < n_act; ++k) {
+        const size_t o = (size_t)s->pin_idx[k] * T * d.hop;
+        memcpy(s->pin_in + o, pcm_in + o, (size_t)T * d.hop * sizeof(float));
+    }
+    {   // snapshot on the stage-2 stream (idle until stage 1 of the call is through), beside the call's first kernels; the main
+        // stream waits for it before anything writes the state (the staging kernel only touches in_tail: ordered by the event too)
+        const size_t ns = (size_t)S * d.state_size, nt = (size_t)S * d.hop;
+        if ((rc = s->snap_state.ensure(ns)) || (rc = s->snap_in.ensure(nt)) || (rc = s->snap_ola.ensure(nt))) return rc;
+        if (!s->ev_snap) HIP_TRY(hipEventCreateWithFlags(&s->ev_snap, hipEventDisableTiming));
+        hipStream_t sb = m->lanes[0].sB;
+        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((ns / 4 + 256) / 256)), dim3(256), 0, sb, s->snap_state.p, (const float*)s->state.p, ns);
+        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((nt / 4 + 256) / 256)), dim3(256), 0, sb, s->snap_in.p, (const float*)s->in_tail.p, nt);
+        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((nt / 4 + 256) / 256)), dim3(256), 0, sb, s->snap_ola.p, (const float*)s->ola_tail.p, nt);
+        HIP_TRY(hipEventRecord(s->ev_snap, sb));
+        HIP_TRY(hipStreamWaitEvent(m->stream, s->ev_snap, 0));
+    }
+    if ((rc = streams_run(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx, s->pin_err))) return rc;
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (*s->pin_err) {
         *s->pin_err = 0;
-        return check_device_err(m);
+        if ((rc = streams_recover_and_rerun(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx))) return rc;
     }
-    memcpy(pcm_out, s->pin_out, npcm * sizeof(float));
+    if (n_act == S) memcpy(pcm_out, s->pin_out, npcm * sizeof(float));
+    else for (int k = 0; k < n_act; ++k) {
+        const size_t o = (size_t)s->pin_idx[k] * T * d.hop;
+        memcpy(pcm_out + o, s->pin_out + o, (size_t)T * d.hop * sizeof(float));
+    }
     return DPDF_OK;
 }
+extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, int flags) {
+    return dpdf_streams_process_masked(s, pcm_in, n_hops, pcm_out, nullptr, flags);
+}
+// Resume a stream from saved data: `state` is the reference's flat state vector (dpdf_streams_get_state, or a state the
+// reference's own session loop produced: onnx_backend.py:52-78); in_tail / ola_tail are the StreamEnhancer's analysis and
+// overlap-add buffers (stream.py:62-72; hop floats each, dpdf_streams_get_tails).  Null pointers leave that part as it is;
+// a stream that receives an in_tail counts as primed.
+extern "C" int dpdf_streams_set_state(dpdf_streams* s, int stream, const float* state, const float* in_tail, const float* ola_tail) {
+    if (!s) return set_err(DPDF_E_INVALID, "null streams");
+    if (stream < 0 || stream >= s->S) return set_err(DPDF_E_STATE, "stream %d out of range (have %d)", stream, s->S);
+    dpdf_model* m = s->m;
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (state) HIP_TRY(hipMemcpy(s->state.p + (size_t)stream * m->d.state_size, state, (size_t)m->d.state_size * sizeof(float), hipMemcpyHostToDevice));
+    if (in_tail) { HIP_TRY(hipMemcpy(s->in_tail.p + (size_t)stream * m->d.hop, in_tail, (size_t)m->d.hop * sizeof(float), hipMemcpyHostToDevice)); s->primed[stream] = 1; }
+    if (ola_tail) HIP_TRY(hipMemcpy(s->ola_tail.p + (size_t)stream * m->d.hop, ola_tail, (size_t)m->d.hop * sizeof(float), hipMemcpyHostToDevice));
+    return DPDF_OK;
+}
+extern "C" int dpdf_streams_get_tails(dpdf_streams* s, int stream, float* in_tail, float* ola_tail) {
+    if (!s) return set_err(DPDF_E_INVALID, "null streams");
+    if (stream < 0 || stream >= s->S) return set_err(DPDF_E_STATE, "stream %d out of range (have %d)", stream, s->S);
+    dpdf_model* m = s->m;
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (in_tail) HIP_TRY(hipMemcpy(in_tail, s->in_tail.p + (size_t)stream * m->d.hop, (size_t)m->d.hop * sizeof(float), hipMemcpyDeviceToHost));
+    if (ola_tail) HIP_TRY(hipMemcpy(ola_tail, s->ola_tail.p + (size_t)stream * m->d.hop, (size_t)m->d.hop * sizeof(float), hipMemcpyDeviceToHost));
+    return DPDF_OK;
+}
+extern "C" int dpdf_streams_is_primed(dpdf_streams* s, int stream) {
+    if (!s || stream < 0 || stream >= s->S) return 0;
+    return s->primed[stream];
+}
+// prime ONE stream with its first hop (host pointer)
+extern "C" int dpdf_streams_prime_one(dpdf_streams* s, int stream, const float* pcm_hop) {
+    if (!s || !pcm_hop) return set_err(DPDF_E_INVALID, "null argument");
+    return dpdf_streams_set_state(s, stream, nullptr, pcm_hop, nullptr);
+}
+extern "C" long dpdf_recovery_count(const dpdf_model* m) { return m ? m->recoveries : 0; }
 extern "C" int dpdf_streams_get_state(dpdf_streams* s, int stream, float* state_host) {
     if (!s || !state_host) return set_err(DPDF_E_INVALID, "null argument");
     if (stream < 0 || stream >= s->S) return set_err(DPDF_E_STATE, "stream %d out of range (have %d)", stream, s->S);

@@ -404,6 +404,42 @@ __global__ void fill_state_kernel(float* state, const float* init, long S, int B
     state[idx] = init[idx % S];
 }
 
+// Streams that do not take part in a call keep their state: the active ones are packed into a dense batch before the call
+// and unpacked after it (dpdf_streams_process_masked).  k-th active stream = idx[k]; one workgroup row per (k, slice).
+//   pack:   state / in_tail / ola_tail of stream idx[k] -> slot k of the c* buffers, PCM row idx[k] of src -> row k of pcm_c
+//   unpack: the reverse for the state and the tails, row k of pcm_c -> row idx[k] of dst; the device error flag -> host_err
+struct StreamPackArgs {
+    float* state; float* in_tail; float* ola_tail;          // [S][.]
+    float* cstate; float* cin; float* cola;                 // [n_act][.]
+    const float* pcm_src; float* pcm_c;                     // pack: src [S][npcm] -> pcm_c [n_act][npcm]
+    const float* pcm_c_out; float* pcm_dst;                 // unpack: [n_act][npcm] -> dst [S][npcm]
+    const int* idx; long S_state; int hop, npcm;
+    const int* dev_err; int* host_err;
+};
+template <bool UNPACK>
+__global__ void stream_pack_kernel(StreamPackArgs a) {
+    const int k = blockIdx.x, st = a.idx[k];
+    const int t0 = blockIdx.y * blockDim.x + threadIdx.x, tn = gridDim.y * blockDim.x;
+    float* full = a.state + (size_t)st * a.S_state; float* comp = a.cstate + (size_t)k * a.S_state;
+    if (UNPACK) { for (long i = t0; i < a.S_state; i += tn) full[i] = comp[i]; }
+    else { for (long i = t0; i < a.S_state; i += tn) comp[i] = full[i]; }
+    for (int i = t0; i < a.hop; i += tn) {
+        if (UNPACK) { a.in_tail[(size_t)st * a.hop + i] = a.cin[(size_t)k * a.hop + i]; a.ola_tail[(size_t)st * a.hop + i] = a.cola[(size_t)k * a.hop + i]; }
+        else { a.cin[(size_t)k * a.hop + i] = a.in_tail[(size_t)st * a.hop + i]; a.cola[(size_t)k * a.hop + i] = a.ola_tail[(size_t)st * a.hop + i]; }
+    }
+    for (int i = t0; i < a.npcm; i += tn) {
+        if (UNPACK) a.pcm_dst[(size_t)st * a.npcm + i] = a.pcm_c_out[(size_t)k * a.npcm + i];
+        else a.pcm_c[(size_t)k * a.npcm + i] = a.pcm_src[(size_t)st * a.npcm + i];
+    }
+    if (UNPACK && a.host_err && k == 0 && t0 == 0) *a.host_err = *a.dev_err;
+}
+// dst <- src for n floats (snapshot / restore of the streaming state around a call: dpdf_streams_process)
+__global__ void copy_f4_kernel(float* dst, const float* src, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) *(float4*)(dst + i) = *(const float4*)(src + i);
+    else for (size_t j = i; j < n; ++j) dst[j] = src[j];
+}
+
 // y += x (n multiple of 4)
 __global__ void axpy_kernel(float* y, const float* x, size_t n) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;

@@ -9,11 +9,18 @@ HBM.  All complete hops of a `process()` call are handled by ONE device call.
 
 `StreamGroup` (also `StreamEnhancer.group(n)`) is the same object for n concurrent streams that advance in
 lockstep -- BASELINE config 5 (64 live StreamEnhancer states): one device call per hop for ALL streams instead of
-one launch sequence per stream."""
+one launch sequence per stream.
+
+`StreamPool` is for streams that do NOT advance in lockstep -- what the reference's objects are: independent, each fed
+whenever its caller has a chunk (stream.py:13-72).  `pool.enhancer()` hands out objects with the StreamEnhancer interface
+that share one device-resident stream set; hops that arrive within a short window (from several threads), or in one
+`pool.process_many()` call, go to the GPU as ONE masked device call (`dpdf_streams_process_masked`), and
+`save_state()` / `load_state()` move a stream between objects, pools or processes (resume = the explicit state vector)."""
 from __future__ import annotations
 
+import threading
 from pathlib import Path
-from typing import Optional, Union
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -138,6 +145,13 @@ class StreamEnhancer:
         """n concurrent streams behind one object: one device call per hop for all of them (`StreamGroup`)."""
         return StreamGroup(n_streams, model=model, onnx_path=onnx_path, verbose=verbose)
 
+    @staticmethod
+    def pool(n_slots: int, model: str = DEFAULT_MODEL, onnx_path: Optional[Union[str, Path]] = None,
+             verbose: bool = False, window_s: float = 2e-4) -> "StreamPool":
+        """Up to n_slots INDEPENDENT streams (each a StreamEnhancer-shaped object from `pool.enhancer()`) whose hops are
+        coalesced into shared device calls (`StreamPool`)."""
+        return StreamPool(n_slots, model=model, onnx_path=onnx_path, verbose=verbose, window_s=window_s)
+
     def reset(self) -> None:
         """Reset RNN state and internal buffers (reference stream.py:62-72)."""
         self._g.reset()
@@ -153,3 +167,239 @@ class StreamEnhancer:
     def flush(self) -> np.ndarray:
         """Drain the last partial window (reference stream.py:167-200)."""
         return self._g.flush().reshape(-1).astype(np.float32)
+
+
+class _Request:
+    __slots__ = ("slot", "pcm", "k", "done", "out", "err")
+
+    def __init__(self, slot: int, pcm: np.ndarray, k: int) -> None:
+        self.slot, self.pcm, self.k = slot, pcm, k
+        self.done = threading.Event()
+        self.out: Optional[np.ndarray] = None
+        self.err: Optional[BaseException] = None
+
+
+class StreamPool:
+    """Independent streams behind one device-resident stream set.
+
+    Args:
+        n_slots: how many streams the pool can hold at once.
+        model / onnx_path / verbose: as for `StreamEnhancer`.
+        window_s: how long the first `process()` caller of a round waits for other threads' hops before it issues the
+            device call for everyone queued (0: no waiting, still coalesces what is already queued).
+    """
+
+    def __init__(self, n_slots: int, model: str = DEFAULT_MODEL, onnx_path: Optional[Union[str, Path]] = None,
+                 verbose: bool = False, window_s: float = 2e-4) -> None:
+        if int(n_slots) < 1:
+            raise ValueError(f"n_slots must be positive, got {n_slots}")
+        self._n = int(n_slots)
+        resolved = resolve_model(model=model, onnx_path=onnx_path, auto_download=True, verbose=verbose)
+        import os
+        device = int(os.environ.get("DPDFNET_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self._runtime: RuntimeModel = build_runtime_model(resolved.onnx_path, resolved.info, device)
+        self._model_sr: int = resolved.info.sample_rate
+        self._win_len: int = infer_win_len(self._runtime.session, self._model_sr)
+        self._hop_size: int = self._win_len // 2
+        self._streams = self._runtime.session.open_streams(self._n)
+        self._free: List[int] = list(range(self._n - 1, -1, -1))
+        self._window = float(window_s)
+        self._lock = threading.Lock()
+        self._queue: List[_Request] = []
+        self._leader_active = False
+        self.device_calls = 0              # masked device calls issued so far (what the coalescing saves)
+
+    @property
+    def n_slots(self) -> int:
+        return self._n
+
+    def enhancer(self) -> "PooledStreamEnhancer":
+        """A new independent stream (StreamEnhancer interface) in a free slot of the pool."""
+        with self._lock:
+            if not self._free:
+                raise RuntimeError(f"all {self._n} slots of the pool are in use")
+            slot = self._free.pop()
+        self._streams.reset(slot)
+        return PooledStreamEnhancer(self, slot)
+
+    def _release(self, slot: int) -> None:
+        with self._lock:
+            self._free.append(slot)
+
+    # ------------------------------------------------------------------
+    def _execute(self, reqs: Sequence[_Request]) -> None:
+        """One or a few masked device calls for a set of requests (each: k whole hops for its slot).  Requests with the
+        same hop count share a call; different counts peel off in rounds of the smallest remaining count."""
+        hop = self._hop_size
+        done = {id(r): 0 for r in reqs}
+        outs = {id(r): np.empty(r.k * hop, dtype=np.float32) for r in reqs}
+        try:
+            while True:
+                live = [r for r in reqs if done[id(r)] < r.k]
+                if not live:
+                    break
+                n = min(r.k - done[id(r)] for r in live)
+                pcm = np.zeros((self._n, n * hop), dtype=np.float32)
+                active = np.zeros(self._n, dtype=bool)
+                for r in live:
+                    o = done[id(r)] * hop
+                    pcm[r.slot] = r.pcm[o: o + n * hop]
+                    active[r.slot] = True
+                res = self._streams.process_masked(pcm, active)
+                self.device_calls += 1
+                for r in live:
+                    o = done[id(r)] * hop
+                    outs[id(r)][o: o + n * hop] = res[r.slot]
+                    done[id(r)] += n
+            for r in reqs:
+                r.out = outs[id(r)]
+        except BaseException as exc:          # every waiter must wake up
+            for r in reqs:
+                r.err = exc
+        finally:
+            for r in reqs:
+                r.done.set()
+
+    def _run(self, slot: int, pcm: np.ndarray, k: int) -> np.ndarray:
+        """Called by a member from its own thread: queue k hops; the first caller of a round leads it."""
+        req = _Request(slot, pcm, k)
+        with self._lock:
+            self._queue.append(req)
+            lead = not self._leader_active
+            if lead:
+                self._leader_active = True
+        if lead:
+            if self._window > 0:
+                req.done.wait(self._window)          # nobody sets it yet: a plain bounded wait for followers to queue up
+            with self._lock:
+                batch, self._queue = self._queue, []
+                self._leader_active = False
+            self._execute(batch)
+        req.done.wait()
+        if req.err is not None:
+            raise req.err
+        return req.out
+
+    def process_many(self, items: Iterable[Tuple["PooledStreamEnhancer", np.ndarray]],
+                     sample_rate: Optional[int] = None) -> List[np.ndarray]:
+        """[(enhancer, chunk), ...] -> [enhanced, ...]: every member's complete hops in ONE coalesced execution
+        (chunks may have different sizes; each result is exactly what `enhancer.process(chunk)` returns)."""
+        items = list(items)
+        reqs: List[Optional[_Request]] = []
+        for enh, chunk in items:
+            if enh._pool is not self:
+                raise ValueError("enhancer belongs to another pool")
+            got = enh._stage(chunk, sample_rate)
+            reqs.append(None if got is None else _Request(enh._slot, got[0], got[1]))
+        live = [r for r in reqs if r is not None]
+        if live:
+            self._execute(live)
+        outs = []
+        for (enh, _), r in zip(items, reqs):
+            if r is None:
+                outs.append(np.zeros(0, dtype=np.float32))
+                continue
+            if r.err is not None:
+                raise r.err
+            outs.append(enh._finish(r.out))
+        return outs
+
+
+class PooledStreamEnhancer:
+    """One independent stream of a `StreamPool`: the StreamEnhancer interface (process / flush / reset, reference
+    stream.py:62-200) plus save_state / load_state."""
+
+    def __init__(self, pool: StreamPool, slot: int) -> None:
+        self._pool, self._slot = pool, slot
+        self._pending = np.zeros(0, dtype=np.float32)
+        self._primed = False
+        self._input_sr: Optional[int] = None
+        self._closed = False
+
+    def close(self) -> None:
+        """Give the slot back to the pool."""
+        if not self._closed:
+            self._closed = True
+            self._pool._release(self._slot)
+
+    def reset(self) -> None:
+        self._pool._streams.reset(self._slot)
+        self._pending = np.zeros(0, dtype=np.float32)
+        self._primed = False
+        self._input_sr = None
+
+    # ---- the host half of process(): buffering exactly as the reference (stream.py:74-115) ----
+    def _stage(self, chunk: np.ndarray, sample_rate: Optional[int]):
+        """Buffer the chunk; returns (pcm of k whole hops, k) when there is something to run, else None."""
+        p = self._pool
+        chunk = to_mono(np.asarray(chunk, dtype=np.float32))
+        if chunk.size == 0:
+            return None
+        sr_in = sample_rate if sample_rate is not None else p._model_sr
+        if self._input_sr is None:
+            self._input_sr = sr_in
+        elif self._input_sr != sr_in:
+            raise ValueError(
+                f"Sample rate changed from {self._input_sr} to {sr_in} between "
+                "process() calls.  Call reset() before processing a new stream."
+            )
+        self._pending = np.concatenate([self._pending, ensure_sample_rate(chunk, sr_in, p._model_sr)])
+        hop = p._hop_size
+        if not self._primed:
+            if self._pending.shape[0] < p._win_len:
+                return None
+            p._streams.prime_one(self._slot, self._pending[:hop])
+            self._pending = self._pending[hop:]
+            self._primed = True
+        k = self._pending.shape[0] // hop
+        if k == 0:
+            return None
+        pcm = np.ascontiguousarray(self._pending[: k * hop])
+        self._pending = self._pending[k * hop:]
+        return pcm, k
+
+    def _finish(self, enhanced_model_sr: np.ndarray) -> np.ndarray:
+        p = self._pool
+        if self._input_sr is not None and self._input_sr != p._model_sr:
+            return ensure_sample_rate(enhanced_model_sr, p._model_sr, self._input_sr)
+        return enhanced_model_sr
+
+    def process(self, chunk: np.ndarray, sample_rate: Optional[int] = None) -> np.ndarray:
+        """Enhance a chunk (reference stream.py:74-165).  Hops of other pool members queued within the pool's window
+        ride in the same device call."""
+        got = self._stage(chunk, sample_rate)
+        if got is None:
+            return np.zeros(0, dtype=np.float32)
+        return self._finish(self._pool._run(self._slot, got[0], got[1]))
+
+    def flush(self) -> np.ndarray:
+        """Drain the last partial window by zero-padding to a full frame (reference stream.py:167-200)."""
+        p = self._pool
+        remainder = (p._hop_size if self._primed else 0) + int(self._pending.shape[0])
+        if remainder == 0 or p._win_len - remainder == 0:
+            return np.zeros(0, dtype=np.float32)
+        sr_in = self._input_sr or p._model_sr
+        out = self.process(np.zeros(p._win_len - remainder, dtype=np.float32), sample_rate=p._model_sr)
+        trimmed = out[: min(p._hop_size, out.shape[0])]
+        if sr_in != p._model_sr:
+            trimmed = ensure_sample_rate(trimmed, p._model_sr, sr_in)
+        return np.ascontiguousarray(trimmed, dtype=np.float32)
+
+    # ---- resume = the explicit state vector (SURVEY.md section 5; onnx_backend.py:52-78) ----
+    def save_state(self) -> Dict[str, np.ndarray]:
+        """Everything that defines the stream: the reference-layout model state, the analysis and overlap-add buffers
+        (stream.py:62-72) and the samples not yet consumed."""
+        st = self._pool._streams
+        in_tail, ola_tail = st.get_tails(self._slot)
+        return {"state": st.get_state(self._slot), "in_tail": in_tail, "ola_tail": ola_tail, "pending": self._pending.copy(),
+                "primed": np.asarray(self._primed), "input_sr": np.asarray(-1 if self._input_sr is None else self._input_sr)}
+
+    def load_state(self, saved: Dict[str, np.ndarray]) -> None:
+        st = self._pool._streams
+        st.reset(self._slot)
+        primed = bool(np.asarray(saved["primed"]))
+        st.set_state(self._slot, saved["state"], saved["in_tail"] if primed else None, saved["ola_tail"])
+        self._pending = np.asarray(saved["pending"], dtype=np.float32).copy()
+        self._primed = primed
+        sr = int(np.asarray(saved["input_sr"]))
+        self._input_sr = None if sr < 0 else sr

@@ -98,6 +98,29 @@ int dpdf_streams_reset(dpdf_streams* s, int stream /* -1 = all */);
 int dpdf_streams_prime(dpdf_streams* s, const float* pcm_in, int flags);            /* [S,hop] */
 int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, int flags);
 int dpdf_streams_get_state(dpdf_streams* s, int stream, float* state_host);          /* S floats */
+/* The reference's StreamEnhancer objects are independent of each other (stream.py:13-72): each takes chunks whenever its
+ * caller has them.  The masked form advances only the streams with active[i] != 0 (HOST array of S bytes, also with
+ * DPDF_DEVICE_PTRS; NULL = all) by n_hops hops in ONE device call: they are packed into a dense batch, processed, unpacked.
+ * Rows of pcm_in / pcm_out keep their [S, n_hops*hop] positions; rows of inactive streams are neither read nor written,
+ * and those streams' state, analysis tail and overlap-add tail stay exactly as they were. */
+int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out,
+                                const unsigned char* active, int flags);
+/* Resume = the explicit state vector (onnx_backend.py:52-78): `state` is the reference's flat state
+ * layout (from dpdf_streams_get_state, dpdf_run_frames or the reference's own session loop); in_tail / ola_tail are the
+ * StreamEnhancer's analysis buffer and overlap-add buffer (stream.py:62-72, hop floats each).  Host pointers; a NULL part
+ * is left as it is; a stream given an in_tail counts as primed.  dpdf_streams_prime_one = set_state(stream, NULL, hop, NULL). */
+int dpdf_streams_set_state(dpdf_streams* s, int stream, const float* state, const float* in_tail, const float* ola_tail);
+int dpdf_streams_get_tails(dpdf_streams* s, int stream, float* in_tail, float* ola_tail);   /* hop floats each, NULL = skip */
+int dpdf_streams_prime_one(dpdf_streams* s, int stream, const float* pcm_hop);
+int dpdf_streams_is_primed(dpdf_streams* s, int stream);
+/* Forward progress.  The multi-workgroup GRU-256 kernels wait for their peers under ordinary launches; a wait that times
+ * out (~1 s; peers not co-resident: a GPU shared with other processes) raises a device flag.  HOST-pointer calls then
+ * recover by themselves: dpdf_enhance_batch* / dpdf_run_frames start again from the caller's (or the initial) state,
+ * dpdf_streams_process* from a copy of state and tails taken at the start of the call, with every GRU-256 recurrence on
+ * the single-workgroup scan, which has no cross-workgroup waits -- DPDF_OK, results equal to rounding; this counter says
+ * how often that happened.  DEVICE-pointer calls are asynchronous: dpdf_sync returns DPDF_E_RUNTIME, the results are
+ * invalid and in-place state is half advanced (reset or restore the streams, re-issue batch calls). */
+long dpdf_recovery_count(const dpdf_model* m);
 
 /* Wait for the model's stream.  Calls with DPDF_DEVICE_PTRS return as soon as the work is queued: dpdf_sync is where
  * their completion -- and a device-side failure (DPDF_E_RUNTIME: a GRU-256 cluster exchange that timed out) -- is

@@ -230,25 +230,151 @@ def test_ort_shim_drives_the_reference_loop(tag, be, tmp_path):
         rt.session.run(None, {rt.in_spec_name: spec_t[:, :, :-1], rt.in_state_name: state})
 
 
-# ----- device-side failure is reported, not swallowed ---------------------------------------------
-def test_device_error_flag_turns_into_runtime_error(be):
-    """A GRU-256 cluster exchange that times out raises a device flag (csrc/gru_scan.h); every synchronisation point must
-    turn it into DPDF_E_RUNTIME instead of returning corrupted audio.  The flag is raised through the test hook."""
+# ----- device-side failure: host-pointer calls recover by themselves, asynchronous ones report it -----
+def test_device_error_flag_recovery_and_reporting(be):
+    """A GRU-256 exchange that times out raises a device flag (csrc/gru_scan.h).  Host-pointer calls must come back with
+    DPDF_OK and ORACLE-EQUAL results: the call is restored to its pre-call state and re-run on the single-workgroup scan
+    (dpdf_recovery_count goes up); asynchronous device-pointer calls report DPDF_E_RUNTIME at dpdf_sync.  The flag is raised
+    through the test hook before the call, i.e. the first execution advances the in-place state and is then thrown away --
+    a recovery that did not restore the state would double-advance it."""
+    from oracle import oracle as orc
     sr, nb, blob = _synthetic(be, "dpdfnet2", 5)
     m = be.HipModel(sr, nb, blob, 0)
     wav = synth_clip(4000, sr, 1)[None]
     good = m.enhance_batch(wav)
+    assert m.recovery_count == 0
+    m.debug_raise_device_error()
+    again = m.enhance_batch(wav)                                          # no exception
+    assert m.recovery_count == 1
+    assert rms(again - good) < 1e-6 and rms(again[0] - orc.Oracle(sr, nb, blob).enhance(wav[0])) < WAVE_TOL
+    np.testing.assert_array_equal(m.enhance_batch(wav), good)            # and the engine is back on its normal kernels
     m.debug_raise_device_error()
     with pytest.raises(RuntimeError, match="GRU-256 cluster exchange timed out"):
-        m.enhance_batch(wav)
-    np.testing.assert_array_equal(m.enhance_batch(wav), good)            # the flag was cleared; the engine is usable again
-    m.debug_raise_device_error()
-    with pytest.raises(RuntimeError):
         m.sync()
     m.sync()
-    st = m.open_streams(2)
-    st.prime(np.zeros((2, m.hop), np.float32))
-    m.debug_raise_device_error()
-    with pytest.raises(RuntimeError):
-        st.process(np.zeros((2, m.hop), np.float32))
-    st.close(); m.close()
+    # streams: in-place state.  Two identical stream sets, one of them hit by the flag in the middle
+    hop = m.hop
+    pcm = np.stack([synth_clip(9 * hop, sr, 70 + i) for i in range(3)])
+    a, b = m.open_streams(3), m.open_streams(3)
+    for st in (a, b):
+        st.prime(pcm[:, :hop])
+    outs_a, outs_b = [], []
+    for j in range(1, 9):
+        blk = pcm[:, j * hop:(j + 1) * hop]
+        outs_a.append(a.process(blk))
+        if j in (3, 6):
+            m.debug_raise_device_error()
+        outs_b.append(b.process(blk))
+    assert m.recovery_count == 3
+    assert rms(np.concatenate(outs_a, 1) - np.concatenate(outs_b, 1)) < 1e-6
+    for i in range(3):
+        assert np.abs(a.get_state(i) - b.get_state(i)).max() < 1e-5
+    a.close(); b.close(); m.close()
+
+
+# ----- independent streams: masked calls, resume from a state vector, the pool ----------------------------------------
+def test_masked_process_and_state_round_trip(be):
+    """dpdf_streams_process_masked: only the active streams advance, bit-identically to an unmasked set that is fed the
+    same hops; set_state / get_state / get_tails: save -> reset -> restore continues bit-exactly."""
+    sr, nb, blob = _synthetic(be, "dpdfnet2", 11)
+    m = be.HipModel(sr, nb, blob, 0)
+    hop, S = m.hop, 5
+    pcm = np.stack([synth_clip(12 * hop, sr, 300 + i) for i in range(S)])
+    ref = m.open_streams(S); msk = m.open_streams(S)
+    ref.prime(pcm[:, :hop])
+    for i in range(S):
+        assert not msk.is_primed(i)
+        msk.prime_one(i, pcm[i, :hop])
+        assert msk.is_primed(i)
+    want = np.concatenate([ref.process(pcm[:, j * hop:(j + 1) * hop]) for j in range(1, 11)], axis=1)
+    # the masked set gets the same hops in a staggered order: stream i lags by (i % 3) rounds
+    got = np.zeros_like(want)
+    nxt = [1] * S
+    rnd = 0
+    while min(nxt) <= 10:
+        active = np.array([(rnd >= i % 3) and nxt[i] <= 10 and (rnd + i) % 2 == 0 for i in range(S)])
+        rnd += 1
+        if not active.any():
+            continue
+        blk = np.zeros((S, hop), np.float32)
+        for i in range(S):
+            if active[i]:
+                blk[i] = pcm[i, nxt[i] * hop:(nxt[i] + 1) * hop]
+        before = [msk.get_state(i) for i in range(S) if not active[i]]
+        out = msk.process_masked(blk, active)
+        after = [msk.get_state(i) for i in range(S) if not active[i]]
+        for x, y in zip(before, after):
+            np.testing.assert_array_equal(x, y)                         # inactive streams: state untouched
+        for i in range(S):
+            if active[i]:
+                got[i, (nxt[i] - 1) * hop: nxt[i] * hop] = out[i]; nxt[i] += 1
+            else:
+                assert np.all(out[i] == 0.0)
+    assert rms(got - want) < 1e-6
+    # save -> reset -> restore (into a different slot of a different stream set)
+    st, (tin, tola) = ref.get_state(2), ref.get_tails(2)
+    cont = ref.process(pcm[:, 11 * hop:12 * hop])[2]
+    other = m.open_streams(2)
+    other.set_state(1, st, tin, tola)
+    other.prime_one(0, np.zeros(hop, np.float32))
+    np.testing.assert_array_equal(other.process_masked(np.stack([np.zeros(hop, np.float32), pcm[2, 11 * hop:12 * hop]]), [False, True])[1], cont)
+    with pytest.raises(ValueError, match="not primed"):
+        m.open_streams(2).process_masked(np.zeros((2, hop), np.float32), [True, False])      # not primed
+    ref.close(); msk.close(); other.close(); m.close()
+
+
+@pytest.mark.parametrize("tag", ["16k_nb2", "48k_nb8"])
+def test_pool_of_independent_enhancers_matches_reference_goldens(tag, be, tmp_path, monkeypatch):
+    """64 (16 for the 48 kHz model) independent StreamEnhancer-shaped objects of one StreamPool, fed at staggered chunk sizes:
+    each equals the reference StreamEnhancer goldens; the coalesced execution costs at most 1.3 x the lock-step
+    StreamGroup on the same audio."""
+    import time
+    from dpdfnet_amd import runtime, stream, weights
+    from dpdfnet_amd.models import ModelInfo, ResolvedModel
+    runtime.clear_cache()
+    g, meta = load_golden(tag)
+    sr = meta["sample_rate"]
+    wfile = weights.save_blob(tmp_path / "w.npz", golden_blob(meta))
+    info = ModelInfo(name=f"test_{tag}", sample_rate=sr, frame_ms=20.0, description="", onnx_filename="w.onnx",
+                     dprnn_num_blocks=meta["nb"])
+    monkeypatch.setattr(stream, "resolve_model", lambda **_k: ResolvedModel(info=info, onnx_path=wfile))
+    G = np.load(GOLDEN / f"stream_{tag}.npz")
+    wav = G["wav"]
+    hop = 160 if sr == 16000 else 480
+    N = 64 if sr == 16000 else 16
+    sizes = [171, hop, len(wav)]
+    pool = stream.StreamEnhancer.pool(N)
+    members = [pool.enhancer() for _ in range(N)]
+    chunk = [sizes[i % 3] for i in range(N)]
+    got = [[] for _ in range(N)]
+    pos = [0] * N
+    t0 = time.perf_counter()
+    while any(p < len(wav) for p in pos):
+        items = [(i, wav[pos[i]: pos[i] + chunk[i]]) for i in range(N) if pos[i] < len(wav)]
+        outs = pool.process_many([(members[i], c) for i, c in items])
+        for (i, c), o in zip(items, outs):
+            got[i].append(o); pos[i] += chunk[i]
+    t_pool = time.perf_counter() - t0
+    for i in range(N):
+        got[i].append(members[i].flush())
+        ref = G[f"real_chunk{chunk[i]}"]
+        out = np.concatenate(got[i])
+        assert out.shape == ref.shape and rms(out - ref) < WAVE_TOL, (i, chunk[i], rms(out - ref))
+    # cost against the lock-step group on the same audio (hop-sized chunks for everyone)
+    grp = stream.StreamEnhancer.group(N)
+    rows = np.stack([wav] * N)
+    def timed(fn):
+        t = time.perf_counter(); fn(); return time.perf_counter() - t
+    t_grp = min(timed(lambda: (grp.reset(), [grp.process(rows[:, i:i + hop]) for i in range(0, len(wav), hop)])) for _ in range(2))
+    def run_pool_hopwise():
+        for mm in members:
+            mm.reset()
+        for i in range(0, len(wav), hop):
+            pool.process_many([(mm, wav[i:i + hop]) for mm in members])
+    t_hop = min(timed(run_pool_hopwise) for _ in range(2))
+    print(f"[pool {tag}] staggered {1e3 * t_pool:.1f} ms; hop-wise pool {1e3 * t_hop:.1f} ms vs group {1e3 * t_grp:.1f} ms")
+    # device work within 1.3 x of the lock-step group; on top of it the pool runs the reference's per-object host buffering
+    # (stream.py:74-115) once per member and hop in Python, ~5 us each, which the vectorised group does once per hop
+    rounds = -(-len(wav) // hop)
+    assert t_hop <= 1.3 * t_grp + N * rounds * 8e-6, (t_hop, t_grp)
+    runtime.clear_cache()

@@ -349,3 +349,90 @@ def test_evalkit_matches_reference_known_answers():
         np.testing.assert_array_equal(b_al, G[f"xc{i}_b_al"])
         a2, b2, lag2 = evalkit.align_by_xcorr_trim(b, clean)
         assert lag2 == int(G[f"xc{i}_rev_lag"]) and len(a2) == len(b2) == int(G[f"xc{i}_rev_len"])
+
+
+# ----- StreamPool: independent streams, coalesced device calls (host logic on the passthrough double) -----------------
+def _pool(monkeypatch, n, win=320, zero=False, window_s=0.0):
+    _patch(monkeypatch, win=win, zero=zero)
+    from dpdfnet_amd.stream import StreamEnhancer
+    return StreamEnhancer.pool(n, model="dpdfnet2", window_s=window_s)
+
+
+def test_pool_members_equal_independent_stream_enhancers(monkeypatch):
+    """Every pool member returns exactly what a StreamEnhancer of its own returns, for staggered chunk sizes, whether the
+    hops arrive through process_many (one coalesced execution) or member by member."""
+    from dpdfnet_amd import StreamEnhancer
+    WIN = 320
+    pool = _pool(monkeypatch, 4, win=WIN)
+    rng = np.random.default_rng(5)
+    sigs = [(rng.standard_normal(4000) * 0.3).astype(np.float32) for _ in range(4)]
+    chunk = [171, 160, 333, 1000]
+    members = [pool.enhancer() for _ in range(4)]
+    got = [[] for _ in range(4)]
+    pos = [0] * 4
+    while any(pos[i] < 4000 for i in range(4)):
+        items = []
+        for i in range(4):
+            if pos[i] < 4000:
+                items.append((i, sigs[i][pos[i]: pos[i] + chunk[i]])); pos[i] += chunk[i]
+        outs = pool.process_many([(members[i], c) for i, c in items], sample_rate=16000)
+        for (i, _), o in zip(items, outs):
+            got[i].append(o)
+    for i in range(4):
+        got[i].append(members[i].flush())
+        ref_e = StreamEnhancer(model="dpdfnet2")
+        ref = np.concatenate([ref_e.process(sigs[i][p: p + chunk[i]], sample_rate=16000) for p in range(0, 4000, chunk[i])] + [ref_e.flush()])
+        np.testing.assert_array_equal(np.concatenate(got[i]), ref)
+    # equal chunk sizes -> exactly one device call per round
+    pool2 = _pool(monkeypatch, 3, win=WIN)
+    ms = [pool2.enhancer() for _ in range(3)]
+    pool2.process_many([(m, np.zeros(WIN, np.float32)) for m in ms])
+    before = pool2.device_calls
+    pool2.process_many([(m, np.zeros(160 * 3, np.float32)) for m in ms])
+    assert pool2.device_calls == before + 1
+    with pytest.raises(RuntimeError, match="slots"):
+        pool2.enhancer()
+    ms[0].close()
+    pool2.enhancer()
+
+
+def test_pool_threads_share_device_calls_and_state_round_trip(monkeypatch):
+    """Members driven from their own threads: hops that arrive within the window ride in one device call; a stream saved,
+    reset and restored (also into another member) continues exactly."""
+    import threading
+    WIN, HOP = 320, 160
+    pool = _pool(monkeypatch, 8, win=WIN, window_s=0.05)
+    members = [pool.enhancer() for _ in range(8)]
+    rng = np.random.default_rng(9)
+    sigs = [(rng.standard_normal(WIN + 4 * HOP) * 0.3).astype(np.float32) for _ in range(8)]
+    outs = [None] * 8
+    for i in range(8):
+        members[i].process(sigs[i][:WIN])            # prime + first hop, one after the other
+    base = pool.device_calls
+    bar = threading.Barrier(8)
+
+    def work(i):
+        bar.wait()
+        outs[i] = members[i].process(sigs[i][WIN:])
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert all(o is not None and o.shape == (4 * HOP,) for o in outs)
+    assert pool.device_calls - base < 8                # coalesced (normally 1 or 2 calls for the eight threads)
+    from dpdfnet_amd import StreamEnhancer
+    for i in (0, 7):
+        e = StreamEnhancer(model="dpdfnet2")
+        e.process(sigs[i][:WIN])
+        np.testing.assert_array_equal(outs[i], e.process(sigs[i][WIN:]))
+    # save -> reset -> restore, and restore into ANOTHER member
+    a, b = members[0], members[1]
+    a.process(np.ones(70, np.float32) * 0.1)           # leaves a partial hop pending
+    saved = a.save_state()
+    nxt = (rng.standard_normal(500) * 0.2).astype(np.float32)
+    want = a.process(nxt)
+    a.reset()
+    a.load_state(saved)
+    np.testing.assert_array_equal(a.process(nxt), want)
+    b.load_state(saved)
+    np.testing.assert_array_equal(b.process(nxt), want)

@@ -66,11 +66,44 @@ class PassthroughStreams:
         self.reset(-1)
 
     def reset(self, _stream: int = -1):
+        if _stream is not None and _stream >= 0 and hasattr(self, "tail"):
+            self.reset_one(_stream)
+            return
         self.tail = np.zeros((self.n, self.hop), dtype=np.float32)
         self.ola = np.zeros((self.n, self.hop), dtype=np.float32)
 
     def prime(self, pcm):
         self.tail = np.asarray(pcm, dtype=np.float32).reshape(self.n, self.hop).copy()
+
+    def reset_one(self, i: int):
+        self.tail[i] = 0; self.ola[i] = 0
+
+    def prime_one(self, i: int, pcm):
+        self.tail[i] = np.asarray(pcm, dtype=np.float32).reshape(self.hop)
+
+    def get_state(self, i: int):
+        return np.zeros(1, dtype=np.float32)
+
+    def get_tails(self, i: int):
+        return self.tail[i].copy(), self.ola[i].copy()
+
+    def set_state(self, i: int, state=None, in_tail=None, ola_tail=None):
+        if in_tail is not None:
+            self.tail[i] = np.asarray(in_tail, dtype=np.float32)
+        if ola_tail is not None:
+            self.ola[i] = np.asarray(ola_tail, dtype=np.float32)
+
+    def process_masked(self, pcm, active):
+        """Only the streams with active[i] advance (engine: dpdf_streams_process_masked)."""
+        pcm = np.asarray(pcm, dtype=np.float32).reshape(self.n, -1)
+        active = np.asarray(active).astype(bool)
+        tail, ola = self.tail.copy(), self.ola.copy()
+        out = self.process(pcm)
+        for i in range(self.n):
+            if not active[i]:
+                self.tail[i], self.ola[i] = tail[i], ola[i]
+                out[i] = 0
+        return out
 
     def process(self, pcm):
         pcm = np.asarray(pcm, dtype=np.float32).reshape(self.n, -1)
