@@ -100,6 +100,42 @@ def synth_blob(entries: List[ManifestEntry], seed: int) -> np.ndarray:
     return blob
 
 
+STRESS_KINDS = ("hot", "stiff")
+
+
+def stress_blob(entries: List[ManifestEntry], seed: int, kind: str) -> np.ndarray:
+    """Seeded synthetic weights pushed into the corners a trained checkpoint can sit in (the plain `synth_blob` keeps every
+    recurrence contractive and every normalisation near unit scale):
+      "hot":   every GRU matrix and bias, fc_intra and fc_inter x 3 -- gates deep in saturation (sigmoid / tanh tails, where
+               the engine's exp2 / rcp forms and folded scales could part from the reference's);
+      "stiff": every third BatchNorm channel gets a running_var of 1e-4 .. 5e-4 (gamma rescaled so that the layer's output
+               scale stays where it was: it is the 1 / sqrt(var + eps) fold at var ~ eps that is exercised, not an
+               exploding network), LayerNorm gains x 5.
+    Used by tests/golden/make_golden.py (reference side) and by the parity tests."""
+    if kind not in STRESS_KINDS:
+        raise ValueError(f"unknown stress kind '{kind}'")
+    blob = synth_blob(entries, seed)
+    by_name = {e.name: e for e in entries}
+    for e in entries:
+        v = blob[e.offset:e.offset + e.count]
+        if kind == "hot":
+            if re.search(r"weight_ih|weight_hh|bias_ih|bias_hh|fc_intra\.|fc_inter\.", e.name):
+                v *= np.float32(3.0)
+        else:
+            if e.name.endswith(".running_var"):
+                idx = np.arange(e.count)
+                sel = idx % 3 == 0
+                new = (1e-4 * (1 + idx % 5)).astype(np.float32)
+                gam = by_name[e.name[: -len("running_var")] + "weight"]
+                g = blob[gam.offset:gam.offset + gam.count]
+                ratio = np.sqrt((new.astype(np.float64) + 1e-5) / (v.astype(np.float64) + 1e-5)).astype(np.float32)
+                g[sel] *= ratio[sel]
+                v[sel] = new[sel]
+            elif re.search(r"ln_(intra|inter)\.weight$", e.name):
+                v *= np.float32(5.0)
+    return blob
+
+
 # ----------------------------------------------------------------------------------------------
 # state_dict <-> blob
 # ----------------------------------------------------------------------------------------------
@@ -134,8 +170,12 @@ def pack_state_dict(entries: List[ManifestEntry], state_dict: Mapping[str, objec
             G = e.shape[0]
             if f"{prefix}.layers.0.weight" in sd:
                 arr = np.stack([_to_np(sd[f"{prefix}.layers.{g}.weight"]) for g in range(G)], axis=0)
-            elif e.name in sd:                       # einsum storage [G, Ig, Og]
-                arr = np.transpose(_to_np(sd[e.name]), (0, 2, 1))
+            elif e.name in sd:                       # einsum storage [G, Ig, Og] (reference onnx_model/layers.py:976-1018, 1053-1080)
+                arr = _to_np(sd[e.name])
+                if arr.ndim != 3 or (arr.shape[0], arr.shape[2], arr.shape[1]) != e.shape:
+                    raise ValueError(f"tensor {e.name}: expected {e.shape} or its einsum form "
+                                     f"{(e.shape[0], e.shape[2], e.shape[1])}, got {arr.shape}")
+                arr = np.transpose(arr, (0, 2, 1))
             else:
                 raise KeyError(f"checkpoint lacks grouped-linear weight for {prefix}")
         elif e.name.endswith(".bias") and f"{e.name[:-5]}.layers.0.bias" in sd:
@@ -148,8 +188,11 @@ def pack_state_dict(entries: List[ManifestEntry], state_dict: Mapping[str, objec
             arr = _to_np(sd[e.name])
         else:
             raise KeyError(f"checkpoint lacks tensor {e.name}")
-        if int(arr.size) != e.count:
-            raise ValueError(f"tensor {e.name}: expected {e.shape}, got {arr.shape}")
+        if tuple(arr.shape) != e.shape:
+            # the only reshape accepted is PyTorch's storage of the same tensor with unit axes dropped / added
+            squeeze = lambda shp: tuple(d for d in shp if d != 1)
+            if int(arr.size) != e.count or squeeze(tuple(arr.shape)) != squeeze(e.shape):
+                raise ValueError(f"tensor {e.name}: expected {e.shape}, got {arr.shape}")
         blob[e.offset:e.offset + e.count] = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
     return blob
 

@@ -123,13 +123,15 @@ def run_reference_frames(model, spec_unnorm: np.ndarray, probe_frames=PROBE_FRAM
     return dict(spec_e=out, state_out=st.numpy().copy(), init_state=init_state, **probes)
 
 
-def make_model_fixture(tag: str, sr: int, nb: int, seconds: float, seed: int, attn_dbs=(0.0, 12.0)):
+def make_model_fixture(tag: str, sr: int, nb: int, seconds: float, seed: int, attn_dbs=(0.0, 12.0), stress: str = ""):
+    """stress: "" = the plain seeded weights; "hot" / "stiff" = dpdfnet_amd.weights.stress_blob (saturating GRU gates;
+    BatchNorm running_var ~ eps and LayerNorm gains x 5) -- weight-robustness goldens."""
     import torch
     from oracle import oracle as orc
-    from dpdfnet_amd.weights import parse_manifest_text, synth_blob
+    from dpdfnet_amd.weights import parse_manifest_text, synth_blob, stress_blob
 
     entries = parse_manifest_text(orc.manifest_text(sr, nb))
-    blob = synth_blob(entries, seed)
+    blob = stress_blob(entries, seed, stress) if stress else synth_blob(entries, seed)
     model = build_reference_model(sr, nb, blob, entries)
     n = int(seconds * sr)
     wav = synth_clip(n, sr, seed + 1)
@@ -169,6 +171,8 @@ def make_model_fixture(tag: str, sr: int, nb: int, seconds: float, seed: int, at
     meta = dict(tag=tag, sample_rate=sr, nb=nb, seed=seed, n=n, T=int(spec.shape[0]),
                 state_size=int(model.state_size()), n_weights=int(blob.size),
                 probe_frames=list(PROBE_FRAMES))
+    if stress:
+        meta["stress"] = stress
     fix["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(OUT / f"model_{tag}.npz", **fix)
     print(f"[golden] model_{tag}.npz  T={spec.shape[0]} S={model.state_size()} "
@@ -335,6 +339,39 @@ def make_checkpoint_keys_fixture():
     (OUT / "checkpoint_keys.json").write_text(json.dumps(out, indent=0))
 
 
+def make_einsum_fixture():
+    """N1: the grouped linears of a checkpoint in the reference's EINSUM storage.  Our seeded weights are loaded into the
+    reference's streaming module, the module is converted by the reference's own convert_grouped_linear_to_einsum
+    (onnx_model/layers.py:1053-1080) and the converted module's state_dict entries of every grouped linear are recorded
+    ([G, Ig, Og] weights + merged biases: data only).  tests/test_checkpoint_keys.py feeds them to pack_state_dict and
+    expects the original blob back, and checks that the converted module still computes the same frame."""
+    import torch
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import parse_manifest_text, synth_blob
+    from onnx_model.layers import convert_grouped_linear_to_einsum
+    out = {}
+    for tag, sr, nb in (("16k", 16000, 0), ("48k", 48000, 1)):
+        entries = parse_manifest_text(orc.manifest_text(sr, nb))
+        blob = synth_blob(entries, SEED + 700)
+        model = build_reference_model(sr, nb, blob, entries)
+        before = {k for k in model.state_dict()}
+        spec = (np.random.default_rng(SEED + 701).standard_normal((1, 1, model.stft.win_len // 2 + 1, 2)) * 3.0).astype(np.float32)
+        with torch.no_grad():
+            y0, _ = model(torch.from_numpy(spec), model.initial_state(dtype=torch.float32))
+        convert_grouped_linear_to_einsum(model)
+        with torch.no_grad():
+            y1, _ = model(torch.from_numpy(spec), model.initial_state(dtype=torch.float32))
+        assert float((y0 - y1).abs().max()) < 1e-5
+        sd = model.state_dict()
+        new = [k for k in sd if k not in before]
+        assert new and all(sd[k].dim() in (1, 3) for k in new), new
+        for k in new:
+            out[f"{tag}:{k}"] = sd[k].numpy().copy()
+        out[f"{tag}:meta_json"] = np.frombuffer(json.dumps(dict(sample_rate=sr, nb=nb, seed=SEED + 700, keys=new)).encode(), dtype=np.uint8)
+        print(f"[golden] einsum {tag}: {len(new)} converted tensors, e.g. {new[0]} {tuple(sd[new[0]].shape)}")
+    np.savez_compressed(OUT / "einsum_checkpoint.npz", **out)
+
+
 def make_eval_fixture():
     """N4: known answers of the reference's SI-SNR and cross-correlation alignment (pesq_stoi_sisnr_calc.py:16-27, 101-146)."""
     for name in ("pystoi", "pystoi.stoi", "pesq", "pandas"):
@@ -371,6 +408,14 @@ def make_eval_fixture():
     print("[golden] evalkit.npz", {k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items() if k.startswith(("sisnr", "xc0"))})
 
 
+def make_stress_fixtures():
+    """Weight-robustness goldens (round-3 review item 5): the same probes and waveforms on weights in the corners."""
+    make_model_fixture("16k_nb2_hot", 16000, 2, 0.5, SEED + 202, stress="hot")
+    make_model_fixture("16k_nb2_stiff", 16000, 2, 0.5, SEED + 203, stress="stiff")
+    make_model_fixture("48k_nb1_hot", 48000, 1, 0.6, SEED + 248, stress="hot")
+    make_model_fixture("48k_nb1_stiff", 48000, 1, 0.6, SEED + 249, stress="stiff")
+
+
 def main():
     assert REF.is_dir(), "reference checkout not mounted; goldens can only be regenerated in the build container"
     _stub_modules()
@@ -379,6 +424,10 @@ def main():
     import torch
     torch.set_num_threads(1)
     torch.manual_seed(0)
+    if "--stress-only" in sys.argv:          # the round-3 additions alone (the other fixtures regenerate bit-for-bit anyway)
+        make_stress_fixtures()
+        make_einsum_fixture()
+        return
 
     make_constants_fixture()
     make_host_dsp_fixture()
@@ -395,6 +444,8 @@ def main():
     m488, _, _ = make_model_fixture("48k_nb8", 48000, 8, 0.6, SEED + 152)   # dpdfnet8_48khz_hr (BASELINE config 5)
     make_stream_fixture(m488, 48000, "48k_nb8")
     make_checkpoint_keys_fixture()
+    make_stress_fixtures()
+    make_einsum_fixture()
 
 
 if __name__ == "__main__":

@@ -91,3 +91,35 @@ def test_offline_pth_through_hip_matches_reference_waveform(tag, tmp_path):
         assert rms(out - g["enhanced"]) < 2e-6
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("tag", ["16k", "48k"])
+def test_reference_einsum_conversion_packs_to_the_same_blob(tag):
+    """Grouped linears in the reference's EINSUM storage: tests/golden/einsum_checkpoint.npz holds the tensors the
+    reference's own convert_grouped_linear_to_einsum (onnx_model/layers.py:1053-1080) produced from our seeded weights
+    loaded into its streaming module.  pack_state_dict must give the original blob back -- and must check SHAPES: a tensor
+    of the right size in the wrong layout is an error, not a silent reinterpretation."""
+    from dpdfnet_amd import backend, weights
+    E = np.load(GOLDEN / "einsum_checkpoint.npz")
+    meta = json.loads(bytes(E[f"{tag}:meta_json"]).decode())
+    ents = backend.manifest(meta["sample_rate"], meta["nb"])
+    blob = weights.synth_blob(ents, meta["seed"])
+    sd = {k: v for k, v in weights.unpack_to_streaming_state_dict(ents, blob).items() if ".layers." not in k}
+    n3 = 0
+    for k in meta["keys"]:
+        sd[k] = E[f"{tag}:{k}"]
+        if sd[k].ndim == 3:
+            e = next(e for e in ents if e.name == k)
+            assert sd[k].shape == (e.shape[0], e.shape[2], e.shape[1])        # [G, Ig, Og]: the transpose of the manifest's layout
+            n3 += 1
+    assert n3 == sum(1 for e in ents if len(e.shape) == 3)
+    np.testing.assert_array_equal(weights.pack_state_dict(ents, sd), blob)
+    # shape, not size: the same einsum tensor flattened, or with Ig and Og regrouped, is refused
+    k3 = next(k for k in meta["keys"] if sd[k].ndim == 3)
+    bad = dict(sd); bad[k3] = sd[k3].reshape(sd[k3].shape[0], -1, 2 * sd[k3].shape[2])
+    with pytest.raises(ValueError, match="expected"):
+        weights.pack_state_dict(ents, bad)
+    k2 = next(e.name for e in ents if len(e.shape) == 2)
+    bad = dict(sd); bad[k2] = np.ascontiguousarray(sd[k2].T) if sd[k2].shape[0] != sd[k2].shape[1] else sd[k2].reshape(-1)
+    with pytest.raises(ValueError, match="expected"):
+        weights.pack_state_dict(ents, bad)

