@@ -8,9 +8,32 @@ import os as _os
 from typing import TYPE_CHECKING
 
 # The engine drives four HIP streams per handle concurrently; HIP's default of four hardware queues per process makes them
-# share queues (and serialise) as soon as anything else owns a stream.  Must be set before the HIP runtime initialises;
-# an application that sets it itself wins (csrc/dpdf_model.hip: dpdf_default_hw_queues).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# share queues (and serialise) as soon as anything else owns a stream: one 10 s clip 11.4 ms alone, 16.0 ms beside a second
+# handle.  The variable is read once, when the HIP runtime initialises, so importing this package sets a default of 8 --
+# unless the application chose a value itself, or opts out with DPDFNET_NO_HW_QUEUE_DEFAULT=1.  If HIP is already up (torch
+# touched the GPU first) the default cannot take effect any more: that is said once, instead of silently differing.
+def _default_hw_queues() -> None:
+    if _os.environ.get("DPDFNET_NO_HW_QUEUE_DEFAULT", "") not in ("", "0"):
+        return
+    if "GPU_MAX_HW_QUEUES" in _os.environ:
+        return
+    import sys as _sys
+    torch = _sys.modules.get("torch")
+    try:
+        hip_up = bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        hip_up = False
+    if hip_up:
+        import warnings
+        warnings.warn("dpdfnet_amd: the HIP runtime was initialised before this import, GPU_MAX_HW_QUEUES stays at its default "
+                      "(4): the engine's four streams may share hardware queues with other stream owners (up to ~40 % longer "
+                      "small-batch calls).  Set GPU_MAX_HW_QUEUES=8 in the environment, or import dpdfnet_amd first.",
+                      RuntimeWarning, stacklevel=3)
+        return
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
+
+_default_hw_queues()
 
 __all__ = [
     "enhance",

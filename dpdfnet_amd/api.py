@@ -81,11 +81,40 @@ def _enhance_with_runtime(
         progress_callback(0, total_frames)
     if wav_model.shape[0] == 0:
         return waveform.copy()
-    enhanced_model_sr = runtime.session.enhance_batch(wav_model[None, :], attn)[0]
-    if progress_callback is not None:
-        # the GPU path has no per-frame host loop; keep the (done,total) protocol of api.py:94-104
-        for t in range(total_frames):
-            progress_callback(t + 1, total_frames)
+    if progress_callback is None or not hasattr(runtime.session, "progress"):
+        enhanced_model_sr = runtime.session.enhance_batch(wav_model[None, :], attn)[0]
+        if progress_callback is not None:
+            for t in range(total_frames):
+                progress_callback(t + 1, total_frames)
+    else:
+        # The (done, total) protocol of api.py:94-104 with REAL progress: the engine call runs on a worker thread (it releases
+        # the GIL) and publishes the frames whose output is complete, once per time chunk; this thread polls that figure and
+        # reports every finished frame, in order, on the caller's thread.
+        import threading
+        import time
+        box: Dict[str, Any] = {}
+
+        def _call() -> None:
+            try:
+                box["out"] = runtime.session.enhance_batch(wav_model[None, :], attn)[0]
+            except Exception as exc:                       # re-raised below, on the caller's thread
+                box["err"] = exc
+
+        th = threading.Thread(target=_call, name="dpdfnet-enhance")
+        th.start()
+        reported = 0
+        while th.is_alive():
+            th.join(0.002)
+            done = min(int(runtime.session.progress()), total_frames)
+            while reported < done:
+                reported += 1
+                progress_callback(reported, total_frames)
+        if "err" in box:
+            raise box["err"]
+        while reported < total_frames:
+            reported += 1
+            progress_callback(reported, total_frames)
+        enhanced_model_sr = box["out"]
     enhanced = ensure_sample_rate(enhanced_model_sr, model_sample_rate, sr_in)
     return fit_length(enhanced, waveform.shape[0]).astype(np.float32, copy=False)
 
@@ -151,7 +180,9 @@ def _enhance_model_rate_clips(runtimes: list, model_clips: List[np.ndarray], att
             lo, hi = shard_range(len(bucket), nd, k)
             if hi > lo:
                 work[k].append(bucket[lo:hi])
-    errors: List[BaseException] = []
+    errors: List[Exception] = []
+    import threading
+    done_lock = threading.Lock()          # on_done (file writes, the caller's file_callback) runs on the workers: one at a time
 
     def _worker(k: int) -> None:
         try:
@@ -160,14 +191,14 @@ def _enhance_model_rate_clips(runtimes: list, model_clips: List[np.ndarray], att
                 for i, r in zip(idxs, res):
                     out[i] = r
                     if on_done is not None:
-                        on_done(i, r)
-        except BaseException as exc:  # surfaced on the calling thread
+                        with done_lock:
+                            on_done(i, r)
+        except Exception as exc:  # surfaced on the calling thread (KeyboardInterrupt / SystemExit are not swallowed)
             errors.append(exc)
 
     if nd == 1:
         _worker(0)
     else:
-        import threading
         ts = [threading.Thread(target=_worker, args=(k,), name=f"dpdfnet-gpu{runtimes[k].device}") for k in range(nd) if work[k]]
         for t in ts:
             t.start()
@@ -199,14 +230,15 @@ def enhance_batch(
     resolved = resolve_model(model=model, onnx_path=onnx_path, auto_download=True, verbose=verbose)
     runtimes = _runtimes_for(resolved, devices)
     msr, sr_in = resolved.info.sample_rate, int(sample_rate)
-    model_clips = [ensure_sample_rate(c, sr_in, msr) for c in clips]
+    dev0 = runtimes[0].device                      # resampling runs on a GPU the call was given, not on DPDFNET_DEVICE
+    model_clips = [ensure_sample_rate(c, sr_in, msr, dev0) for c in clips]
     res = _enhance_model_rate_clips(runtimes, model_clips, attn)
     out: List[np.ndarray] = []
     for c, r in zip(clips, res):
         if r is None:
             out.append(c.copy())
         else:
-            out.append(fit_length(ensure_sample_rate(r, msr, sr_in), c.shape[0]).astype(np.float32, copy=False))
+            out.append(fit_length(ensure_sample_rate(r, msr, sr_in, dev0), c.shape[0]).astype(np.float32, copy=False))
     return out
 
 
@@ -360,19 +392,19 @@ def enhance_dir(
             try:
                 audio, sr = _read_audio(p)
                 mono = to_mono(audio)
-                mc = ensure_sample_rate(mono, int(sr), msr)
+                mc = ensure_sample_rate(mono, int(sr), msr, runtimes[0].device)
                 kept.append(p); monos.append(mono); rates.append(int(sr)); model_clips.append(mc)
             except Exception as exc:
                 errors.append((p, exc))
 
         def _emit(i: int, enhanced_model_sr: np.ndarray, kept=kept, monos=monos, rates=rates) -> None:
             p, mono, sr = kept[i], monos[i], rates[i]
-            y = fit_length(ensure_sample_rate(enhanced_model_sr, msr, sr), mono.shape[0])
+            y = fit_length(ensure_sample_rate(enhanced_model_sr, msr, sr, runtimes[0].device), mono.shape[0])
             dst = out_dir / f"{p.stem}_enhanced.wav"
             _write_pcm16(dst, y, sr)
             with wlock:
                 written[p] = dst
-            if file_callback is not None:
+            if file_callback is not None:           # _emit itself runs under _enhance_model_rate_clips' lock: one callback at a time
                 file_callback(p, dst)
 
         try:

@@ -63,6 +63,26 @@ def validate_attn_limit_db(attn_limit_db: Optional[float]) -> Optional[float]:
     return value
 
 
+def apply_attn_limit(spec_noisy: np.ndarray, spec_enh: np.ndarray, attn_limit_db: Optional[float]) -> np.ndarray:
+    """Attenuation limit on [B, T, F, 2] spectra, on the host (reference audio.py:50-76): out = a * noisy[t - 4] + (1 - a) * enh[t]
+    with a = 10^(-dB / 20); frames before the 4-frame offset blend against zero.  The engine's own offline path applies the
+    same blend inside the deep-filter kernel; this function is for callers that hold spectra themselves -- the
+    reference's enhance() loop run over `ort_shim`, spectral post-processing."""
+    value = validate_attn_limit_db(attn_limit_db)
+    enh = np.asarray(spec_enh, dtype=np.float32)
+    if value is None:
+        return enh
+    noisy = np.asarray(spec_noisy, dtype=np.float32)
+    if noisy.shape != enh.shape:
+        raise ValueError(f"spec_noisy and spec_enh must have matching shapes, got {noisy.shape} and {enh.shape}.")
+    k = ATTN_LIMIT_NOISY_FRAME_OFFSET
+    delayed = np.zeros_like(noisy)
+    if noisy.shape[1] > k:
+        delayed[:, k:] = noisy[:, :-k]
+    a = float(10.0 ** (-value / 20.0))
+    return np.ascontiguousarray(a * delayed + (1.0 - a) * enh, dtype=np.float32)
+
+
 def pcm16_safe(audio: np.ndarray) -> np.ndarray:
     """Clip to [-1,1] and scale to int16 (reference audio.py:79-81)."""
     x = np.clip(np.asarray(audio, dtype=np.float32), -1.0, 1.0)

@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = (
     "dpdf_set_chunk_frames", "dpdf_set_overlap", "dpdf_set_fuse_dprnn", "dpdf_debug_fetch",
     "dpdf_resample_len", "dpdf_resample", "dpdf_enhance_batch_ragged", "dpdf_debug_raise_device_error",
     "dpdf_set_option", "dpdf_streams_process_masked", "dpdf_streams_set_state", "dpdf_streams_get_tails",
-    "dpdf_streams_prime_one", "dpdf_streams_is_primed", "dpdf_recovery_count",
+    "dpdf_streams_prime_one", "dpdf_streams_is_primed", "dpdf_recovery_count", "dpdf_progress",
 )
 
 
@@ -110,6 +110,7 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_streams_get_tails.argtypes = [vp, ctypes.c_int, vp, vp]
         L.dpdf_streams_prime_one.argtypes = [vp, ctypes.c_int, vp]
         L.dpdf_streams_is_primed.argtypes = [vp, ctypes.c_int]
+        L.dpdf_progress.argtypes = [vp]
         L.dpdf_recovery_count.argtypes = [vp]
         L.dpdf_recovery_count.restype = ctypes.c_long
         L.dpdf_profile_enable.argtypes = [vp, ctypes.c_int]
@@ -283,6 +284,10 @@ class HipModel:
 
     def sync(self) -> None:
         _check(self._L.dpdf_sync(self._h))
+
+    def progress(self) -> int:
+        """Frames of the offline call in flight whose output is complete (lock-free; poll from another thread)."""
+        return int(self._L.dpdf_progress(self._h))
 
     @property
     def recovery_count(self) -> int:

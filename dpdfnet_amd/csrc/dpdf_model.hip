@@ -40,11 +40,10 @@
 // streams per handle concurrently (stage 1, ERB branch, stage 2, DF decoder), so with the default a second handle --
 // even an idle one -- or any other stream user makes two of them share a queue and serialise: one 10 s clip 11.4 ms
 // alone, 16.0 ms beside a second handle; with 8 queues 11.4 ms in both cases (tools/clock_probe.py).  The variable is
-// read when the HIP runtime initialises, so it is set when this library is loaded, unless the host application has
-// chosen a value itself (it has no effect if HIP was already initialised: dpdfnet_amd/__init__.py and bench.py also set
-// it before anything touches the GPU).
+// read when the HIP runtime initialises, which a library cannot influence once its host has touched the GPU: the
+// LIBRARY does not set it.  The Python package (dpdfnet_amd/__init__.py) and bench.py set a default of 8 before HIP
+// comes up and say so when they are too late; C hosts set GPU_MAX_HW_QUEUES=8 themselves.
 // ------------------------------------------------------------------------------------------------
-__attribute__((constructor)) static void dpdf_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -340,6 +339,8 @@ struct dpdf_model {
     int* d_err = nullptr;
     int* d_lens = nullptr; size_t d_lens_cap = 0; std::vector<int> h_lens;   // per-clip lengths of a ragged batch
     int use_gru256_cluster = 1;
+    int* pin_progress = nullptr;       // pinned host word: frames of the running offline call whose stage 2 is complete (dpdf_progress)
+    bool progress_on = false;          // set by the offline entry points only (a streaming hop does not pay for the extra launch)
     long recoveries = 0;               // calls re-run on the non-spinning GRU-256 kernels after a cluster exchange timed out (dpdf_recovery_count)
     // prepared weights (arena offsets)
     size_t conv0_w, conv0_b;
@@ -1461,6 +1462,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         sio.do_export = 1;
         hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, st, sio);
     }
+    if (m->progress_on && m->pin_progress) hipLaunchKernelGGL(progress_kernel, dim3(1), dim3(1), 0, st, m->pin_progress, c.out_t0 + Tc);
     if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_s2[c.parity], st)); m->ln->s2_pending[c.parity] = true; }
     m->ln->dbg_emb = w.emb.p;
     HIP_TRY(hipGetLastError());
@@ -1862,6 +1864,8 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
     }
     HIP_TRY(hipMalloc((void**)&m->d_err, sizeof(int)));
     HIP_TRY(hipMemset(m->d_err, 0, sizeof(int)));
+    HIP_TRY(hipHostMalloc((void**)&m->pin_progress, sizeof(int), hipHostMallocDefault));
+    *m->pin_progress = 0;
     *out = m;
     return DPDF_OK;
 }
@@ -1883,6 +1887,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     if (m->consts) (void)hipFree(m->consts);
     if (m->iconsts) (void)hipFree(m->iconsts);
     if (m->d_err) (void)hipFree(m->d_err);
+    if (m->pin_progress) (void)hipHostFree(m->pin_progress);
     if (m->d_lens) (void)hipFree(m->d_lens);
     if (m->d_init_state) (void)hipFree(m->d_init_state);
     for (hipEvent_t e : m->prof_events) if (e) (void)hipEventDestroy(e);
@@ -1990,6 +1995,10 @@ extern "C" int dpdf_sync(dpdf_model* m) {
     HIP_TRY(hipStreamSynchronize(m->stream));
     return check_device_err(m);      // device-pointer calls surface a failed GRU-256 exchange here
 }
+// Frames of the offline call in flight (or of the last one) whose enhanced spectra are complete: lock-free, callable from
+// another host thread while dpdf_enhance_batch* runs (reference api.py:94-104 reports (t + 1, total) after every frame; here
+// the figure advances once per time chunk).
+extern "C" int dpdf_progress(const dpdf_model* m) { return (m && m->pin_progress) ? *(volatile int*)m->pin_progress : 0; }
 extern "C" int dpdf_debug_raise_device_error(dpdf_model* m) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
     std::lock_guard<std::mutex> lk(m->mu);
@@ -2146,8 +2155,11 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
     // A2..A13: frame function over time chunks (+ attenuation limit fused in the DF kernel)
     const bool attn = std::isfinite(attn_limit_db);
     const float alpha = attn ? (float)std::pow(10.0, -(double)attn_limit_db / 20.0) : 0.f;
+    if (m->pin_progress) *m->pin_progress = 0;
+    m->progress_on = true;
     rc = run_chunks(m, m->raw_spec.p, (size_t)T * d.F * 2, B, T, m->batch_state.p, m->enh_spec.p,
                     attn ? m->raw_spec.p : nullptr, alpha);
+    m->progress_on = false;
     if (rc) return rc;
     // A14: synthesis
     {

@@ -433,6 +433,9 @@ __global__ void stream_pack_kernel(StreamPackArgs a) {
     }
     if (UNPACK && a.host_err && k == 0 && t0 == 0) *a.host_err = *a.dev_err;
 }
+// progress of an offline call, written straight into pinned host memory at the end of every chunk's stage 2
+__global__ void progress_kernel(int* host_word, int frames_done) { *host_word = frames_done; }
+
 // dst <- src for n floats (snapshot / restore of the streaming state around a call: dpdf_streams_process)
 __global__ void copy_f4_kernel(float* dst, const float* src, size_t n) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;

@@ -77,6 +77,9 @@ int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, float* state
  * fit to N.  wav/out: [B,N].  attn_limit_db: NaN or +inf = off (reference None/inf). */
 int dpdf_enhance_batch(dpdf_model* m, const float* wav, int B, int N, float attn_limit_db, float* out, int flags);
 int dpdf_num_frames(const dpdf_model* m, int n_samples);   /* T = 1 + (N + win)/hop */
+/* Progress of the dpdf_enhance_batch* call in flight: frames (per clip) whose enhanced spectra are complete, 0 .. T.  No lock,
+ * no synchronisation: meant to be polled from another host thread (reference api.py:94-104 progress_callback(t + 1, total)). */
+int dpdf_progress(const dpdf_model* m);
 /* The same for clips of DIFFERENT lengths in one call -- what a directory of files is (reference cli.py:222-311 runs
  * enhance_file per file on a thread pool; api.py:172-280).  wav/out: [B, n_max] rows; clip b holds lengths[b] <= n_max
  * samples (lengths: HOST array, also with DPDF_DEVICE_PTRS).  Every clip gets exactly the result of dpdf_enhance_batch

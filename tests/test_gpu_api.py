@@ -378,3 +378,22 @@ def test_pool_of_independent_enhancers_matches_reference_goldens(tag, be, tmp_pa
     rounds = -(-len(wav) // hop)
     assert t_hop <= 1.3 * t_grp + N * rounds * 8e-6, (t_hop, t_grp)
     runtime.clear_cache()
+
+
+def test_enhance_progress_is_real_and_ordered(be):
+    """enhance(progress_callback=...) on the engine: (0, T) first, then every frame once and in order; the engine publishes
+    its progress once per time chunk (dpdf_progress), so with 60-frame chunks the reports arrive in several batches."""
+    import dpdfnet_amd
+    from dpdfnet_amd import runtime
+    runtime.clear_cache()
+    sr = 16000
+    wav = synth_clip(3 * sr, sr, 3)
+    seen = []
+    out = dpdfnet_amd.enhance(wav, sr, model="dpdfnet2", onnx_path="synthetic:9", progress_callback=lambda d, t: seen.append((d, t)))
+    T = 1 + (len(wav) + 320) // 160
+    assert seen[0] == (0, T) and seen[1:] == [(i + 1, T) for i in range(T)]
+    ref = dpdfnet_amd.enhance(wav, sr, model="dpdfnet2", onnx_path="synthetic:9")
+    np.testing.assert_array_equal(out, ref)
+    sess = next(iter(runtime._cache.values())).session
+    assert sess.progress() == T
+    runtime.clear_cache()

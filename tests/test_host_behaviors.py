@@ -436,3 +436,46 @@ def test_pool_threads_share_device_calls_and_state_round_trip(monkeypatch):
     np.testing.assert_array_equal(a.process(nxt), want)
     b.load_state(saved)
     np.testing.assert_array_equal(b.process(nxt), want)
+
+
+def test_apply_attn_limit_known_answers_and_errors():
+    """audio.apply_attn_limit (host blend on [B, T, F, 2] spectra) against outputs of the reference's function (host_dsp.npz)."""
+    from dpdfnet_amd.audio import apply_attn_limit
+    H = np.load(GOLDEN / "host_dsp.npz")
+    noisy, enh = H["noisy"], H["enh"]
+    np.testing.assert_allclose(apply_attn_limit(noisy, enh, 0.0), H["attn0"], atol=1e-7)
+    np.testing.assert_allclose(apply_attn_limit(noisy, enh, 6.0), H["attn6"], atol=1e-6)
+    np.testing.assert_array_equal(apply_attn_limit(noisy, enh, float("inf")), H["attn_inf"])
+    np.testing.assert_array_equal(apply_attn_limit(noisy, enh, None), H["attn_none"])
+    assert apply_attn_limit(noisy, enh, 3.0).dtype == np.float32
+    with pytest.raises(ValueError, match="matching shapes"):
+        apply_attn_limit(noisy[:, :-1], enh, 3.0)
+    with pytest.raises(ValueError, match="non-negative"):
+        apply_attn_limit(noisy, enh, -1.0)
+    short = apply_attn_limit(noisy[:, :3], enh[:, :3], 0.0)              # fewer frames than the offset: blends against zero
+    np.testing.assert_array_equal(short, np.zeros_like(short))
+
+
+def test_progress_callback_reports_in_order_with_a_polling_session(monkeypatch):
+    """With a session that publishes progress (the HIP engine does, dpdf_progress) enhance() reports every frame exactly once,
+    in order, on the calling thread, while the engine call runs on a worker."""
+    import threading, time
+    sess = _patch(monkeypatch, win=8)
+    state = {"p": 0}
+    real = sess.enhance_batch
+
+    def slow(wav, attn=None, **kw):
+        T = 1 + (wav.shape[1] + 8) // 4
+        for t in range(0, T, 3):
+            state["p"] = t; time.sleep(0.004)
+        state["p"] = T
+        return real(wav, attn, **kw)
+
+    sess.enhance_batch = slow
+    sess.progress = lambda: state["p"]
+    import dpdfnet_amd
+    seen, threads = [], set()
+    out = dpdfnet_amd.enhance(np.zeros(64, np.float32), 16000, progress_callback=lambda d, t: (seen.append((d, t)), threads.add(threading.get_ident())))
+    T = 1 + (64 + 8) // 4
+    assert seen[0] == (0, T) and seen[1:] == [(i + 1, T) for i in range(T)]
+    assert threads == {threading.get_ident()} and out.shape == (64,)
