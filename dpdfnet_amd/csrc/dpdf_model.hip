@@ -1251,23 +1251,11 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         int nth = ((d.E + d.D + 63) / 64) * 64;
         hipLaunchKernelGGL(feat_b_kernel, dim3(B), dim3(nth), 0, sA, fb);
     }
-    // ---- encoder, ERB branch (reference onnx_model/dpdfnet.py:206-219) on its own stream ----
+    // The DF branch is the longer dependent chain (48 band positions per intra-band scan against 8 / 40) and its kernels are
+    // ENQUEUED first: in the latency regime the host is only just ahead of the GPU (~2.5 us per launch), and the ~20 launches of
+    // the branch that is enqueued first delay the start of the other one by ~50 us -- which the shorter ERB chain can afford
+    // and the DF chain cannot (64 x 48 kHz streams, one hop: 757 -> see DESIGN.md).  The fork point is the same either way.
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fk[c.parity], sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fk[c.parity], 0)); }
-    m->cur = sC;
-    TView e0v{x.e0.p, Tc, 0, d.Ec, 64}, e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
-    {
-        ProfScope ps(m, "enc_convs_erb");
-        Conv0ErbArgs ca{w.feat_erb.p, x.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
-        size_t rows16 = ((size_t)BT * d.Ec + 15) / 16;
-        hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)std::min<size_t>(rows16, 8192)), dim3(256), 0, sC, ca);
-        run_dwconv_s(m, m->erb_conv1, e0v, e1v, B, Tc, d.s1);
-        run_dwconv_s(m, m->erb_conv2, e1v, e2v, B, Tc, d.s2);
-        run_dwconv_s(m, m->erb_conv3, e2v, e3v, B, Tc, d.s3);
-    }
-    x.e3d = x.e3.p;
-    if (d.nb > 0) {
-        x.e3d = run_dprnn(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
-    }
     // ---- encoder, DF branch (dpdfnet.py:221-234) on the main stream ----
     m->cur = sA;
     TView c0v{x.c0.p, Tc + 4, 4, d.D, 64}, c1v{x.c1.p, Tc, 0, d.Fd, 64};
@@ -1296,6 +1284,23 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     if (d.nb > 0) {
         x.c1d = run_dprnn(m, m->dprnn_df, x.c1.p, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
     }
+    // ---- encoder, ERB branch (reference onnx_model/dpdfnet.py:206-219) on its own stream ----
+    m->cur = sC;
+    TView e0v{x.e0.p, Tc, 0, d.Ec, 64}, e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
+    {
+        ProfScope ps(m, "enc_convs_erb");
+        Conv0ErbArgs ca{w.feat_erb.p, x.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
+        size_t rows16 = ((size_t)BT * d.Ec + 15) / 16;
+        hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)std::min<size_t>(rows16, 8192)), dim3(256), 0, sC, ca);
+        run_dwconv_s(m, m->erb_conv1, e0v, e1v, B, Tc, d.s1);
+        run_dwconv_s(m, m->erb_conv2, e1v, e2v, B, Tc, d.s2);
+        run_dwconv_s(m, m->erb_conv3, e2v, e3v, B, Tc, d.s3);
+    }
+    x.e3d = x.e3.p;
+    if (d.nb > 0) {
+        x.e3d = run_dprnn(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
+    }
+    m->cur = sA;
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_jn[c.parity], sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_jn[c.parity], 0)); }
     {
         ProfScope ps(m, "state_io");
@@ -2256,14 +2261,16 @@ extern "C" int dpdf_streams_prime(dpdf_streams* s, const float* pcm_in, int flag
 // One streaming call on device buffers: src [S][T*hop] -> dst [S][T*hop], everything enqueued on the engine's streams and
 // joined back into m->stream.  host_err (pinned host memory, may be null): the last kernel mirrors the device error flag into it.
 // (S, state, in_tail, ola_tail): the stream set itself, or the packed active subset of a masked call.
-struct StreamView { int S; float* state; float* in_tail; float* ola_tail; };
+// snap_in / snap_ola (null: none): where the staging and overlap-add kernels leave the pre-call tails; ev_state (null: none):
+// event behind the pre-call copy of the state, awaited before the frame function starts to update the state in place
+struct StreamView { int S; float* state; float* in_tail; float* ola_tail; float* snap_in = nullptr; float* snap_ola = nullptr; hipEvent_t ev_state = nullptr; };
 static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* src, int T, float* dst, int* host_err) {
     dpdf_model* m = s->m;
     const dpdf_dims& d = m->d;
     const int S = v.S;
     int rc;
     float* xbuf = s->pcm_in.p;                       // [S][(T+1)*hop]
-    hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, v.in_tail, xbuf, S, T, d.hop);
+    hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, v.in_tail, xbuf, S, T, d.hop, v.snap_in);
     {   // causal analysis (stream.py:119-126): frame j = xbuf[j*hop : j*hop+win] * window -> rfft.
         StftA<64> ap{xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
         if (S * T <= SMALL_M_ROWS) {
@@ -2274,6 +2281,7 @@ static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* sr
             launch_gemm_rows_wn<2, 64>(m->stream, ap, m->C(m->stft_frag_s), ep, S * T, d.win, m->stft_groups_s / 4);
         }
     }
+    if (v.ev_state) HIP_TRY(hipStreamWaitEvent(m->stream, v.ev_state, 0));
     rc = run_chunks(m, s->spec.p, (size_t)T * d.F * 2, S, T, v.state, s->spec_e.p, nullptr, 0.f);
     if (rc) return rc;
     {
@@ -2288,11 +2296,11 @@ static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* sr
             BiasActStore<5> ep7{m->stft_part.p, (size_t)ks * W, 80, nullptr, 0, 80, ACT_NONE};
             launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep7, S * T, m->istft_K, m->istft_groups, 2048, ks);
             hipLaunchKernelGGL(stream_ola_ksplit_kernel, dim3(S), dim3(256), 0, m->stream, (const float*)m->stft_part.p, ks, W, m->C(m->window), v.ola_tail, dst, S, T, d.hop,
-                               (const int*)m->d_err, host_err);
+                               (const int*)m->d_err, host_err, v.snap_ola);
         } else {
             if (S * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups / 4);
             else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, S * T, m->istft_K, m->istft_groups);
-            hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, v.ola_tail, dst, S, T, d.hop, (const int*)m->d_err, host_err);
+            hipLaunchKernelGGL(stream_ola_kernel, dim3(S), dim3(256), 0, m->stream, m->frames.p, v.ola_tail, dst, S, T, d.hop, (const int*)m->d_err, host_err, v.snap_ola);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -2301,10 +2309,30 @@ static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* sr
 
 // The body of a streaming call on device-visible buffers (src / dst: device memory or pinned host memory), all streams or
 // the n_act packed ones listed in idx (device-visible).
-static int streams_run(dpdf_streams* s, const float* src, int T, float* dst, int n_act, const int* idx, int* host_err) {
+// snap: take the pre-call copy (state on the stage-2 stream, tails inside the kernels that overwrite them).
+static int streams_run(dpdf_streams* s, const float* src, int T, float* dst, int n_act, const int* idx, int* host_err, bool snap = false) {
     dpdf_model* m = s->m;
     const dpdf_dims& d = m->d;
-    if (n_act == s->S) return streams_enqueue(s, StreamView{s->S, s->state.p, s->in_tail.p, s->ola_tail.p}, src, T, dst, host_err);
+    hipEvent_t ev_state = nullptr;
+    if (snap) {
+        // the state copy runs on the stage-2 stream (idle until stage 1 of this call is through) beside the staging kernel and
+        // the STFT; only the frame function waits for it
+        const size_t ns = (size_t)s->S * d.state_size;
+        hipStream_t sb = m->lanes[0].sB;
+        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((ns / 4 + 256) / 256)), dim3(256), 0, sb, s->snap_state.p, (const float*)s->state.p, ns);
+        HIP_TRY(hipEventRecord(s->ev_snap, sb));
+        ev_state = s->ev_snap;
+    }
+    if (n_act == s->S) {
+        StreamView v{s->S, s->state.p, s->in_tail.p, s->ola_tail.p, snap ? s->snap_in.p : nullptr, snap ? s->snap_ola.p : nullptr, ev_state};
+        return streams_enqueue(s, v, src, T, dst, host_err);
+    }
+    if (snap) {     // masked call: the packed copies are what the kernels overwrite; the full-set tails are copied here (rare path)
+        const size_t nt = (size_t)s->S * d.hop;
+        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((nt / 4 + 256) / 256)), dim3(256), 0, m->stream, s->snap_in.p, (const float*)s->in_tail.p, nt);
+        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((nt / 4 + 256) / 256)), dim3(256), 0, m->stream, s->snap_ola.p, (const float*)s->ola_tail.p, nt);
+        HIP_TRY(hipStreamWaitEvent(m->stream, ev_state, 0));
+    }
     const int npcm = T * d.hop;
     StreamPackArgs pa{s->state.p, s->in_tail.p, s->ola_tail.p, s->cstate.p, s->cin.p, s->cola.p, src, s->cpcm_in.p, s->cpcm_out.p, dst,
                       idx, (long)d.state_size, d.hop, npcm, (const int*)m->d_err, host_err};
@@ -2385,19 +2413,12 @@ extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in,
         const size_t o = (size_t)s->pin_idx[k] * T * d.hop;
         memcpy(s->pin_in + o, pcm_in + o, (size_t)T * d.hop * sizeof(float));
     }
-    {   // snapshot on the stage-2 stream (idle until stage 1 of the call is through), beside the call's first kernels; the main
-        // stream waits for it before anything writes the state (the staging kernel only touches in_tail: ordered by the event too)
+    {
         const size_t ns = (size_t)S * d.state_size, nt = (size_t)S * d.hop;
         if ((rc = s->snap_state.ensure(ns)) || (rc = s->snap_in.ensure(nt)) || (rc = s->snap_ola.ensure(nt))) return rc;
         if (!s->ev_snap) HIP_TRY(hipEventCreateWithFlags(&s->ev_snap, hipEventDisableTiming));
-        hipStream_t sb = m->lanes[0].sB;
-        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((ns / 4 + 256) / 256)), dim3(256), 0, sb, s->snap_state.p, (const float*)s->state.p, ns);
-        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((nt / 4 + 256) / 256)), dim3(256), 0, sb, s->snap_in.p, (const float*)s->in_tail.p, nt);
-        hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)((nt / 4 + 256) / 256)), dim3(256), 0, sb, s->snap_ola.p, (const float*)s->ola_tail.p, nt);
-        HIP_TRY(hipEventRecord(s->ev_snap, sb));
-        HIP_TRY(hipStreamWaitEvent(m->stream, s->ev_snap, 0));
     }
-    if ((rc = streams_run(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx, s->pin_err))) return rc;
+    if ((rc = streams_run(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx, s->pin_err, true))) return rc;
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (*s->pin_err) {
         *s->pin_err = 0;

@@ -455,11 +455,16 @@ __global__ void axpy_kernel(float* y, const float* x, size_t n) {
 // streaming glue (reference package/src/dpdfnet/stream.py:116-156): causal analysis buffer and
 // overlap-add with carried tails, hop = win/2.
 //   xbuf[s] = in_tail[s] (hop samples) ++ pcm_in[s] (n_hops*hop samples); new in_tail = last hop samples
-__global__ void stream_stage_in_kernel(const float* pcm_in, float* in_tail, float* xbuf, int S, int n_hops, int hop) {
+// snap_in (may be null): pre-call copy of the analysis tails, taken here because this kernel is the one that overwrites them
+__global__ void stream_stage_in_kernel(const float* pcm_in, float* in_tail, float* xbuf, int S, int n_hops, int hop, float* snap_in) {
     const int s = blockIdx.x;
     const int n = n_hops * hop;
     float* xb = xbuf + (size_t)s * (n + hop);
-    for (int i = threadIdx.x; i < hop; i += blockDim.x) xb[i] = in_tail[(size_t)s * hop + i];
+    for (int i = threadIdx.x; i < hop; i += blockDim.x) {
+        const float v = in_tail[(size_t)s * hop + i];
+        xb[i] = v;
+        if (snap_in) snap_in[(size_t)s * hop + i] = v;
+    }
     for (int i = threadIdx.x; i < n; i += blockDim.x) xb[hop + i] = pcm_in[(size_t)s * n + i];
     __syncthreads();
     for (int i = threadIdx.x; i < hop; i += blockDim.x) in_tail[(size_t)s * hop + i] = xb[n + i];
@@ -469,9 +474,10 @@ __global__ void stream_stage_in_kernel(const float* pcm_in, float* in_tail, floa
 // (the streaming iSTFT of a few frames runs split over K, gemm_rows.h; this kernel is its summing half).
 // dev_err / host_err: the last kernel of a streaming call mirrors the device error flag into pinned host memory (null: no mirror)
 __global__ void stream_ola_ksplit_kernel(const float* part, int ks, int W, const float* window, float* ola_tail, float* pcm_out, int S, int n_hops, int hop,
-                                         const int* dev_err, int* host_err) {
+                                         const int* dev_err, int* host_err, float* snap_ola) {
     const int s = blockIdx.x;
     if (host_err && s == 0 && threadIdx.x == 0) *host_err = *dev_err;
+    if (snap_ola) { for (int i = threadIdx.x; i < hop; i += blockDim.x) snap_ola[(size_t)s * hop + i] = ola_tail[(size_t)s * hop + i]; }
     const int win = 2 * hop;
     auto fr = [&](int j, int c) {
         const float* p = part + ((size_t)(s * n_hops + j) * ks) * W + c;
@@ -488,9 +494,10 @@ __global__ void stream_ola_ksplit_kernel(const float* part, int ks, int W, const
     for (int i = threadIdx.x; i < hop; i += blockDim.x) ola_tail[(size_t)s * hop + i] = fr(n_hops - 1, hop + i);
 }
 
-__global__ void stream_ola_kernel(const float* frames, float* ola_tail, float* pcm_out, int S, int n_hops, int hop, const int* dev_err, int* host_err) {
+__global__ void stream_ola_kernel(const float* frames, float* ola_tail, float* pcm_out, int S, int n_hops, int hop, const int* dev_err, int* host_err, float* snap_ola) {
     const int s = blockIdx.x;
     if (host_err && s == 0 && threadIdx.x == 0) *host_err = *dev_err;
+    if (snap_ola) { for (int i = threadIdx.x; i < hop; i += blockDim.x) snap_ola[(size_t)s * hop + i] = ola_tail[(size_t)s * hop + i]; }
     const int win = 2 * hop;
     const float* fr = frames + (size_t)s * n_hops * win;
     for (int idx = threadIdx.x; idx < n_hops * hop; idx += blockDim.x) {
