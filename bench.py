@@ -42,6 +42,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md:
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: ~2.5 PF dense bf16 MFMA peak (only the opt-in bf16x3 line of other_configs is priced against it, / 6)
 GRU64_FLOP_PER_ROW_STEP = 2 * 3 * 64 * (64 + 64)   # r,z,n gates x 64 units x (W_ih x + W_hh h), MAC = 2 FLOP
 FLOP_PER_FRAME = 45.18e6               # algorithmic FLOP / frame, dpdfnet4
+# SURVEY.md 8(d), measured with forward hooks on the reference modules: algorithmic MFLOP / frame of every registry model
+FLOP_PER_FRAME_BY_MODEL = {(16000, 0): 6.64e6, (16000, 2): 25.91e6, (16000, 4): 45.18e6, (16000, 8): 83.71e6,
+                           (48000, 2): 45.68e6, (48000, 8): 136.51e6}
 
 
 def synth_clips(n_clips: int, n: int, sr: int, first_seed: int) -> np.ndarray:
@@ -155,29 +158,44 @@ def other_configs() -> dict:
         T = m.num_frames(n); m.close()
         return B * T / dt, 1e3 * dt
 
+    def mfma(fps: float, sr: int, nb: int) -> float:
+        return round(fps * FLOP_PER_FRAME_BY_MODEL[(sr, nb)] / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+
+    def streams(sr_: int, nb_: int, S: int, calls: int = 200) -> dict:
+        m = backend.HipModel(sr_, nb_, synth_blob(backend.manifest(sr_, nb_), WEIGHT_SEED), device=torch.cuda.current_device())
+        st = backend.HipStreams(m, S)
+        rng = np.random.default_rng(0)
+        hop = m.hop
+        st.prime((0.05 * rng.standard_normal((S, hop))).astype(np.float32))
+        pcm = (0.05 * rng.standard_normal((S, hop))).astype(np.float32)
+        for _ in range(20):
+            st.process(pcm)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            st.process(pcm)
+        dt = (time.perf_counter() - t0) / calls
+        st.close(); m.close()
+        d = backend.query_dims(sr_, nb_)
+        # Latency model of a hop: the two branches run side by side, each a chain of nb x (F' dependent
+        # GRU-64 steps + one glue launch); the DF branch (F' = 48) is the longer one.  Measured minima on this chip
+        # (rocprofv3 trace of single hops, profiles/r3_stream_hop_*): 0.55 us per 4-row scan step (64 x 8.4-cycle
+        # v_mfma_f32_4x4x1 + one LDS round trip + the gate chain), ~1.5 us per dependent kernel boundary.
+        steps = nb_ * d.Fd
+        bound_us = steps * 0.55 + (2 * nb_ + 30) * 1.5
+        return {"us_per_call": round(1e6 * dt, 1), "frames_per_s": round(S / dt), "rtf": round(dt / (hop / sr_), 4),
+                "mfma_frac": mfma(S / dt, sr_, nb_),
+                "latency_model": {"dependent_gru64_steps": steps, "dependent_launches_on_critical_path": 2 * nb_ + 30,
+                                  "bound_us": round(bound_us, 1), "achieved_over_bound": round(1e6 * dt / bound_us, 2)},
+                "io": "host PCM in, host PCM out (pinned staging, zero-copy), one device call per hop"}
+
     # latency-bound configurations first (short kernels: measured before the long throughput runs heat the chip)
     fps, ms = offline(NB, 1, 5)
     out[f"{MODEL}_16k_1x10s"] = {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5)}
-    sr48, nb48, S = 48000, 8, 64
-    m = backend.HipModel(sr48, nb48, synth_blob(backend.manifest(sr48, nb48), WEIGHT_SEED), device=torch.cuda.current_device())
-    st = backend.HipStreams(m, S)
-    rng = np.random.default_rng(0)
-    hop = m.hop
-    st.prime((0.05 * rng.standard_normal((S, hop))).astype(np.float32))
-    pcm = (0.05 * rng.standard_normal((S, hop))).astype(np.float32)
-    for _ in range(20):
-        st.process(pcm)
-    t0 = time.perf_counter()
-    calls = 200
-    for _ in range(calls):
-        st.process(pcm)
-    dt = (time.perf_counter() - t0) / calls
-    st.close(); m.close()
-    out["dpdfnet8_48khz_hr_64_streams_1_hop"] = {"us_per_call": round(1e6 * dt, 1), "frames_per_s": round(S / dt),
-                                                  "rtf": round(dt / (hop / sr48), 4)}
+    out["dpdfnet8_48khz_hr_64_streams_1_hop"] = streams(48000, 8, 64)         # BASELINE configs[4]
+    out["dpdfnet2_16k_1_stream_1_hop"] = streams(16000, 2, 1)                  # one StreamEnhancer (the reference's unit of work)
     for nb in (2, 8):
-        fps, ms = offline(nb, 256, 2)
-        out[f"dpdfnet{nb}_16k_256x10s"] = {"frames_per_s": round(fps), "ms_per_step": round(ms, 2)}
+        fps, ms = offline(nb, 256, 3)
+        out[f"dpdfnet{nb}_16k_256x10s"] = {"frames_per_s": round(fps), "ms_per_step": round(ms, 2), "whole_path_frac": mfma(fps, SR, nb)}
     # OPT-IN precision mode (csrc/gru_bf16x3.h): the GRU-64 scans as three-limb bf16 products with fp32 accumulation.  NOT the
     # headline dtype: priced against the dense bf16 MFMA peak / 6 limb products, not against the fp32 MFMA peak.
     fps, ms = offline(NB, 256, 2, gru64_bf16x3=1)

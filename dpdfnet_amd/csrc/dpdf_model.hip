@@ -326,6 +326,7 @@ struct dpdf_model {
     int gru64_bf16x3 = 0;              // OPT-IN: GRU-64 scans as three-limb bf16 products on the bf16 matrix pipe (gru_bf16x3.h); default 0 = fp32 MFMA;
                                        // 1 = on, 2 = on without the fused fc + LN forms
     int df_ring = 2;                   // big batches: 1 = df_conv1 + DF pathway conv as one time-walking pass over c0 (df_ring.h), 2 = df_conv0 in it too
+    int dec_seg = 1;                   // 48 kHz decoder stages as band-segment tiles with inputs read once (dec_last.h: dec_seg_kernel; 0: gemm_rows producers, A/B)
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
@@ -1323,6 +1324,23 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
     TView dembv{dembp, Tc, 0, d.F3, 64};
     TView d3v{w.d3.p, Tc, 0, d.F2, 64}, d2v{w.d2.p, Tc, 0, d.F1, 64}, d1v{w.d1.p, Tc, 0, d.Ec, 64};
     const bool geo16 = m->fuse_mask && !d.is48 && d.s1 == 2 && d.s2 == 2 && d.s3 == 1 && d.Ec == 32 && d.F1 == 16 && d.F2 == 8 && d.F3 == 8;
+    const bool geo48 = m->dec_seg && d.is48 && m->fuse_mask && d.s3 == 2 && d.s2 == 2 && d.s1 == 3 && d.F2 % 80 == 0 && d.F1 % 80 == 0 && d.Ec % 96 == 0;
+    if (geo48) {    // 48 kHz geometry: tiles of 80 / 80 / 96 output bands of one frame, inputs loaded once (dec_last.h: dec_seg_kernel)
+        const long cap = 256 * 2 * 4;
+        DecSegArgs a3{x.e3.p, dembp, w.d3.p, m->C(m->conv3p.ps), m->C(m->conv3p.pb), m->C(m->convt3.dw), m->C(m->convt3.pwfrag), m->C(m->convt3.bias),
+                      nullptr, nullptr, nullptr, nullptr, nullptr, BT, d.F2};
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), dim3((unsigned)std::min<long>((long)BT * (d.F2 / 80), cap)), dim3(256), 0, st, a3);
+        DecSegArgs a2{x.e2.p, w.d3.p, w.d2.p, m->C(m->conv2p.ps), m->C(m->conv2p.pb), m->C(m->convt2.dw), m->C(m->convt2.pwfrag), m->C(m->convt2.bias),
+                      nullptr, nullptr, nullptr, nullptr, nullptr, BT, d.F1};
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), dim3((unsigned)std::min<long>((long)BT * (d.F1 / 80), cap)), dim3(256), 0, st, a2);
+        // convt1 + mask head: w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
+        DecSegArgs a1{x.e1.p, w.d2.p, nullptr, m->C(m->conv1p.ps), m->C(m->conv1p.pb), m->C(m->convt1.dw), m->C(m->convt1.pwfrag), m->C(m->convt1.bias),
+                      x.e0.p, w.d1.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), BT, d.Ec};
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<3, 96, true>), dim3((unsigned)std::min<long>((long)BT * (d.Ec / 96), cap)), dim3(256), 0, st, a1);
+        MaskFinArgs mf{w.d1.p, w.m.p, m->c0out_bias, BT * d.Ec, d.Ec, d.E, d.is48};
+        hipLaunchKernelGGL(mask_fin_kernel, dim3((BT * d.Ec + 255) / 256), dim3(256), 0, st, mf);
+        return;
+    }
     if (geo16) {    // 16 kHz geometry: whole frames per 64-row tile, inputs loaded once (dec_last.h)
         const int cap = 256 * 3 * 4;
         DecStageArgs a3{x.e3.p, dembp, w.d3.p, m->C(m->conv3p.ps), m->C(m->conv3p.pb), m->C(m->convt3.dw), m->C(m->convt3.pwfrag), m->C(m->convt3.bias), BT};
@@ -1973,6 +1991,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     for (int g = 0; g < 2; ++g) m->lanes[g].sync_all();
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
+    else if (n == "dec_seg") m->dec_seg = value != 0;
     else if (n == "gru64_bf16x3") m->gru64_bf16x3 = value < 0 ? 0 : (value > 2 ? 2 : value);   // 1: on (fc + LN fused into the scans for big batches), 2: plain scans + fp32 GEMM fc/LN passes only (A/B)
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
