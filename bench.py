@@ -132,6 +132,54 @@ def parity_vs_oracle(blob: np.ndarray, wav_host: np.ndarray, out_host: np.ndarra
             "against": "oracle/dpdf_oracle.c (pinned to the reference's goldens) on the same clips; output of the LAST timed step"}
 
 
+def ort_baseline(onnx_path: str, seconds: float = 15.0) -> dict:
+    """OPTIONAL: the reference's own CPU runtime beside the GPU, when `onnxruntime` imports and DPDFNET_ONNX
+    names a streaming dpdfnet4 .onnx file (neither exists in the offline image).  Session options are the reference's
+    (package/src/dpdfnet/onnx_backend.py:21-49: one intra-op and one inter-op thread, ORT_ENABLE_ALL, CPUExecutionProvider);
+    the loop is its per-frame session.run (api.py:96-104; onnx_model/infer_dpdfnet_onnx.py:299-306), one session per usable
+    core, run for a bounded time on synthetic spectra."""
+    import onnxruntime as ort  # noqa: F401  (ImportError is the caller's signal that the leg does not apply)
+    opts = ort.SessionOptions()
+    opts.intra_op_num_threads = 1
+    opts.inter_op_num_threads = 1
+    opts.graph_optimization_level = ort.GraphOptimizationLevel.ORT_ENABLE_ALL
+    cores = usable_cores()
+    sessions = [ort.InferenceSession(onnx_path, sess_options=opts, providers=["CPUExecutionProvider"]) for _ in range(cores)]
+    s0 = sessions[0]
+    ins, outs = s0.get_inputs(), s0.get_outputs()
+    meta = s0.get_modelmeta().custom_metadata_map
+    state0 = np.zeros(int(meta["state_size"]), dtype=np.float32)
+    en = np.array([float(x) for x in meta["erb_norm_init"].split(",")], dtype=np.float32)
+    sn = np.array([float(x) for x in meta["spec_norm_init"].split(",")], dtype=np.float32)
+    state0[: en.size] = en
+    state0[en.size: en.size + sn.size] = sn
+    F = int(ins[0].shape[-2])
+    rng = np.random.default_rng(1)
+    spec = (0.1 * rng.standard_normal((64, 1, 1, F, 2))).astype(np.float32)
+    counts = [0] * cores
+    stop = time.perf_counter() + seconds
+
+    def work(i: int) -> None:
+        st = state0.copy()
+        n = 0
+        while time.perf_counter() < stop:
+            _, st = sessions[i].run([outs[0].name, outs[1].name], {ins[0].name: spec[n & 63], ins[1].name: st})
+            n += 1
+        counts[i] = n
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(counts) / dt, "unit": "frames/s", "cores": cores, "kind": "ort",
+            "sample": f"{sum(counts)} session.run calls (one frame each) over {dt:.1f} s, one 1-thread CPUExecutionProvider session per usable core, "
+                      f"{Path(onnx_path).name}; options of package/src/dpdfnet/onnx_backend.py:21-49",
+            "ms_per_frame_per_thread": 1e3 * dt * cores / max(1, sum(counts))}
+
+
 def other_configs() -> dict:
     """BASELINE.json's remaining single-GPU configurations, timed briefly beside the headline (they are parity-test
     cases in tests/test_gpu_fullsize.py; these are their speeds): dpdfnet2 / dpdfnet8 at 256 clips x 10 s, one clip
@@ -553,6 +601,15 @@ def main() -> None:
             print("[bench.py] no GRU-64 kernel launches were profiled (--profile-steps 0?): the roofline block is empty", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blob, args.cpu_clip_seconds, args.cpu_clips_per_thread)
+            # the reference's own CPU runtime, if this box has it (it does not offline: then the leg is reported as absent, not faked)
+            onnx_path = os.environ.get("DPDFNET_ONNX", "")
+            try:
+                if not onnx_path or not Path(onnx_path).is_file():
+                    raise FileNotFoundError("DPDFNET_ONNX not set or not a file")
+                line["cpu_baseline"]["reference_runtime"] = ort_baseline(onnx_path)
+            except Exception as exc:
+                line["cpu_baseline"]["reference_runtime"] = {"kind": "ort", "available": False,
+                                                              "why": f"{type(exc).__name__}: {exc}"[:200]}
         if world == 1 and not args.no_other_configs and not args.no_isolated:
             try:
                 line["other_configs"] = other_configs()
