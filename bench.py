@@ -39,7 +39,6 @@ MODEL, SR, NB = "dpdfnet4", 16000, 4
 CLIP_SECONDS = 10.0
 WEIGHT_SEED = 20260417
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0         # same guide: ~2.5 PF dense bf16 MFMA peak (only the opt-in bf16x3 line of other_configs is priced against it, / 6)
 GRU64_FLOP_PER_ROW_STEP = 2 * 3 * 64 * (64 + 64)   # r,z,n gates x 64 units x (W_ih x + W_hh h), MAC = 2 FLOP
 FLOP_PER_FRAME = 45.18e6               # algorithmic FLOP / frame, dpdfnet4
 # SURVEY.md 8(d), measured with forward hooks on the reference modules: algorithmic MFLOP / frame of every registry model
@@ -244,14 +243,6 @@ def other_configs() -> dict:
     for nb in (2, 8):
         fps, ms = offline(nb, 256, 3)
         out[f"dpdfnet{nb}_16k_256x10s"] = {"frames_per_s": round(fps), "ms_per_step": round(ms, 2), "whole_path_frac": mfma(fps, SR, nb)}
-    # OPT-IN precision mode (csrc/gru_bf16x3.h): the GRU-64 scans as three-limb bf16 products with fp32 accumulation.  NOT the
-    # headline dtype: priced against the dense bf16 MFMA peak / 6 limb products, not against the fp32 MFMA peak.
-    fps, ms = offline(NB, 256, 2, gru64_bf16x3=1)
-    out[f"{MODEL}_16k_256x10s_optin_bf16x3_gru64"] = {
-        "frames_per_s": round(fps), "ms_per_step": round(ms, 2), "dtype": "f32 emulated as 3 x bf16 limbs (GRU-64 scans only), f32 accumulate",
-        "fp32_equivalent_tflops_whole_path": round(fps * FLOP_PER_FRAME / 1e12, 1),
-        "frac_of_bf16_peak_over_6": round(fps * FLOP_PER_FRAME / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 3),
-        "note": "opt-in via dpdf_set_option('gru64_bf16x3', 1); same parity tests and tolerance as the default mode"}
     return out
 
 
@@ -263,7 +254,7 @@ def main() -> None:
     ap.add_argument("--clips", type=int, default=256, help="clips per GPU")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("DPDF_CHUNK_FRAMES", "0")),
                     help="time-chunk length in frames (0 = engine default)")
-    ap.add_argument("--overlap", type=int, default=-1, help="overlap bit mask (1 stage-2 stream, 2 ERB stream, 4 two lanes, 8 decoder fork, 16 8-WG GRU-256 clusters; 0 serial; -1 engine default)")
+    ap.add_argument("--overlap", type=int, default=-1, help="overlap bit mask (1 stage-2 stream, 2 ERB stream, 8 decoder fork, 16 8-/16-WG GRU-256 clusters; 0 serial; -1 engine default)")
     ap.add_argument("--no-fuse", action="store_true", help="run fc+LN of the DPRNN blocks as separate kernels")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 control flow on a box with fewer GPUs than ranks)")

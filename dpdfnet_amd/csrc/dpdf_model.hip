@@ -30,7 +30,6 @@
 #include "resample.h"
 #include "df_ring.h"
 #include "dec_last.h"
-#include "gru_bf16x3.h"
 #include "gru_stack.h"
 #include "fcln_gi.h"
 #include "gru_scan4.h"
@@ -200,14 +199,12 @@ BnFold fold_bn(const Blob& B, const std::string& p, int ch) {
 struct SepConvW { size_t dw, pwfrag, bias; int nsub; };        // arena offsets
 struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs;
-                size_t wlimb;                 // opt-in bf16x3 mode: the same weights as three bf16 limbs per value (gru_bf16x3.h), in float-sized arena slots
                 size_t hh4;                   // W_hh for the 4-row scan (gru_scan4.h): [dir][wave 4][k 64][lane 4u+j]: gate j of unit 16 wave + u (j = 3: zero)
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
 struct GlW { size_t frag, bias, raw; int G, Og, Ig, NT; };   // raw: the reference's [G][Og][Ig] weight as is (gru256_chain16_kernel)
 struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn, ih_as_hh; };   // ih_as_hh: W_ih packed like hh_frag (second cell of a stacked pair, gru_stack.h)   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
-                size_t fci_epi, fce_epi;
-                size_t fcl_fwd, fcl_bwd, fcl_inter; };   // opt-in bf16x3 mode: fc halves as bf16 limbs (gru_bf16x3.h)   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
+                size_t fci_epi, fce_epi; };   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
 
 }  // namespace
 
@@ -240,7 +237,7 @@ struct XSet {
         for (DevBuf* b : all) b->release();
     }
 };
-constexpr int NRING = 4;            // chunk-ring depth of the stage-crossing tensors: 2 used by the two-stage pipeline, 4 by the sub-stage pipeline
+constexpr int NRING = 2;            // stage-crossing tensors are double-buffered by chunk parity
 struct Workspace {
     int Bcap = 0, Tcap = 0;
     XSet x[NRING];
@@ -250,16 +247,8 @@ struct Workspace {
     // stage-2 temporaries
     DevBuf embin, g256a, g256b, g256c, gi, emb, demb, demb2, d3, d2, d1, m, dfo, coefs, xm;
     DevBuf g256d, g256e, g256f, gi2;   // DF-decoder chain's own scratch (runs beside the ERB decoder)
-    // sub-stage pipeline of stage 2 (small batches): tensors handed from one sub-stage to the next, by chunk parity,
-    // and per-cell scratch for the cells that then run concurrently
-    DevBuf embr[NRING], hbe[NRING], hbd[NRING], ge_in, gi3, gi4, gi5;
-    int pipeB = 0, pipeT = 0;
     void release() {
         for (int k = 0; k < NRING; ++k) x[k].release();
-        DevBuf* pipe[] = {&ge_in, &gi3, &gi4, &gi5};
-        for (DevBuf* b : pipe) b->release();
-        for (int k = 0; k < NRING; ++k) { embr[k].release(); hbe[k].release(); hbd[k].release(); }
-        pipeB = pipeT = 0;
         DevBuf* all[] = {&feat_erb, &feat_spec, &hcat, &hin, &hcat_e, &hin_e, &gi64, &gi64_e,
                          &embin, &g256a, &g256b, &g256c, &gi, &g256d, &g256e, &g256f, &gi2, &emb, &demb, &demb2, &d3, &d2, &d1, &m, &dfo, &coefs, &xm};
         for (DevBuf* b : all) b->release();
@@ -272,24 +261,18 @@ struct Workspace {
 // HBM-bound phases of one lane run under MFMA-bound scans of the other.
 struct Lane {
     hipStream_t sA = nullptr, sB = nullptr, sC = nullptr, sD = nullptr;   // sD: DF-decoder half of stage 2
-    hipStream_t sE = nullptr, sF = nullptr, sG = nullptr;                  // small batches: stage 2 as a pipeline of sub-stages (run_stage2_pipe)
-    hipEvent_t ev_a[NRING] = {}, ev_be[NRING] = {}, ev_bd[NRING] = {}, ev_cd[NRING] = {};
     void sync_all() const {
-        hipStream_t all[] = {sA, sB, sC, sD, sE, sF, sG};
+        hipStream_t all[] = {sA, sB, sC, sD};
         for (hipStream_t st : all) if (st) (void)hipStreamSynchronize(st);
     }
     hipEvent_t ev_s1[NRING] = {}, ev_s2[NRING] = {}, ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr;
     hipEvent_t ev_fk[NRING] = {}, ev_jn[NRING] = {};   // ERB-branch fork/join, per chunk-ring slot
     hipEvent_t ev_dfk[NRING] = {}, ev_djn[NRING] = {}; // decoder fork/join inside stage 2
     bool s2_pending[NRING] = {};
-    int prev_slot = -1;                                // ring slot of the chunk before the current one (sub-stage pipeline)
     Workspace ws;
     // GRU-256 cluster exchange granules: [0] embedding + ERB-decoder cells, [1] DF-decoder cells (they may run concurrently)
-    // (the sub-stage pipeline runs all five cells concurrently: [2] ERB-decoder cell 0, [3] cell 1, [4] DF-decoder cell 1)
     unsigned long long* gru_xbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int gru_xbuf_tiles[5] = {0, 0, 0, 0, 0}; unsigned gru_epoch[5] = {0, 0, 0, 0, 0};
     // stacked decoder pairs (gru256_stack16_kernel): per pair [tiles][Tcap + 2][16][256] granules = cell A's per-frame ring + cell B's two slots
-    // all five cells as one launch (gru256_chain16_kernel): 7 per-frame rings [tiles][Tcap][16][256]
-    unsigned long long* gru_cbuf = nullptr; int gru_cbuf_tiles = 0, gru_cbuf_T = 0; unsigned gru_cepoch = 0;
     unsigned* arrive[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int arrive_tiles[5] = {0, 0, 0, 0, 0}; unsigned arrive_count[5] = {0, 0, 0, 0, 0};   // gru256_step_kernel
     unsigned long long* gru_sbuf[2] = {nullptr, nullptr}; int gru_sbuf_tiles[2] = {0, 0}, gru_sbuf_T[2] = {0, 0}; unsigned gru_sepoch[2] = {0, 0};
     const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; const float* dbg_emb = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
@@ -302,18 +285,14 @@ struct dpdf_model {
     int device = 0;
     hipStream_t stream = nullptr;      // main stream (= lanes[0].sA): I/O, STFT/iSTFT, stage 1 of lane 0
     hipStream_t cur = nullptr;         // stream the helper launchers enqueue on
-    Lane lanes[2]; Lane* ln = nullptr; // current lane of the host-side enqueue loop
-    // bit 0: stage 2 on its own stream; bit 1: ERB encoder branch on its own stream (single-lane runs);
-    // bit 2: split the batch over two lanes; bit 3: DF decoder beside the ERB decoder inside stage 2 (needs bit 0);
-    // bit 4: GRU-256 scans on 8 workgroups per tile when the launch has <= 4 tiles.
-    // 0 = everything serial on the main stream (A/B timing).
-    int overlap = 27;                  // bit 5 (sub-stage pipeline of stage 2 for <= 64 streams) is OFF by default: measured slower (run_stage2_pipe)
-    int pipe_chunk = 128;              // automatic chunk length (frames) of the sub-stage pipeline for small batches
+    Lane lanes[1]; Lane* ln = nullptr; // the execution lane: streams, events, workspace (one per handle)
+    // bit 0: stage 2 on its own stream; bit 1: ERB encoder branch on its own stream; bit 3: DF decoder beside the ERB decoder
+    // inside stage 2 (needs bit 0); bit 4: GRU-256 scans on 8 / 16 workgroups per tile for launches of few tiles.
+    // 0 = everything serial on the main stream (A/B timing).  (Bits 2 and 5 -- two lanes, five-stream sub-stage pipeline --
+    // were measured slower and removed: DESIGN.md section 7; they are ignored.)
+    int overlap = 27;
     int scan4_max_wgs = 512;           // hoisted-input GRU-64 scans on 4-row tiles (gru_scan4.h) while the launch has at most this many workgroups (0 = never)
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
-    // OPT-IN (measured, no gain: DESIGN.md section 7): at most gru256_chain_tiles tiles -> all five GRU-256 cells of stage 2
-    // as one wavefront launch (gru_stack.h: gru256_chain16_kernel)
-    int gru256_chain = 0, gru256_chain_tiles = 2;
     int gru256_stack = 1;              // one or two tiles: the two cells of each decoder stack as one wavefront launch (gru_stack.h)
     int tail_frames = 32;              // throughput regime: frames of the short chunk split off a long last chunk (pipeline drain; 0 = off)
     int gru256_step = 1;               // single-hop streaming: input projection + GRUCell(256) step as one launch per cell
@@ -321,16 +300,11 @@ struct dpdf_model {
     int fcln_gi = 1;                   // small batches: fc + LayerNorm GEMMs of the DPRNN also produce the next recurrence's input projection (fcln_gi.h)
     int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
     int gru256_c16_tiles = 2;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
-    int gru256_pair = 0;               // GRU-256 cluster scans with this many round-robin tiles per cluster (0 = off / 2 / 3 / 4; launches
-                                       // of >= 8 tiles).  Measured and left OFF: DESIGN.md section 7.
-    int gru64_bf16x3 = 0;              // OPT-IN: GRU-64 scans as three-limb bf16 products on the bf16 matrix pipe (gru_bf16x3.h); default 0 = fp32 MFMA;
-                                       // 1 = on, 2 = on without the fused fc + LN forms
     int df_ring = 2;                   // big batches: 1 = df_conv1 + DF pathway conv as one time-walking pass over c0 (df_ring.h), 2 = df_conv0 in it too
     int dec_seg = 1;                   // 48 kHz decoder stages as band-segment tiles with inputs read once (dec_last.h: dec_seg_kernel; 0: gemm_rows producers, A/B)
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
-    bool two_lanes_active = false;
     std::mutex mu;
     float* consts = nullptr;           // device arena
     int* iconsts = nullptr;            // band_start[33] | band_of[F]
@@ -429,8 +403,8 @@ static int with_recovery(dpdf_model* m, Body body) {
     return rc;
 }
 
-// streams + events of one lane; `pipe` adds the three extra streams of the sub-stage pipeline (run_stage2_pipe)
-static int init_lane(Lane& L, bool pipe) {
+// streams + events of the lane
+static int init_lane(Lane& L) {
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     if (!L.sA) {
@@ -440,10 +414,6 @@ static int init_lane(Lane& L, bool pipe) {
         HIP_TRY(hipStreamCreateWithFlags(&L.sC, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithPriority(&L.sD, hipStreamNonBlocking, hi));
         for (int p = 0; p < NRING; ++p) {
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_a[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_be[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_bd[p], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.ev_cd[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_s1[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_s2[p], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&L.ev_fk[p], hipEventDisableTiming));
@@ -454,11 +424,6 @@ static int init_lane(Lane& L, bool pipe) {
         HIP_TRY(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
-    }
-    if (pipe && !L.sE) {
-        HIP_TRY(hipStreamCreateWithPriority(&L.sE, hipStreamNonBlocking, hi));
-        HIP_TRY(hipStreamCreateWithPriority(&L.sF, hipStreamNonBlocking, hi));
-        HIP_TRY(hipStreamCreateWithPriority(&L.sG, hipStreamNonBlocking, hi));
     }
     return DPDF_OK;
 }
@@ -511,14 +476,6 @@ PathW build_path(Arena& A, const Blob& B, const std::string& p) {
     PathW w; w.ps = A.add(ps); w.pb = A.add(pb);
     return w;
 }
-// float -> bf16, round to nearest even (what the device's (__bf16) conversion does), and back
-static inline uint16_t f2bf(float f) {
-    uint32_t u; memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static inline float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 // [dir][wave][part][gate][chunk*4+kb][lane] + bias [dir][4][64]
 GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::string, std::string>>& dirs) {
@@ -560,27 +517,6 @@ GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::str
                 f4[(((size_t)(d * 4 + w) * 64) + k) * 64 + 4 * u + j] = whh[(size_t)(j * 64 + 16 * w + u) * 64 + k] * gate_scale[j];
         }
         g.hh4 = A.add(f4);
-    }
-    {   // bf16x3 limbs of the same (scaled) weights: [dir][wave 4][gate 3][kblock 4][limb 3][lane 64][8] (gru_bf16x3.h)
-        std::vector<uint16_t> limbs((size_t)g.ndirs * 4 * 3 * 4 * 3 * 64 * 8);
-        for (int d = 0; d < g.ndirs; ++d) {
-            const std::string &p = dirs[d].first, &sfx = dirs[d].second;
-            const float* wih = B.get(p + ".weight_ih" + sfx); const float* whh = B.get(p + ".weight_hh" + sfx);
-            for (int w = 0; w < 4; ++w) for (int gate = 0; gate < 3; ++gate) for (int kb = 0; kb < 4; ++kb)
-                for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
-                    const float* W = kb < 2 ? wih : whh;
-                    const int k = 32 * (kb & 1) + 8 * (lane >> 4) + j, col = gate * 64 + 16 * w + (lane & 15);
-                    float r = W[col * 64 + k] * gate_scale[gate];
-                    for (int t = 0; t < 3; ++t) {
-                        const uint16_t l = f2bf(r);
-                        limbs[((((((size_t)(d * 4 + w) * 3 + gate) * 4 + kb) * 3 + t) * 64) + lane) * 8 + j] = l;
-                        r -= bf2f(l);
-                    }
-                }
-        }
-        std::vector<float> packed(limbs.size() / 2);
-        memcpy(packed.data(), limbs.data(), limbs.size() * 2);
-        g.wlimb = A.add(packed);
     }
     {   // the same W_ih (and input-side biases), scaled alike, as an ordinary GEMM operand for gru64_scan_gi_kernel
         std::vector<float> gfrag, gbias;
@@ -685,25 +621,6 @@ std::vector<DprnnW> build_dprnn(Arena& A, const Blob& B, const std::string& p, i
             fi.insert(fi.end(), fi1.begin(), fi1.end());
             w.fci_epi = A.add(fi);
             w.fce_epi = A.add(pack_epi(B.get(q + ".fc_inter.weight"), 64, 0));
-        }
-        {   // bf16x3 limbs of the fc halves: [wave 4][kblock 2][limb 3][lane 64][8], element = W[16 wave + (lane&15)][koff + 32 kblock + 8 (lane>>4) + j]
-            auto pack_limbs = [&](const float* W, int ld, int koff) {
-                std::vector<uint16_t> limbs((size_t)4 * 2 * 3 * 64 * 8);
-                for (int wv = 0; wv < 4; ++wv) for (int kb = 0; kb < 2; ++kb) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
-                    float r = W[(size_t)(16 * wv + (lane & 15)) * ld + koff + 32 * kb + 8 * (lane >> 4) + j];
-                    for (int t = 0; t < 3; ++t) {
-                        const uint16_t l = f2bf(r);
-                        limbs[((((size_t)wv * 2 + kb) * 3 + t) * 64 + lane) * 8 + j] = l;
-                        r -= bf2f(l);
-                    }
-                }
-                std::vector<float> packed(limbs.size() / 2);
-                memcpy(packed.data(), limbs.data(), limbs.size() * 2);
-                return packed;
-            };
-            w.fcl_fwd = A.add(pack_limbs(B.get(q + ".fc_intra.weight"), 128, 0));
-            w.fcl_bwd = A.add(pack_limbs(B.get(q + ".fc_intra.weight"), 128, 64));
-            w.fcl_inter = A.add(pack_limbs(B.get(q + ".fc_inter.weight"), 64, 0));
         }
         v.push_back(w);
     }
@@ -883,53 +800,6 @@ bool run_gru256_stack(dpdf_model* m, const Gru256W& g0, const Gru256W& g1, const
     return true;
 }
 
-// All five GRU-256 cells of stage 2 as one wavefront launch (gru_stack.h: gru256_chain16_kernel) when the launch is one or
-// two tiles.  x: the embedding cell's input [B*Tc][256]; out_e / out_erb / out_df: hidden sequences of the embedding cell
-// and of the second cell of each decoder.  false = not eligible.
-bool run_gru256_chain(dpdf_model* m, const float* x, float* out_e, float* out_erb, float* out_df, float* state, long S, int B, int Tc) {
-    const int ntiles = (B + 15) / 16;
-    if (Tc == 1 && m->gru256_step) return false;
-    if (!m->gru256_chain || !(m->overlap & 16) || !m->use_gru256_cluster || ntiles > m->gru256_chain_tiles) return false;
-    const dpdf_state_layout& SL = m->L;
-    Lane& L = *m->ln;
-    if (ntiles > L.gru_cbuf_tiles || Tc > L.gru_cbuf_T || !L.gru_cbuf || !m->d_err) {
-        if (L.gru_cbuf) { L.sync_all(); (void)hipFree(L.gru_cbuf); L.gru_cbuf = nullptr; }
-        const int nt = std::max(ntiles, L.gru_cbuf_tiles), T = std::max(Tc, L.gru_cbuf_T);
-        const size_t bytes = (size_t)7 * nt * T * 16 * 256 * 8;
-        if (hipMalloc((void**)&L.gru_cbuf, bytes) != hipSuccess) { L.gru_cbuf_tiles = L.gru_cbuf_T = 0; return false; }
-        (void)hipMemsetAsync(L.gru_cbuf, 0, bytes, m->cur);
-        L.gru_cepoch = 0; L.gru_cbuf_tiles = nt; L.gru_cbuf_T = T;
-        if (!m->d_err) {
-            if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return false;
-            (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->cur);
-        }
-    }
-    if (L.gru_cepoch > 0xF0000000u) {
-        (void)hipMemsetAsync(L.gru_cbuf, 0, (size_t)7 * L.gru_cbuf_tiles * L.gru_cbuf_T * 16 * 256 * 8, m->cur);
-        L.gru_cepoch = 0;
-    }
-    run_gru256_proj(m, m->enc_gru, x, L.ws.gi.p, B * Tc);
-    ProfScope ps(m, "gru256_scan");
-    const size_t rsz = (size_t)ntiles * Tc * 16 * 256;
-    unsigned long long* R = L.gru_cbuf;     // rings: 0 E, 1 ERB cell 0, 2 ERB cell 1, 3 DF cell 0, 4 DF cell 1, 5 x ERB, 6 x DF
-    const Gru256W* gw[5] = {&m->enc_gru, &m->ed_gru0, &m->ed_gru1, &m->df_gru0, &m->df_gru1};
-    const int hoff[5] = {SL.emb_gru, SL.erb_dec_gru, SL.erb_dec_gru + 256, SL.df_dec_gru, SL.df_dec_gru + 256};
-    float* outs[5] = {out_e, nullptr, out_erb, nullptr, out_df};
-    const unsigned long long* ups[5] = {nullptr, R + 5 * rsz, R + 1 * rsz, R + 6 * rsz, R + 3 * rsz};
-    Gru256ChainArgs a{};
-    for (int k = 0; k < 5; ++k)
-        a.c[k] = Gru256ChainCell{m->C(gw[k]->hh_frag), m->C(gw[k]->ih_as_hh), m->C(gw[k]->ih_bias), m->C(gw[k]->b_hn), state + hoff[k], outs[k], R + k * rsz, ups[k]};
-    a.gi = L.ws.gi.p;
-    a.w_out = m->C(m->enc_lin_out.raw); a.b_out = m->C(m->enc_lin_out.bias);
-    a.w_ine = m->C(m->ed_lin_in.raw); a.b_ine = m->C(m->ed_lin_in.bias);
-    a.w_ind = m->C(m->df_lin_in.raw); a.b_ind = m->C(m->df_lin_in.bias);
-    a.xr_e = R + 5 * rsz; a.xr_d = R + 6 * rsz;
-    a.h_stride = S; a.B = B; a.Tc = Tc; a.epoch_base = L.gru_cepoch; a.err = m->d_err;
-    L.gru_cepoch += (unsigned)Tc;
-    hipLaunchKernelGGL(gru256_chain16_kernel, dim3(ntiles * 80), dim3(256), 0, m->cur, a);
-    return true;
-}
-
 // One frame per stream: input projection + cell step as ONE launch (gru_stack.h: gru256_step_kernel)
 bool run_gru256_step(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int which) {
     if (!m->gru256_step || !m->use_gru256_cluster || which < 0 || which > 4) return false;
@@ -980,17 +850,9 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
             // blocks, so the resident set always contains whole clusters, these finish, and later blocks get their CUs
             // (2048 clips = 512 workgroups on 256 CUs is covered by tests/test_gpu_fullsize.py).  If the assumption ever
             // fails the spin times out, d_err is raised and the call returns DPDF_E_RUNTIME (check_device_err).
-            // eight workgroups per tile: measured better up to 64 clips, worse from 128 (tools/sweep2.sh)
-            // two interleaved tiles per cluster from 8 tiles (128 streams) on: the launch is throughput-relevant there (it
-            // pins CUs the GRU-64 kernels want) and stage 2 has slack; below that the step latency matters
+            // sixteen / eight workgroups per tile for launches of few tiles (step latency), four from there on (tools/sweep2.sh)
             if ((m->overlap & 16) && ntiles <= m->gru256_c16_tiles) hipLaunchKernelGGL(gru256_cluster16_kernel, dim3(ntiles * 16), dim3(256), 0, m->cur, a);
             else if ((m->overlap & 16) && ntiles <= m->gru256_c8_tiles) hipLaunchKernelGGL(gru256_cluster8_kernel, dim3(ntiles * 8), dim3(256), 0, m->cur, a);
-            else if (m->gru256_pair && ntiles >= 8 && ntiles % m->gru256_pair == 0) {
-                const int nt = m->gru256_pair;
-                if (nt == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(gru256_ring_kernel<4>), dim3(ntiles), dim3(256), 0, m->cur, a);
-                else if (nt == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(gru256_ring_kernel<3>), dim3(ntiles / 3 * 4), dim3(256), 0, m->cur, a);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(gru256_ring_kernel<2>), dim3(ntiles * 2), dim3(256), 0, m->cur, a);
-            }
             else hipLaunchKernelGGL(gru256_cluster_kernel, dim3(ntiles * 4), dim3(256), 0, m->cur, a);
         } else {
             Gru256Args a{gi, out, m->C(g.hh_frag), m->C(g.b_hn), state + hoff, S, B, Tc};
@@ -1016,12 +878,11 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                  float* state, long S, int soff, int B, int Tc) {
     const int M = B * Tc * Fp;
     float* x = xin; float* y = xa;
-    const bool bf3 = m->gru64_bf16x3 != 0;              // opt-in precision mode (gru_bf16x3.h): the scans on the bf16 pipe as three-limb products
-    const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0 && (!bf3 || m->gru64_bf16x3 == 1);
+    const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0;
     const bool fuse_intra = can_fuse && (m->fuse_dprnn == 2 || (long)B * Tc >= 3072);
     const bool fuse_inter = can_fuse && (m->fuse_dprnn == 2 || (long)B * Fp >= 64 * 16);
-    const bool gi_intra = !bf3 && !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
-    const bool gi_inter = !bf3 && !fuse_inter && m->hoist_gi && Tc >= 4 && (size_t)M * 192 <= gibuf.n;
+    const bool gi_intra = !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
+    const bool gi_inter = !fuse_inter && m->hoist_gi && Tc >= 4 && (size_t)M * 192 <= gibuf.n;
     const bool df = Fp >= 48;
     // small batches: each fc + LayerNorm GEMM also computes the input projection of the recurrence that follows it
     // (fcln_gi.h) -- two dependent launches per block fewer
@@ -1035,18 +896,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
         ai.x = x; ai.wfrag = m->C(w.intra.wfrag); ai.bias = m->C(w.intra.bias); ai.hstate = nullptr;
         ai.nrows = B * Tc; ai.nsteps = Fp; ai.rdiv = 1;
         ai.x_hi = (long)Fp * 64; ai.x_lo = 0; ai.x_step = 64;
-        if (fuse_intra && bf3) {
-            {   // forward direction + forward half of fc_intra: pf -> `hin` scratch [rows][Fp][64]
-                ProfScope ps(m, df ? "gru64_epi_bf16x3_kernel<0>/intra_fwd_df" : "gru64_epi_bf16x3_kernel<0>/intra_fwd_erb");
-                Gru64EpiBf3Args ea{ai, (const __bf16*)m->C(w.intra.wlimb), (const __bf16*)m->C(w.fcl_fwd), nullptr, nullptr, nullptr, nullptr, hin};
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_bf16x3_kernel<0>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
-            }
-            {   // backward direction + backward half of fc_intra + pf + ln_intra + residual
-                ProfScope ps(m, df ? "gru64_epi_bf16x3_kernel<2>/intra_bwd_df" : "gru64_epi_bf16x3_kernel<2>/intra_bwd_erb");
-                Gru64EpiBf3Args ea{ai, (const __bf16*)m->C(w.intra.wlimb), (const __bf16*)m->C(w.fcl_bwd), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b), hin, y};
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_bf16x3_kernel<2>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
-            }
-        } else if (fuse_intra) {
+        if (fuse_intra) {
             {   // forward direction: plain scan, hf -> `hin` scratch [rows][Fp][64]
                 ProfScope ps(m, df ? "gru64_scan_kernel/intra_fwd_df" : "gru64_scan_kernel/intra_fwd_erb");
                 ai.out = hin; ai.ndirs = 1; ai.o_hi = (long)Fp * 64; ai.o_lo = 0; ai.o_step = 64; ai.o_dir_off = 0;
@@ -1071,9 +921,6 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                     hipLaunchKernelGGL(gru64_scan4_gi_kernel, dim3((ai.nrows + 3) / 4, 2), dim3(256), 0, m->cur, ai, m->C(w.intra.hh4), (const float*)gibuf.p, 384);
                 else
                     hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const float*)gibuf.p, 384);
-            } else if (bf3) {
-                ProfScope ps(m, df ? "gru64_scan_bf16x3_kernel/intra_df" : "gru64_scan_bf16x3_kernel/intra_erb");
-                hipLaunchKernelGGL(gru64_scan_bf16x3_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const __bf16*)m->C(w.intra.wlimb));
             } else {
                 ProfScope ps(m, df ? "gru64_scan_kernel/intra_df" : "gru64_scan_kernel/intra_erb");
                 hipLaunchKernelGGL(gru64_scan_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai);
@@ -1118,12 +965,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
         ae.x_hi = (long)Tc * Fp * 64; ae.x_lo = 64; ae.x_step = (long)Fp * 64;
         ae.o_hi = ae.x_hi; ae.o_lo = 64; ae.o_step = ae.x_step; ae.o_dir_off = 0;
         ae.h_hi = S; ae.h_lo = 64;
-        if (fuse_inter && bf3) {
-            ProfScope ps(m, df ? "gru64_epi_bf16x3_kernel<1>/inter_df" : "gru64_epi_bf16x3_kernel<1>/inter_erb");
-            ae.out = nullptr;
-            Gru64EpiBf3Args ea{ae, (const __bf16*)m->C(w.inter.wlimb), (const __bf16*)m->C(w.fcl_inter), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_bf16x3_kernel<1>), dim3((ae.nrows + 15) / 16), dim3(256), 0, m->cur, ea);
-        } else if (fuse_inter) {   // inter scan + fc_inter + ln_inter + residual
+        if (fuse_inter) {   // inter scan + fc_inter + ln_inter + residual
             ProfScope ps(m, df ? "gru64_epi_kernel<1>/inter_df" : "gru64_epi_kernel<1>/inter_erb");
             ae.out = nullptr;
             Gru64EpiArgs ea{ae, m->C(w.fce_epi), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
@@ -1141,9 +983,6 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                     hipLaunchKernelGGL(gru64_scan4_gi_kernel, dim3((ae.nrows + 3) / 4, 1), dim3(256), 0, m->cur, ae, m->C(w.inter.hh4), (const float*)gibuf.p, 192);
                 else
                     hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const float*)gibuf.p, 192);
-            } else if (bf3) {
-                ProfScope ps(m, df ? "gru64_scan_bf16x3_kernel/inter_df" : "gru64_scan_bf16x3_kernel/inter_erb");
-                hipLaunchKernelGGL(gru64_scan_bf16x3_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const __bf16*)m->C(w.inter.wlimb));
             } else {
                 ProfScope ps(m, df ? "gru64_scan_kernel/inter_df" : "gru64_scan_kernel/inter_erb");
                 hipLaunchKernelGGL(gru64_scan_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae);
@@ -1232,7 +1071,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     const int B = c.B, Tc = c.Tc, BT = B * Tc;
     const long S = d.state_size;
     float* state = c.state;
-    hipStream_t sA = m->ln->sA, sC = ((m->overlap & 2) && !m->two_lanes_active) ? m->ln->sC : m->ln->sA;
+    hipStream_t sA = m->ln->sA, sC = (m->overlap & 2) ? m->ln->sC : m->ln->sA;
     m->cur = sA;
     if (m->ln->s2_pending[c.parity]) {      // stage 2 of chunk i-2 must be done with this XSet
         HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_s2[c.parity], 0));
@@ -1412,9 +1251,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
                                       hipMemcpyDeviceToDevice, st));
         run_gl_auto(m, m->enc_lin_in, w.embin.p, 1024, w.g256a.p, 256, BT, ACT_RELU);
     }
-    // one or two tiles: all five cells as one wavefront launch (the decoders' linear_in layers are computed in it)
-    const bool chained = run_gru256_chain(m, w.g256a.p, w.g256b.p, w.g256c.p, w.g256f.p, state, S, B, Tc);
-    if (!chained) run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc);
+    run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc);
     {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->enc_lin_out, w.g256b.p, 256, w.emb.p, 512, BT, ACT_RELU);
@@ -1427,14 +1264,13 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     // ---- DF decoder (dpdfnet.py:486-519) ----
     {
         m->cur = sd;
-        float* ga = fork ? w.g256d.p : w.g256a.p; float* gb = fork ? w.g256e.p : w.g256b.p; float* gc = (fork || chained) ? w.g256f.p : w.g256c.p;
+        float* ga = fork ? w.g256d.p : w.g256a.p; float* gb = fork ? w.g256e.p : w.g256b.p; float* gc = fork ? w.g256f.p : w.g256c.p;
         const int which = fork ? 1 : 0;
-        if (!chained) {
+        {
             ProfScope ps(m, "grouped_linear");
             run_gl_auto(m, m->df_lin_in, w.emb.p, 512, ga, 256, BT, ACT_RELU);
         }
-        if (chained) {}
-        else if (!run_gru256_stack(m, m->df_gru0, m->df_gru1, ga, gb, gc, state, S, L.df_dec_gru, B, Tc, which)) {
+        if (!run_gru256_stack(m, m->df_gru0, m->df_gru1, ga, gb, gc, state, S, L.df_dec_gru, B, Tc, which)) {
             run_gru256(m, m->df_gru0, ga, gb, state, S, L.df_dec_gru, B, Tc, which);
             run_gru256(m, m->df_gru1, gb, gc, state, S, L.df_dec_gru + 256, B, Tc, which);
         }
@@ -1462,12 +1298,11 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         m->cur = st;
     }
     // ---- ERB decoder (dpdfnet.py:343-368; 48k hr.py:405-432) ----
-    if (!chained) {
+    {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->ed_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
     }
-    if (chained) {}
-    else if (!run_gru256_stack(m, m->ed_gru0, m->ed_gru1, w.g256a.p, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru, B, Tc, 0)) {
+    if (!run_gru256_stack(m, m->ed_gru0, m->ed_gru1, w.g256a.p, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru, B, Tc, 0)) {
         run_gru256(m, m->ed_gru0, w.g256a.p, w.g256b.p, state, S, L.erb_dec_gru, B, Tc);
         run_gru256(m, m->ed_gru1, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc);
     }
@@ -1493,164 +1328,13 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     return DPDF_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Stage 2 for SMALL batches as a pipeline of sub-stages across chunks.  With few streams a GRU-256 scan step is pure
-// latency (~4.4 us: MFMAs of 16 rows + one cross-CU exchange), and stage 2 is three scans deep (embedding cell ->
-// decoder cell 0 -> decoder cell 1): one 10 s clip = 3 x 1003 dependent steps = 13.2 ms, the whole call.  The cells
-// only depend on each other chunk-wise, so while cell 1 works on chunk i, cell 0 can work on chunk i+1 and the
-// embedding cell on chunk i+2 -- five cells on five streams, the chain three deep only at the pipeline's ends:
-//   sB: import . embedding linears . GRU enc . linear_out            -> emb[parity]          (ev_a)
-//   sE: ERB decoder linear_in . GRU 0                                -> hbe[parity]          (ev_be)
-//   sD: DF  decoder linear_in . GRU 0                                -> hbd[parity]          (ev_bd)
-//   sG: DF  decoder GRU 1 . skip . df_out (+ pathway) -> coefs                               (ev_cd)
-//   sF: ERB decoder GRU 1 . linear_out . decoder convs -> m ; join sG ; FIFO import . mask . deep filter . export (ev_s2)
-// Each stream sees the chunks in order, so every cell's carried state (its own segment of the flat state) stays
-// ordered; tensors that cross streams are double-buffered by chunk parity and are rewritten only after stage 1 of
-// chunk i+2, which waits for ev_s2 of chunk i; per-cell scratch is private to its stream; every cell has its own
-// granule buffer.  coefs / xm are single buffers: sG's write of chunk i+1 waits for the end of chunk i on sF.
-// For <= 64 streams (four GRU-256 tiles: 5 cells x 32 workgroups leave the chip to stage 1); bit 5 of `overlap`.
-// MEASURED AND LEFT OFF (tools/pipe_sweep.py): 1 clip x 10 s 10.3 ms two-stage vs 13.3 / 17.0 / 26.8 ms here at 256- /
-// 128- / 64-frame chunks.  Not the host (it enqueues a whole 10 s call, ~480 launches, in 1.2 ms: tools/enqueue_probe.py):
-// a chunk is ~120 launches of 5-60 us kernels that sit on dependency chains, each chunk costs ~0.4 ms of such latency on
-// the GPU whatever its length, and a deeper pipeline needs MORE, shorter chunks to fill.  The wavefront inside ONE launch
-// (gru_stack.h) is what this became.
-// ------------------------------------------------------------------------------------------------
-int ensure_pipe_ws(dpdf_model* m, int B, int Tc) {
-    Workspace& w = m->ln->ws;
-    if (B <= w.pipeB && Tc <= w.pipeT) return DPDF_OK;
-    m->ln->sync_all();
-    B = std::max(B, w.pipeB); Tc = std::max(Tc, w.pipeT);
-    const size_t BT = (size_t)B * Tc, BTp = (size_t)((B + 15) & ~15) * Tc;
-    int rc;
-#define ENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
-    for (int k = 0; k < NRING; ++k) { ENS(w.embr[k], BT * 512); ENS(w.hbe[k], BTp * 256); ENS(w.hbd[k], BTp * 256); }
-    for (int k = 2; k < NRING; ++k) { rc = ensure_xset(m, w.x[k], B, Tc); if (rc) return rc; }
-    ENS(w.ge_in, BTp * 256); ENS(w.gi3, BTp * 768); ENS(w.gi4, BTp * 768); ENS(w.gi5, BTp * 768);
-#undef ENS
-    w.pipeB = B; w.pipeT = Tc;
-    return DPDF_OK;
-}
-
-int run_stage2_pipe(dpdf_model* m, const ChunkArgs& c) {
-    const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L;
-    Lane& ln = *m->ln; Workspace& w = ln.ws; XSet& x = w.x[c.parity];
-    const int B = c.B, Tc = c.Tc, BT = B * Tc, p = c.parity;
-    const long S = d.state_size;
-    float* state = c.state;
-    float* emb = w.embr[p].p;
-    StateIoArgs sio = make_sio(m, c, x);
-    sio.seg_lo = 4; sio.seg_hi = 6;                    // DF coefs delay / masked-spec FIFOs
-    const float* e3d = x.e3d; const float* c1d = x.c1d;
-    TView e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
-    TView c0v{x.c0.p, Tc + 4, 4, d.D, 64};
-    // ---- sB: embedding (dpdfnet.py:233-241) ----
-    m->cur = ln.sB;
-    HIP_TRY(hipStreamWaitEvent(ln.sB, ln.ev_s1[p], 0));
-    {
-        ProfScope ps(m, "grouped_linear");
-        run_gl_auto(m, m->df_fc_emb, c1d, (size_t)d.Fd * 64, w.embin.p + 512, 1024, BT, ACT_RELU);
-        if (d.is48) run_gl_auto(m, m->enc_erb_fc, e3d, (size_t)d.F3 * 64, w.embin.p, 1024, BT, ACT_RELU);
-        else HIP_TRY(hipMemcpy2DAsync(w.embin.p, 1024 * sizeof(float), e3d, 512 * sizeof(float), 512 * sizeof(float), BT,
-                                      hipMemcpyDeviceToDevice, ln.sB));
-        run_gl_auto(m, m->enc_lin_in, w.embin.p, 1024, w.g256a.p, 256, BT, ACT_RELU);
-    }
-    run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc, 0, w.gi.p);
-    {
-        ProfScope ps(m, "grouped_linear");
-        run_gl_auto(m, m->enc_lin_out, w.g256b.p, 256, emb, 512, BT, ACT_RELU);
-    }
-    HIP_TRY(hipEventRecord(ln.ev_a[p], ln.sB));
-    // ---- sE: ERB decoder, cell 0 ----
-    m->cur = ln.sE;
-    HIP_TRY(hipStreamWaitEvent(ln.sE, ln.ev_a[p], 0));
-    {
-        ProfScope ps(m, "grouped_linear");
-        run_gl_auto(m, m->ed_lin_in, emb, 512, w.ge_in.p, 256, BT, ACT_RELU);
-    }
-    run_gru256(m, m->ed_gru0, w.ge_in.p, w.hbe[p].p, state, S, L.erb_dec_gru, B, Tc, 2, w.gi3.p);
-    HIP_TRY(hipEventRecord(ln.ev_be[p], ln.sE));
-    // ---- sD: DF decoder, cell 0 ----
-    m->cur = ln.sD;
-    HIP_TRY(hipStreamWaitEvent(ln.sD, ln.ev_a[p], 0));
-    {
-        ProfScope ps(m, "grouped_linear");
-        run_gl_auto(m, m->df_lin_in, emb, 512, w.g256d.p, 256, BT, ACT_RELU);
-    }
-    run_gru256(m, m->df_gru0, w.g256d.p, w.hbd[p].p, state, S, L.df_dec_gru, B, Tc, 1, w.gi2.p);
-    HIP_TRY(hipEventRecord(ln.ev_bd[p], ln.sD));
-    // ---- sG: DF decoder, cell 1 + taps (dpdfnet.py:486-519) ----
-    m->cur = ln.sG;
-    HIP_TRY(hipStreamWaitEvent(ln.sG, ln.ev_bd[p], 0));
-    run_gru256(m, m->df_gru1, w.hbd[p].p, w.g256f.p, state, S, L.df_dec_gru + 256, B, Tc, 4, w.gi5.p);
-    {
-        ProfScope ps(m, "grouped_linear");
-        run_gl_auto(m, m->df_skip, emb, 512, w.g256e.p, 256, BT, ACT_NONE);   // c = df_gru(emb) + df_skip(emb)
-    }
-    if (ln.prev_slot >= 0 && ln.s2_pending[ln.prev_slot]) HIP_TRY(hipStreamWaitEvent(ln.sG, ln.ev_s2[ln.prev_slot], 0));   // coefs / dfo of the previous chunk consumed
-    {
-        ProfScope ps(m, "df_coefs");
-        size_t n = (size_t)BT * 256;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(axpy_kernel), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ln.sG, w.g256f.p, w.g256e.p, n);
-        if (x.have_pconv) {
-            const GlW& g = m->df_out;
-            PlainA<16> ap{w.g256f.p, 256, g.Ig, g.Ig};
-            DfOutEpi ep{w.coefs.p, Tc, FastDiv::make(Tc), x.pconv.p, m->C(g.bias), g.Og};
-            launch_gemm_rows<4, 16, false>(ln.sG, ap, m->C(g.frag), ep, BT, g.Ig, g.G);
-        } else {
-            run_gl_auto(m, m->df_out, w.g256f.p, 256, w.dfo.p, (size_t)d.D * 10, BT, ACT_TANH);
-            RowMap rm = RowMap::make(Tc, d.D);
-            ConvpA ap{c0v, rm};
-            ConvpEpi ep{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
-            launch_gemm_rows<1, 64, false>(ln.sG, ap, m->C(m->convp_frag), ep, BT * d.D, 320, 1);
-        }
-    }
-    HIP_TRY(hipEventRecord(ln.ev_cd[p], ln.sG));
-    // ---- sF: ERB decoder, cell 1 + convs (dpdfnet.py:343-368), then mask + deep filter ----
-    m->cur = ln.sF;
-    HIP_TRY(hipStreamWaitEvent(ln.sF, ln.ev_be[p], 0));
-    run_gru256(m, m->ed_gru1, w.hbe[p].p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc, 3, w.gi4.p);
-    float* dembp = w.demb.p;
-    {
-        ProfScope ps(m, "grouped_linear");
-        run_gl_auto(m, m->ed_lin_out, w.g256c.p, 256, w.demb.p, 512, BT, ACT_RELU);
-        if (d.is48) { run_gl_auto(m, m->ed_erb_fc, w.demb.p, 512, w.demb2.p, (size_t)d.F3 * 64, BT, ACT_RELU); dembp = w.demb2.p; }
-    }
-    run_dec_convs(m, x, dembp, B, Tc, ln.sF);
-    HIP_TRY(hipStreamWaitEvent(ln.sF, ln.ev_cd[p], 0));
-    {
-        ProfScope ps(m, "state_io");
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, ln.sF, sio);
-    }
-    run_mask_df(m, c, x, ln.sF);
-    {
-        ProfScope ps(m, "state_io");
-        sio.do_export = 1;
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, ln.sF, sio);
-    }
-    HIP_TRY(hipEventRecord(ln.ev_s2[p], ln.sF)); ln.s2_pending[p] = true;
-    ln.prev_slot = p;
-    ln.dbg_emb = emb;
-    HIP_TRY(hipGetLastError());
-    m->cur = ln.sA;
-    return DPDF_OK;
-}
-
-// all chunks of a [B][T] problem, split over one or two lanes; on return every stream's work is
-// ordered before the main stream
+// all chunks of a [B][T] problem; on return every stream's work is ordered before the main stream
 int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T, float* state,
                float* out, const float* attn_raw, float alpha) {
     const dpdf_dims& d = m->d;
-    const bool two = (m->overlap & 4) && B >= 64;
-    const int G = two ? 2 : 1;
-    int Bg[2] = {B, 0};
-    if (two) { Bg[0] = ((B / 2 + 15) / 16) * 16; Bg[1] = B - Bg[0]; }
-    m->two_lanes_active = two;
     // chunk_frames: >0 explicit, <0 whole sequence, 0 auto (below); small batches: 256 frames per
     // chunk -- a small batch is latency-bound and wants several chunks so that stage 2 of one runs under stage 1 of the
     // next (tools/latency_bench.py --chunks: 1 clip x 10 s 22.0 -> 18.2 ms, 32 clips 39.3 -> 29.7 ms)
-    // <= 64 streams: stage 2 as a pipeline of sub-stages across chunks (run_stage2_pipe); its fill and drain are two
-    // sub-stages long, so it wants shorter chunks than the two-stage pipeline
-    const bool pipe2 = (m->overlap & 32) && (m->overlap & 1) && !two && B <= 64 && m->use_gru256_cluster;
     int chunk = T;
     if (m->chunk_frames > 0) chunk = std::min(m->chunk_frames, T);
     // Throughput regime (>= 96 streams): 192 frames.  The intra-band launches have streams x frames / 16 workgroups and the
@@ -1659,22 +1343,16 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     // 128 clips 58.9 ms at 192 vs 60.1 at 256, 512 clips 207.3 vs 211.3 at 96 -- as long as a chunk stays below 128k frame
     // rows (~33 GB of workspace).  Fewer streams: 256 frames (latency regime, above).
     else if (m->chunk_frames == 0) {
-        if (pipe2) chunk = std::min(T, m->pipe_chunk);
-        else if (Bg[0] < 96) chunk = std::min(T, 256);
-        else chunk = std::min(T, std::min(192, std::max(64, 131072 / Bg[0])));
+        if (B < 96) chunk = std::min(T, 256);
+        else chunk = std::min(T, std::min(192, std::max(64, 131072 / B)));
     }
     int rc;
-    for (int g = 0; g < G; ++g) {
-        m->ln = &m->lanes[g];
-        if ((rc = init_lane(m->lanes[g], pipe2))) { m->ln = &m->lanes[0]; return rc; }
-        if ((rc = ensure_ws(m, Bg[g], chunk))) { m->ln = &m->lanes[0]; return rc; }
-        if (pipe2 && (rc = ensure_pipe_ws(m, Bg[g], chunk))) { m->ln = &m->lanes[0]; return rc; }
-    }
-    if (two) {       // lane 1 starts after everything already queued on the main stream
-        HIP_TRY(hipEventRecord(m->lanes[0].ev_fork, m->stream));
-        HIP_TRY(hipStreamWaitEvent(m->lanes[1].sA, m->lanes[0].ev_fork, 0));
-    }
-    // (Measured and dropped: ending on a quarter-size chunk to shorten the pipeline drain -- 115.0 vs 114.6 ms/step.)
+    m->ln = &m->lanes[0];
+    if ((rc = init_lane(m->lanes[0]))) return rc;
+    if ((rc = ensure_ws(m, B, chunk))) return rc;
+    // (Measured and dropped: ending on a quarter-size chunk to shorten the pipeline drain -- 115.0 vs 114.6 ms/step; splitting
+    // the batch over two independent lanes -- 180 vs 120 ms/step; stage 2 as a five-stream pipeline of sub-stages across
+    // chunks for small batches -- 13.3 vs 10.3 ms for one clip: DESIGN.md section 7.)
     std::vector<int> sizes;
     for (int rem = T; rem > 0; rem -= std::min(chunk, rem)) sizes.push_back(std::min(chunk, rem));
     // Pipeline drain: stage 2 of the LAST chunk has no stage 1 to run under -- its latency-bound GRU-256 scans (three deep,
@@ -1688,26 +1366,13 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     }
     int i = 0, t0 = 0;
     for (size_t ci = 0; ci < sizes.size(); t0 += sizes[ci], ++ci, ++i) {
-        int b0 = 0;
-        for (int g = 0; g < G; ++g) {
-            m->ln = &m->lanes[g];
-            ChunkArgs c{raw + (size_t)b0 * clip_stride + (size_t)t0 * d.F * 2, clip_stride, Bg[g], sizes[ci],
-                        state + (size_t)b0 * d.state_size, out + (size_t)b0 * clip_stride, clip_stride, t0,
-                        attn_raw ? attn_raw + (size_t)b0 * clip_stride : nullptr, alpha, pipe2 ? i % NRING : (i & 1)};
-            if ((rc = run_stage1(m, c)) || (rc = (pipe2 ? run_stage2_pipe(m, c) : run_stage2(m, c)))) { m->ln = &m->lanes[0]; return rc; }
-            b0 += Bg[g];
-        }
+        ChunkArgs c{raw + (size_t)t0 * d.F * 2, clip_stride, B, sizes[ci], state, out, clip_stride, t0, attn_raw, alpha, i & 1};
+        if ((rc = run_stage1(m, c)) || (rc = run_stage2(m, c))) return rc;
     }
-    for (int g = 0; g < G; ++g) {
-        Lane& L = m->lanes[g];
-        for (int p = 0; p < NRING; ++p)
-            if (L.s2_pending[p]) { HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_s2[p], 0)); L.s2_pending[p] = false; }
-        L.prev_slot = -1;
-        if (g > 0) { HIP_TRY(hipEventRecord(L.ev_done, L.sA)); HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_done, 0)); }
-    }
-    m->ln = &m->lanes[0];
+    Lane& L = m->lanes[0];
+    for (int p = 0; p < NRING; ++p)
+        if (L.s2_pending[p]) { HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_s2[p], 0)); L.s2_pending[p] = false; }
     m->cur = m->stream;
-    m->two_lanes_active = false;
     return DPDF_OK;
 }
 
@@ -1856,7 +1521,7 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
     // mapping -- with 14 streams per handle the four active ones of a second handle ended up sharing queues (one
     // 10 s clip 11.5 -> 14.6 ms, one streaming hop 1.33 -> 2.1 ms when measured beside another live handle)
     HIP_TRY(hipSetDevice(device));
-    { int rc_ = init_lane(m->lanes[0], false); if (rc_) return rc_; }
+    { int rc_ = init_lane(m->lanes[0]); if (rc_) return rc_; }
     m->stream = m->lanes[0].sA;
     m->cur = m->stream;
     m->ln = &m->lanes[0];
@@ -1896,13 +1561,12 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
 extern "C" void dpdf_destroy(dpdf_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < 1; ++g) {
         Lane& L = m->lanes[g];
         L.sync_all();
         L.ws.release();
         for (int k = 0; k < 5; ++k) if (L.gru_xbuf[k]) (void)hipFree(L.gru_xbuf[k]);
         for (int k = 0; k < 2; ++k) if (L.gru_sbuf[k]) (void)hipFree(L.gru_sbuf[k]);
-        if (L.gru_cbuf) (void)hipFree(L.gru_cbuf);
         for (int k = 0; k < 5; ++k) if (L.arrive[k]) (void)hipFree(L.arrive[k]);
     }
     DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state, &m->stft_part};
@@ -1916,19 +1580,15 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     for (hipEvent_t e : m->prof_events) if (e) (void)hipEventDestroy(e);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < 1; ++g) {
         Lane& L = m->lanes[g];
         for (int p = 0; p < NRING; ++p) { if (L.ev_s1[p]) (void)hipEventDestroy(L.ev_s1[p]); if (L.ev_s2[p]) (void)hipEventDestroy(L.ev_s2[p]); if (L.ev_fk[p]) (void)hipEventDestroy(L.ev_fk[p]); if (L.ev_jn[p]) (void)hipEventDestroy(L.ev_jn[p]); if (L.ev_dfk[p]) (void)hipEventDestroy(L.ev_dfk[p]); if (L.ev_djn[p]) (void)hipEventDestroy(L.ev_djn[p]); }
         if (L.ev_fork) (void)hipEventDestroy(L.ev_fork);
         if (L.ev_join) (void)hipEventDestroy(L.ev_join);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
-        for (int p = 0; p < NRING; ++p) { if (L.ev_a[p]) (void)hipEventDestroy(L.ev_a[p]); if (L.ev_be[p]) (void)hipEventDestroy(L.ev_be[p]); if (L.ev_bd[p]) (void)hipEventDestroy(L.ev_bd[p]); if (L.ev_cd[p]) (void)hipEventDestroy(L.ev_cd[p]); }
         if (L.sB) (void)hipStreamDestroy(L.sB);
         if (L.sC) (void)hipStreamDestroy(L.sC);
         if (L.sD) (void)hipStreamDestroy(L.sD);
-        if (L.sE) (void)hipStreamDestroy(L.sE);
-        if (L.sF) (void)hipStreamDestroy(L.sF);
-        if (L.sG) (void)hipStreamDestroy(L.sG);
         if (L.sA) (void)hipStreamDestroy(L.sA);
     }
     delete m;
@@ -1973,7 +1633,7 @@ extern "C" int dpdf_set_overlap(dpdf_model* m, int on) {
     if (!m) return set_err(DPDF_E_INVALID, "null model");
     std::lock_guard<std::mutex> lk(m->mu);
     (void)hipSetDevice(m->device);
-    for (int g = 0; g < 2; ++g) m->lanes[g].sync_all();
+    for (int g = 0; g < 1; ++g) m->lanes[g].sync_all();
     m->overlap = on;
     return DPDF_OK;
 }
@@ -1988,17 +1648,13 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     if (!m || !name) return set_err(DPDF_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(m->mu);
     (void)hipSetDevice(m->device);
-    for (int g = 0; g < 2; ++g) m->lanes[g].sync_all();
+    for (int g = 0; g < 1; ++g) m->lanes[g].sync_all();
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
     else if (n == "dec_seg") m->dec_seg = value != 0;
-    else if (n == "gru64_bf16x3") m->gru64_bf16x3 = value < 0 ? 0 : (value > 2 ? 2 : value);   // 1: on (fc + LN fused into the scans for big batches), 2: plain scans + fp32 GEMM fc/LN passes only (A/B)
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (n == "pipe_chunk") m->pipe_chunk = value < 16 ? 16 : value;
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
     else if (n == "scan4_max_wgs") m->scan4_max_wgs = value < 0 ? 0 : value;
-    else if (n == "gru256_chain") m->gru256_chain = value != 0;
-    else if (n == "gru256_chain_tiles") m->gru256_chain_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
     else if (n == "stft_ksplit") m->stft_ksplit = value & 3;
@@ -2007,7 +1663,6 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_c16_tiles") m->gru256_c16_tiles = value < 0 ? 0 : value;
-    else if (n == "gru256_pair") m->gru256_pair = (value >= 2 && value <= 4) ? value : 0;
     else if (n == "gru256_cluster") m->use_gru256_cluster = value != 0;
     else return set_err(DPDF_E_INVALID, "unknown option '%s'", name);
     return DPDF_OK;

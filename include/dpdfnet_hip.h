@@ -138,29 +138,28 @@ size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap);
 /* Set the time-chunk length used by dpdf_enhance_batch (frames per chunk; <=0 = whole clip). */
 int dpdf_set_chunk_frames(dpdf_model* m, int frames);
 /* Execution-shape mask (default 27 = 1|2|8|16): bit 0 stage 2 of chunk i (GRU-256 scans, decoders) on its own HIP stream
- * underneath stage 1 of chunk i+1; bit 1 the ERB encoder branch on its own stream; bit 2 split the batch over two lanes
- * (measured slower, off); bit 3 the DF decoder beside the ERB decoder inside stage 2; bit 4 eight (not four) workgroups per
- * tile in the GRU-256 cluster scans of small launches; bit 5 (off: measured slower -- every chunk is a chain of ~120 dependent small launches) for <= 64
- * streams stage 2 as a pipeline of sub-stages across chunks (the five GRU-256 cells on five streams).  0: everything
- * serial on one stream (A/B timing). */
+ * underneath stage 1 of chunk i+1; bit 1 the ERB encoder branch on its own stream; bit 3 the DF decoder beside the ERB decoder
+ * inside stage 2; bit 4 eight / sixteen (not four) workgroups per tile in the GRU-256 cluster scans of small launches.
+ * 0: everything serial on one stream (A/B timing).  Bits 2 and 5 (two lanes; five-stream sub-stage pipeline) selected forms that
+ * were measured slower and have been removed; they are accepted and ignored. */
 int dpdf_set_overlap(dpdf_model* m, int mask);
 /* Where fc + LayerNorm + residual of every DPRNN block run: 2 always inside the GRU-64 scan kernels;
  * 0 always as separate GEMM kernels; 1 (default) picks per chunk -- fused once streams x frames fills the
  * chip (>= 3072 frame rows), separate below that (single-hop streaming, small batches). */
 int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
 /* Further A/B switches by name (measurement only; results equal to rounding): "fuse_mask" (1: the mask head's 64->1
- * contraction runs in the last decoder GEMM's epilogue, 0: stand-alone kernel), "df_ring" (df_conv1 + DF pathway conv as one time-walking pass over c0 for
- * big batches, 0: two time-parallel GEMM launches), "gru64_bf16x3" (OPT-IN precision mode, default 0; 1 = the GRU-64 scans (and, for big
- * batches, the fc + LayerNorm fused into them) as three-limb bf16 products with fp32 accumulation on the bf16 matrix
- * pipe -- fp32-accurate to rounding, a different instruction mix, never what the headline figure is measured on;
- * 2 = the same without the fused forms), "hoist_gi" (small-batch GRU-64 input
- * GEMM hoisting), "gru256_cluster" (0: single-workgroup GRU-256 scan), "gru256_pair" (0 off (default) / 2 / 3 / 4 round-robin tiles per
- * GRU-256 cluster, gru256_ring_kernel, for launches of >= 8 tiles), "gru256_c8_tiles" / "gru256_c16_tiles" (launches of at most this many 16-row
- * tiles run the GRU-256 scans on 8 / 16 workgroups per tile; defaults 4 / 2), "gru256_stack" (1 (default): launches of at most
- * gru256_c16_tiles tiles run the two cells of each decoder stack as one wavefront launch, gru_stack.h), "gru256_chain" /
- * "gru256_chain_tiles" (opt-in, default 0 / 2: all five GRU-256 cells as one wavefront launch), "tail_frames" (default 32:
- * >= 96 streams, automatic chunking: a last chunk of >= 96 frames gives up a tail chunk of this many frames; 0 off), "fcln_gi" /
- * "hop_glue" / "gru256_step" (small-batch and single-hop launch fusions, fcln_gi.h, gru_stack.h; default 1), "stft_ksplit" (bit 0: STFT of a few 48 kHz frames split over K, bit 1: streaming iSTFT split over K; default 3), "pipe_chunk".  Unknown name -> DPDF_E_INVALID. */
+ * contraction runs in the last decoder stage's epilogue, 0: stand-alone kernel), "dec_seg" (1: the 48 kHz decoder stages as
+ * band-segment tiles, dec_seg_kernel; 0: gemm_rows producers), "df_ring" (df_conv0 + df_conv1 + DF pathway conv as one
+ * time-walking pass for big batches; 0: time-parallel GEMM launches), "hoist_gi" (small-batch GRU-64 input GEMM hoisting),
+ * "scan4_max_wgs" (default 512: hoisted-input GRU-64 scans run on 4-row tiles, gru64_scan4_gi_kernel, while the launch has at
+ * most this many workgroups; 0 never), "gru256_cluster" (0: single-workgroup GRU-256 scan, the form without cross-workgroup
+ * waits), "gru256_c8_tiles" / "gru256_c16_tiles" (launches of at most this many 16-row tiles run the GRU-256 scans on 8 / 16
+ * workgroups per tile; defaults 4 / 2), "gru256_stack" (1: launches of at most gru256_c16_tiles tiles run the two cells of each
+ * decoder stack as one wavefront launch, gru_stack.h), "tail_frames" (default 32: >= 96 streams, automatic chunking: a last
+ * chunk of >= 96 frames gives up a tail chunk of this many frames; 0 off), "fcln_gi" / "hop_glue" / "gru256_step" (small-batch
+ * and single-hop launch fusions, fcln_gi.h, gru_stack.h; default 1), "stft_ksplit" (bit 0: STFT of a few 48 kHz frames split
+ * over K, bit 1: streaming iSTFT split over K; default 3).  Unknown name -> DPDF_E_INVALID.  (Removed after measurement, see
+ * DESIGN.md section 7 and tools/experimental/: "gru64_bf16x3", "gru256_pair", "gru256_chain", "pipe_chunk".) */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);
 
 /* Rational polyphase resampler on the device, for `ensure_sample_rate` when the caller's rate differs from the

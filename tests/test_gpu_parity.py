@@ -102,7 +102,6 @@ def test_stage_tensors_match_reference_probes(case, be):
 
 @pytest.mark.parametrize("chunk", [1, 3, 16, 50])
 def test_time_chunking_and_state_carry_invariance(case, chunk):
-    # both execution shapes of stage 2: the two-stage pipeline (default) and the opt-in sub-stage pipeline (ring of 4 chunk slots)
     """Splitting T frames into chunks (state carried in the reference flat layout) changes nothing;
     chunk = 1 is literally one session.run per frame."""
     g, meta, o, m = case
@@ -111,12 +110,12 @@ def test_time_chunking_and_state_carry_invariance(case, chunk):
     ref, st_ref = m.run_frames(spec, m.initial_state())
     m.set_chunk_frames(chunk)
     out, st = m.run_frames(spec, m.initial_state())
-    m.set_overlap(59)
-    out59, st59 = m.run_frames(spec, m.initial_state())
+    m.set_overlap(0)                            # the same chunks with every kernel on one stream
+    out0, st0 = m.run_frames(spec, m.initial_state())
     m.set_overlap(27)
     m.set_chunk_frames(0)
-    np.testing.assert_allclose(out59, out, atol=1e-5 * K(meta) * float(np.abs(ref).max()))
-    np.testing.assert_allclose(st59, st, rtol=5e-6, atol=2e-5 * K(meta) * max(1.0, meta["nb"] / 4.0))
+    np.testing.assert_allclose(out0, out, atol=1e-5 * K(meta) * float(np.abs(ref).max()))
+    np.testing.assert_allclose(st0, st, rtol=5e-6, atol=2e-5 * K(meta) * max(1.0, meta["nb"] / 4.0))
     np.testing.assert_allclose(out, ref, atol=1e-5 * K(meta) * float(np.abs(ref).max()))
     # different chunk lengths pick different kernel forms of the recurrences (fused / hoisted-input / plain): equal to
     # rounding, and the rounding differences of a DPRNN stack grow with its depth (8 blocks: 2.1e-5 seen on one state value)
@@ -150,7 +149,7 @@ def test_single_frame_chunks_are_race_free_under_stream_overlap(case):
     ref, st_ref = m.run_frames(spec, m.initial_state())
     m.set_chunk_frames(1)
     try:
-        for mask in (27, 59):                   # 59: also the (opt-in) five-stream sub-stage pipeline of stage 2
+        for mask in (27, 19):                   # 19: without the decoder fork
             m.set_overlap(mask)
             for _ in range(40):
                 out, st = m.run_frames(spec, m.initial_state())
@@ -390,14 +389,12 @@ def test_big_batch_kernel_forms_match_small_batch_forms_and_oracle(be, sr, nb):
     ref_probe = {}
     outs = {}
     for tag, opts in (("small_forms", {"df_ring": 0, "fuse_mask": 0}), ("ring_reads_c0", {"df_ring": 1, "fuse_mask": 1}),
-                      ("big_forms", {"df_ring": 2, "fuse_mask": 1}),
-                      ("ring4", {"gru256_pair": 4}), ("ring3", {"gru256_pair": 3}), ("ring2", {"gru256_pair": 2})):
+                      ("big_forms", {"df_ring": 2, "fuse_mask": 1})):
         for k, v in opts.items():
             m.set_option(k, v)
         outs[tag] = m.enhance_batch(wav, 6.0)
         ref_probe[tag] = {k: m.debug_fetch(k) for k in ("c1", "coefs", "m")}
-    m.set_option("gru256_pair", 0)
-    for tag in ("ring_reads_c0", "big_forms", "ring4", "ring3", "ring2"):
+    for tag in ("ring_reads_c0", "big_forms"):
         assert rms(outs[tag] - outs["small_forms"]) < 1e-6, tag
         for k in ("c1", "coefs", "m"):
             a_, b_ = ref_probe[tag][k], ref_probe["small_forms"][k]
@@ -408,45 +405,10 @@ def test_big_batch_kernel_forms_match_small_batch_forms_and_oracle(be, sr, nb):
     m.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("tag", ["16k_nb4", "48k_nb2"])
-def test_optin_bf16x3_gru64_mode_keeps_fp32_parity(tag, mode, be):
-    """OPT-IN precision mode (`dpdf_set_option("gru64_bf16x3", 1)`, csrc/gru_bf16x3.h): the GRU-64 scans as three-limb bf16
-    products with fp32 accumulation.  Same bar as the default fp32-MFMA mode: reference golden waveform within 2e-6 RMS,
-    stage tensors and state within the stage tolerances -- on one clip (small forms) and on a 192-clip batch (big forms)."""
-    g, meta = load_golden(tag)
-    sr, nb = meta["sample_rate"], meta["nb"]
-    blob = golden_blob(meta)
-    m = be.HipModel(sr, nb, blob, 0)
-    o = make_oracle(meta, blob)
-    m.set_option("gru64_bf16x3", mode)          # 1: on (fc + LN fused into the scans for big batches); 2: plain bf16x3 scans + fp32 fc/LN GEMM passes
-    out = m.enhance_batch(g["wav"][None])[0]
-    assert rms(out - g["enhanced"]) < WAVE_TOL, rms(out - g["enhanced"])
-    spec = o.stft(g["wav"])
-    ref, st_ref = o.run_frames(spec)
-    got, st = m.run_frames(spec, m.initial_state())
-    scale = float(np.abs(ref).max())
-    assert np.abs(got - ref).max() < STAGE_REL_TOL * scale and rms(got - ref) < 1e-5 * scale
-    assert np.abs(st - st_ref).max() < 2e-4
-    B, n = 192, int(0.25 * sr) + 17
-    wav = np.stack([synth_clip(n, sr, 5000 + i) * (0.5 + (i % 5) / 5.0) for i in range(B)]).astype(np.float32)
-    big = m.enhance_batch(wav, None)
-    m.set_fuse_dprnn("always")                  # the fused kernels also on the one-clip shapes
-    out1 = m.enhance_batch(g["wav"][None])[0]
-    assert rms(out1 - g["enhanced"]) < WAVE_TOL, rms(out1 - g["enhanced"])
-    m.set_fuse_dprnn("auto")
-    m.set_option("gru64_bf16x3", 0)
-    fp32 = m.enhance_batch(wav, None)
-    assert rms(big - fp32) < 1e-6
-    for b in (0, 100, 191):
-        assert rms(big[b] - o.enhance(wav[b])) < WAVE_TOL, b
-    m.close()
-
-
 def test_every_gru256_scan_form_agrees(be):
     """The forms of the GRU-256 recurrence -- single-workgroup scan (`gru256_cluster` = 0), 4-workgroup cluster, 8- and
-    16-workgroup clusters for small launches, the two cells of a decoder stack / all five cells as one wavefront launch
-    (gru_stack.h) -- on the same input: equal to rounding, state included."""
+    16-workgroup clusters for small launches, the two cells of a decoder stack as one wavefront launch (gru_stack.h) -- on
+    the same input: equal to rounding, state included."""
     g, meta = load_golden("16k_nb1")
     blob = golden_blob(meta)
     m = be.HipModel(meta["sample_rate"], meta["nb"], blob, 0)
@@ -454,18 +416,16 @@ def test_every_gru256_scan_form_agrees(be):
     spec = np.stack([o.stft(synth_clip(3000, 16000, 900 + i)) for i in range(40)])      # 40 streams = 3 tiles
     st0 = np.tile(m.initial_state(), (40, 1))
     outs = {}
-    for tag, opts, ov in (("cluster", {"gru256_c16_tiles": 0, "gru256_cluster": 1, "gru256_stack": 0, "gru256_chain": 0}, 27 & ~16),
+    for tag, opts, ov in (("cluster", {"gru256_c16_tiles": 0, "gru256_cluster": 1, "gru256_stack": 0}, 27 & ~16),
                           ("cluster8", {"gru256_c16_tiles": 0}, 27), ("cluster16", {"gru256_c16_tiles": 4}, 27),
                           ("stack16", {"gru256_c16_tiles": 4, "gru256_stack": 1}, 27), ("stack16_serial", {}, 16),
-                          ("chain16", {"gru256_chain": 1, "gru256_chain_tiles": 4}, 27), ("chain16_serial", {}, 16),
                           ("single_wg", {"gru256_cluster": 0}, 27)):
         for k, v in opts.items():
             m.set_option(k, v)
         m.set_overlap(ov)
         outs[tag] = m.run_frames(spec, st0)
-    m.set_option("gru256_cluster", 1); m.set_option("gru256_c16_tiles", 2); m.set_option("gru256_chain_tiles", 2); m.set_option("gru256_chain", 0); m.set_overlap(27)
+    m.set_option("gru256_cluster", 1); m.set_option("gru256_c16_tiles", 2); m.set_overlap(27)
     assert not np.array_equal(outs["stack16"][0], outs["cluster16"][0])         # the stacked form really ran
-    assert not np.array_equal(outs["chain16"][0], outs["stack16"][0])           # ... and the five-cell chain
     ref, st_ref = outs["cluster"]
     scale = float(np.abs(ref).max())
     for tag, (out, st) in outs.items():
