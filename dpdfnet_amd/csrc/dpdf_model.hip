@@ -33,6 +33,7 @@
 #include "gru_stack.h"
 #include "fcln_gi.h"
 #include "gru_scan4.h"
+#include "small_fused.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -201,7 +202,7 @@ struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs;
                 size_t hh4;                   // W_hh for the 4-row scan (gru_scan4.h): [dir][wave 4][k 64][lane 4u+j]: gate j of unit 16 wave + u (j = 3: zero)
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
-struct GlW { size_t frag, bias, raw; int G, Og, Ig, NT; };   // raw: the reference's [G][Og][Ig] weight as is (gru256_chain16_kernel)
+struct GlW { size_t frag, bias, raw; int G, Og, Ig, NT; };   // raw: [G][Ig][Og] (k-major: lanes of one group read consecutive outputs) for the per-row VALU forms (small_fused.h)
 struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn, ih_as_hh; };   // ih_as_hh: W_ih packed like hh_frag (second cell of a stacked pair, gru_stack.h)   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
                 size_t fci_epi, fce_epi; };   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
@@ -247,10 +248,11 @@ struct Workspace {
     // stage-2 temporaries
     DevBuf embin, g256a, g256b, g256c, gi, emb, demb, demb2, d3, d2, d1, m, dfo, coefs, xm;
     DevBuf g256d, g256e, g256f, gi2;   // DF-decoder chain's own scratch (runs beside the ERB decoder)
+    DevBuf skipb;                      // df_skip(emb) of the fused small-launch form (emb_out_kernel)
     void release() {
         for (int k = 0; k < NRING; ++k) x[k].release();
         DevBuf* all[] = {&feat_erb, &feat_spec, &hcat, &hin, &hcat_e, &hin_e, &gi64, &gi64_e,
-                         &embin, &g256a, &g256b, &g256c, &gi, &g256d, &g256e, &g256f, &gi2, &emb, &demb, &demb2, &d3, &d2, &d1, &m, &dfo, &coefs, &xm};
+                         &embin, &g256a, &g256b, &g256c, &gi, &g256d, &g256e, &g256f, &gi2, &skipb, &emb, &demb, &demb2, &d3, &d2, &d1, &m, &dfo, &coefs, &xm};
         for (DevBuf* b : all) b->release();
         Bcap = Tcap = 0;
     }
@@ -314,6 +316,11 @@ struct dpdf_model {
     int* d_err = nullptr;
     int* d_lens = nullptr; size_t d_lens_cap = 0; std::vector<int> h_lens;   // per-clip lengths of a ragged batch
     int use_gru256_cluster = 1;
+    // single-hop streaming: chores of the call's front end that the fused feature kernel of the hop picks up (feat_hop_kernel):
+    // the sum over K-split STFT partials and the hand-over of the analysis buffers.  Set by streams_enqueue, consumed by stage 1.
+    struct HopExtras { const float* part = nullptr; int ks = 0, W = 0; const float* pcm_new = nullptr; float* in_tail = nullptr; float* snap_in = nullptr; bool armed = false; } hx;
+    int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
+    int hop_feat = 1;                  // single-hop calls: features A + B (+ those chores) as one launch (0: separate kernels, A/B)
     int* pin_progress = nullptr;       // pinned host word: frames of the running offline call whose stage 2 is complete (dpdf_progress)
     bool progress_on = false;          // set by the offline entry points only (a streaming hop does not pay for the extra launch)
     long recoveries = 0;               // calls re-run on the non-spinning GRU-256 kernels after a cluster exchange timed out (dpdf_recovery_count)
@@ -545,7 +552,12 @@ GlW build_gl(Arena& A, const Blob& B, const std::string& p, int G, int Og, int I
     }
     g.frag = A.add(frag);
     g.bias = A.add(std::vector<float>(b, b + (size_t)G * Og));
-    g.raw = A.add(std::vector<float>(w, w + (size_t)G * Og * Ig));
+    {
+        std::vector<float> wt((size_t)G * Og * Ig);
+        for (int gi = 0; gi < G; ++gi) for (int o = 0; o < Og; ++o) for (int k = 0; k < Ig; ++k)
+            wt[((size_t)gi * Ig + k) * Og + o] = w[((size_t)gi * Og + o) * Ig + k];
+        g.raw = A.add(wt);
+    }
     return g;
 }
 Gru256W build_gru256(Arena& A, const Blob& B, const std::string& p) {
@@ -653,6 +665,11 @@ void erb_bands(int nfft, int fs, std::vector<int>& start, std::vector<int>& band
     }
 }
 
+// Row count below which the wide-N GEMMs switch to their narrow-column packing: with <= 8 row tiles the launch is a
+// handful of workgroups walking all K panels one after the other; narrower column blocks multiply the workgroups.
+// Also the limit of the fused small-launch forms (small_fused.h, mask_df_kernel).
+constexpr int SMALL_M_ROWS = 512;
+
 int ensure_xset(dpdf_model* m, XSet& x, int B, int Tc) {
     const dpdf_dims& d = m->d;
     const size_t BT = (size_t)B * Tc;
@@ -702,6 +719,7 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
     ENS(w.embin, BT * 1024); ENS(w.g256a, BTp * 256); ENS(w.g256b, BTp * 256); ENS(w.g256c, BTp * 256);
     ENS(w.gi, BTp * 768); ENS(w.emb, BT * 512); ENS(w.demb, BT * 512);
     ENS(w.g256d, BTp * 256); ENS(w.g256e, BTp * 256); ENS(w.g256f, BTp * 256); ENS(w.gi2, BTp * 768);
+    ENS(w.skipb, std::min(BTp, (size_t)SMALL_M_ROWS + 16) * 256);
     ENS(w.demb2, BT * (size_t)d.F3 * 64);
     ENS(w.d3, BT * d.F2 * 64); ENS(w.d2, BT * d.F1 * 64); ENS(w.d1, BT * d.Ec * 64);
     ENS(w.m, BT * d.E); ENS(w.dfo, BT * d.D * 10);
@@ -746,9 +764,6 @@ void run_gl_auto(dpdf_model* m, const GlW& g, const float* in, size_t lda, float
 }
 
 // SqueezedGRU_S cell: gi = W_ih x + b (all frames, one GEMM) then the recurrent scan
-// Row count below which the wide-N GEMMs switch to their narrow-column packing: with <= 8 row tiles the launch is a
-// handful of workgroups walking all K panels one after the other; narrower column blocks multiply the workgroups.
-constexpr int SMALL_M_ROWS = 512;
 // which: 0 = embedding / ERB-decoder cells (scratch ws.gi, granules [0]); 1 = DF-decoder cells (ws.gi2, granules [1])
 void run_gru256_proj(dpdf_model* m, const Gru256W& g, const float* x, float* gi, int M) {
     ProfScope ps(m, "gru256_proj");
@@ -1086,10 +1101,16 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     {
         ProfScope ps(m, "features");
         FeatAArgs fa{c.raw, c.raw_clip_stride, x.xs.p, w.feat_erb.p, d.is48 ? nullptr : m->iconsts, B, Tc, d.F, d.E, d.is48, d.wnorm};
-        hipLaunchKernelGGL(feat_a_kernel, dim3(BT), dim3(256), 0, sA, fa);
         FeatBArgs fb{w.feat_erb.p, x.xs.p, w.feat_spec.p, state, S, L.erb_norm, L.spec_norm, B, Tc, d.F, d.E, d.D};
-        int nth = ((d.E + d.D + 63) / 64) * 64;
-        hipLaunchKernelGGL(feat_b_kernel, dim3(B), dim3(nth), 0, sA, fb);
+        if (Tc == 1 && m->hx.armed) {      // a streaming hop: one launch, with the front end's chores folded in
+            FeatHopArgs fh{fa, fb, m->hx.part, m->hx.ks, m->hx.W, m->hx.pcm_new, m->hx.in_tail, m->hx.snap_in, d.hop};
+            hipLaunchKernelGGL(feat_hop_kernel, dim3(B), dim3(256), 0, sA, fh);
+            m->hx = dpdf_model::HopExtras{};
+        } else {
+            hipLaunchKernelGGL(feat_a_kernel, dim3(BT), dim3(256), 0, sA, fa);
+            int nth = ((d.E + d.D + 63) / 64) * 64;
+            hipLaunchKernelGGL(feat_b_kernel, dim3(B), dim3(nth), 0, sA, fb);
+        }
     }
     // The DF branch is the longer dependent chain (48 band positions per intra-band scan against 8 / 40) and its kernels are
     // ENQUEUED first: in the latency regime the host is only just ahead of the GPU (~2.5 us per launch), and the ~20 launches of
@@ -1218,9 +1239,14 @@ void run_mask_df(dpdf_model* m, const ChunkArgs& c, XSet& x, hipStream_t st) {
     ProfScope ps(m, "mask_df");
     MaskApplyArgs mk{x.xs.p, w.m.p, w.xm.p, d.is48 ? nullptr : m->iconsts + 33, B, Tc, d.F, d.E};
     size_t total = (size_t)BT * d.F;
-    hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mk);
     DfApplyArgs da{w.xm.p, w.coefs.p, c.out, c.out_clip_stride, c.out_t0, c.attn_raw, c.alpha, (float)(1.0 - (double)c.alpha),
                    B, Tc, d.F, d.D, (float)(1.0 / (double)d.wnorm)};
+    if (m->fuse_small && BT <= SMALL_M_ROWS) {     // latency regime: one launch (mask_df_kernel)
+        MaskDfArgs md{mk, da};
+        hipLaunchKernelGGL(mask_df_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, md);
+        return;
+    }
+    hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mk);
     hipLaunchKernelGGL(df_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, da);
 }
 
@@ -1232,18 +1258,28 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     float* state = c.state;
     hipStream_t st = (m->overlap & 1) ? m->ln->sB : m->ln->sA;
     m->cur = st;
-    if (st != m->ln->sA) HIP_TRY(hipStreamWaitEvent(st, m->ln->ev_s1[c.parity], 0));
     StateIoArgs sio = make_sio(m, c, x);
     sio.seg_lo = 4; sio.seg_hi = 6;                    // DF coefs delay / masked-spec FIFOs
-    {
+    {   // the FIFO import touches stage-2 tensors and stage-2 state only: it runs BEFORE the wait for stage 1 (off the hop's critical chain)
         ProfScope ps(m, "state_io");
         hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, st, sio);
     }
+    if (st != m->ln->sA) HIP_TRY(hipStreamWaitEvent(st, m->ln->ev_s1[c.parity], 0));
     const float* e3d = x.e3d; const float* c1d = x.c1d;
     TView e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
     TView c0v{x.c0.p, Tc + 4, 4, d.D, 64};
     // ---- embedding (dpdfnet.py:233-241; 48k hr.py:285-293).  channels-last [f][c] IS the (f,c) flatten ----
-    {
+    // small launches (streaming hops, single clips): the grouped linears chained per row in one launch each (small_fused.h)
+    // (per-row workgroups re-read every weight per row: a gain for a handful of rows -- one 16 kHz stream 212 -> 205 us per hop --
+    // and a loss from a few dozen on -- 64 x 48 kHz streams 313 -> 340 us -- where the 64-row MFMA tiles of gemm_rows stay)
+    const bool small = m->fuse_small && BT <= 8 && d.Fd * 64 <= 3072 && d.F3 * 64 <= 3072;
+    auto glrow = [&](const GlW& g) { return GlRow{m->C(g.raw), m->C(g.bias), g.G, g.Og, g.Ig}; };
+    if (small) {
+        ProfScope ps(m, "grouped_linear");
+        EmbInArgs ea{c1d, d.Fd * 64, e3d, d.F3 * 64, glrow(m->df_fc_emb), d.is48 ? glrow(m->enc_erb_fc) : GlRow{nullptr, nullptr, 0, 0, 0},
+                     glrow(m->enc_lin_in), w.g256a.p, BT};
+        hipLaunchKernelGGL(emb_in_kernel, dim3(BT), dim3(256), 0, st, ea);
+    } else {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->df_fc_emb, c1d, (size_t)d.Fd * 64, w.embin.p + 512, 1024, BT, ACT_RELU);
         if (d.is48) run_gl_auto(m, m->enc_erb_fc, e3d, (size_t)d.F3 * 64, w.embin.p, 1024, BT, ACT_RELU);
@@ -1252,13 +1288,20 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         run_gl_auto(m, m->enc_lin_in, w.embin.p, 1024, w.g256a.p, 256, BT, ACT_RELU);
     }
     run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc);
-    {
+    const bool fork = (m->overlap & 8) && st != m->ln->sA;
+    float* df_ga = fork ? w.g256d.p : w.g256a.p;
+    if (small && fork) {    // emb, both decoders' linear_in and df_skip in one launch (needs the DF decoder's own scratch: the fork)
+        ProfScope ps(m, "grouped_linear");
+        EmbOutArgs ea{w.g256b.p, glrow(m->enc_lin_out), glrow(m->df_lin_in), glrow(m->ed_lin_in), glrow(m->df_skip),
+                      w.emb.p, df_ga, w.g256a.p, w.skipb.p, BT};
+        hipLaunchKernelGGL(emb_out_kernel, dim3(BT), dim3(256), 0, st, ea);
+    } else {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->enc_lin_out, w.g256b.p, 256, w.emb.p, 512, BT, ACT_RELU);
     }
+    const bool fanned = small && fork;
     // The two decoders only share `emb`: the DF decoder (2 GRU-256 cells, df_out, pathway conv) runs on its own stream
     // beside the ERB decoder (2 cells, transposed convs, mask) -- the five latency-bound cell scans become three deep.
-    const bool fork = (m->overlap & 8) && st != m->ln->sA;
     hipStream_t sd = fork ? m->ln->sD : st;
     if (fork) { HIP_TRY(hipEventRecord(m->ln->ev_dfk[c.parity], st)); HIP_TRY(hipStreamWaitEvent(sd, m->ln->ev_dfk[c.parity], 0)); }
     // ---- DF decoder (dpdfnet.py:486-519) ----
@@ -1266,7 +1309,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         m->cur = sd;
         float* ga = fork ? w.g256d.p : w.g256a.p; float* gb = fork ? w.g256e.p : w.g256b.p; float* gc = fork ? w.g256f.p : w.g256c.p;
         const int which = fork ? 1 : 0;
-        {
+        if (!fanned) {
             ProfScope ps(m, "grouped_linear");
             run_gl_auto(m, m->df_lin_in, w.emb.p, 512, ga, 256, BT, ACT_RELU);
         }
@@ -1274,13 +1317,28 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
             run_gru256(m, m->df_gru0, ga, gb, state, S, L.df_dec_gru, B, Tc, which);
             run_gru256(m, m->df_gru1, gb, gc, state, S, L.df_dec_gru + 256, B, Tc, which);
         }
-        {
+        if (!fanned) {
             ProfScope ps(m, "grouped_linear");
             run_gl_auto(m, m->df_skip, w.emb.p, 512, ga, 256, BT, ACT_NONE);   // c = df_gru(emb) + df_skip(emb)
         }
         {
             ProfScope ps(m, "df_coefs");
             size_t n = (size_t)BT * 256;
+            if (fanned && x.have_pconv) {            // the sum rides in df_out's A producer
+                const GlW& g = m->df_out;
+                SumA<16> ap{gc, w.skipb.p, 256, g.Ig, g.Ig};
+                DfOutEpi ep{w.coefs.p, Tc, FastDiv::make(Tc), x.pconv.p, m->C(g.bias), g.Og};
+                launch_gemm_rows<4, 16, false>(sd, ap, m->C(g.frag), ep, BT, g.Ig, g.G);
+            } else if (fanned) {
+                const GlW& g = m->df_out;
+                SumA<16> ap{gc, w.skipb.p, 256, g.Ig, g.Ig};
+                BiasActStore<4> ep{w.dfo.p, (size_t)d.D * 10, g.Og, m->C(g.bias), g.Og, g.Og, ACT_TANH};
+                launch_gemm_rows<4, 16, false>(sd, ap, m->C(g.frag), ep, BT, g.Ig, g.G);
+                RowMap rm = RowMap::make(Tc, d.D);
+                ConvpA ap2{c0v, rm};
+                ConvpEpi ep2{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
+                launch_gemm_rows<1, 64, false>(sd, ap2, m->C(m->convp_frag), ep2, BT * d.D, 320, 1);
+            } else {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(axpy_kernel), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, sd, gc, ga, n);
             if (x.have_pconv) {      // pathway conv already done in stage 1: df_out's epilogue adds it and writes the taps
                 const GlW& g = m->df_out;
@@ -1294,11 +1352,12 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
                 ConvpEpi ep{w.coefs.p, Tc + 2, rm, w.dfo.p, m->C(m->convp_bias)};
                 launch_gemm_rows<1, 64, false>(sd, ap, m->C(m->convp_frag), ep, BT * d.D, 320, 1);
             }
+            }
         }
         m->cur = st;
     }
     // ---- ERB decoder (dpdfnet.py:343-368; 48k hr.py:405-432) ----
-    {
+    if (!fanned) {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->ed_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
     }
@@ -1306,11 +1365,15 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         run_gru256(m, m->ed_gru0, w.g256a.p, w.g256b.p, state, S, L.erb_dec_gru, B, Tc);
         run_gru256(m, m->ed_gru1, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc);
     }
-    float* dembp = w.demb.p;
-    {
+    float* dembp = d.is48 ? w.demb2.p : w.demb.p;
+    if (small) {
+        ProfScope ps(m, "grouped_linear");
+        DecInArgs da{w.g256c.p, glrow(m->ed_lin_out), d.is48 ? glrow(m->ed_erb_fc) : GlRow{nullptr, nullptr, 0, 0, 0}, w.demb.p, w.demb2.p, d.F3 * 64, BT};
+        hipLaunchKernelGGL(dec_in_kernel, dim3(BT), dim3(256), 0, st, da);
+    } else {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->ed_lin_out, w.g256c.p, 256, w.demb.p, 512, BT, ACT_RELU);
-        if (d.is48) { run_gl_auto(m, m->ed_erb_fc, w.demb.p, 512, w.demb2.p, (size_t)d.F3 * 64, BT, ACT_RELU); dembp = w.demb2.p; }
+        if (d.is48) run_gl_auto(m, m->ed_erb_fc, w.demb.p, 512, w.demb2.p, (size_t)d.F3 * 64, BT, ACT_RELU);
     }
     run_dec_convs(m, x, dembp, B, Tc, st);
     if (fork) { HIP_TRY(hipEventRecord(m->ln->ev_djn[c.parity], sd)); HIP_TRY(hipStreamWaitEvent(st, m->ln->ev_djn[c.parity], 0)); }
@@ -1660,6 +1723,8 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "stft_ksplit") m->stft_ksplit = value & 3;
     else if (n == "gru256_step") m->gru256_step = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
+    else if (n == "hop_feat") m->hop_feat = value != 0;
+    else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_c16_tiles") m->gru256_c16_tiles = value < 0 ? 0 : value;
@@ -1719,7 +1784,8 @@ extern "C" size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap) {
 // Analysis STFT of a FEW frames (streaming hops, tiny clips): one 64-row tile per column group, so the K loop -- win / 64
 // panels, each a round of B-fragment and PCM loads -- is a chain of latencies (one hop of 64 x 48 kHz streams: 118 us of a
 // 1.2 ms hop).  Split five ways over K: the partial sums of every split land side by side and are added in a fixed order.
-static int stft_small(dpdf_model* m, const StftA<64>& ap, float* spec, int M) {
+// defer_sum: leave the partials of a K-split launch in m->stft_part and say so in m->hx (the hop's feature kernel adds them)
+static int stft_small(dpdf_model* m, const StftA<64>& ap, float* spec, int M, bool defer_sum = false) {
     const dpdf_dims& d = m->d;
     // (16 kHz: 5 panels -- the extra summing launch costs what the split saves; 48 kHz: 15 panels, 1222 -> 1175 us per hop)
     const int npan = d.win / 64, ks = ((m->stft_ksplit & 1) && npan >= 10 && npan % 5 == 0) ? 5 : 1, W = m->stft_groups_s * 32;
@@ -1732,6 +1798,7 @@ static int stft_small(dpdf_model* m, const StftA<64>& ap, float* spec, int M) {
     int rc = m->stft_part.ensure((size_t)M * ks * W); if (rc) return rc;
     BiasActStore<2> ep{m->stft_part.p, (size_t)ks * W, 32, nullptr, 0, 32, ACT_NONE};
     launch_gemm_rows<2, 64, false>(m->stream, ap, m->C(m->stft_frag_s), ep, M, d.win, m->stft_groups_s, 2048, ks);
+    if (defer_sum) { m->hx.part = m->stft_part.p; m->hx.ks = ks; m->hx.W = W; return DPDF_OK; }
     const size_t n = (size_t)M * 2 * d.F;
     hipLaunchKernelGGL(ksplit_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, (const float*)m->stft_part.p, spec, M, ks, W, 2 * d.F, (const float*)nullptr);
     return DPDF_OK;
@@ -1943,18 +2010,32 @@ static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* sr
     const dpdf_dims& d = m->d;
     const int S = v.S;
     int rc;
+    // causal analysis (stream.py:119-126): frame j = x[j*hop : j*hop+win] * window -> rfft with x = [analysis buffer | new samples],
+    // both read in place.  The buffers are handed over (in_tail <- last new hop) only after the STFT has read them: by the hop's
+    // fused feature kernel (single-hop calls), else by a small kernel of its own.
+    // A handful of streams: the STFT reads [analysis buffer | new samples] in place -- also when the new samples sit in pinned
+    // host memory (a few KB).  More streams: every column group of the STFT GEMM re-reads its A rows, which must not go over PCIe
+    // 31 times (64 x 48 kHz streams: +70 us) -- the staging kernel copies them into HBM once and hands the buffers over itself.
+    const bool hop_fused = T == 1 && m->hop_feat && S * T <= SMALL_M_ROWS;
+    const bool in_place = S * T <= 4;
+    m->hx = dpdf_model::HopExtras{};
     float* xbuf = s->pcm_in.p;                       // [S][(T+1)*hop]
-    hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, v.in_tail, xbuf, S, T, d.hop, v.snap_in);
-    {   // causal analysis (stream.py:119-126): frame j = xbuf[j*hop : j*hop+win] * window -> rfft.
-        StftA<64> ap{xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
+    if (!in_place) hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, v.in_tail, xbuf, S, T, d.hop, v.snap_in);
+    {
+        StftA<64> ap{in_place ? src : xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
+        if (in_place) ap.tail = v.in_tail;
         if (S * T <= SMALL_M_ROWS) {
-            if ((rc = stft_small(m, ap, s->spec.p, S * T))) return rc;
+            if ((rc = stft_small(m, ap, s->spec.p, S * T, hop_fused))) return rc;
         } else {
             BiasActStore<2> ep{s->spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
             ep.ncol_total = 2 * d.F;
             launch_gemm_rows_wn<2, 64>(m->stream, ap, m->C(m->stft_frag_s), ep, S * T, d.win, m->stft_groups_s / 4);
         }
     }
+    if (hop_fused) {
+        if (in_place) { m->hx.pcm_new = src; m->hx.in_tail = v.in_tail; m->hx.snap_in = v.snap_in; }
+        m->hx.armed = true;
+    } else if (in_place) hipLaunchKernelGGL(stream_tail_update_kernel, dim3(S), dim3(256), 0, m->stream, src, v.in_tail, v.snap_in, T, d.hop);
     if (v.ev_state) HIP_TRY(hipStreamWaitEvent(m->stream, v.ev_state, 0));
     rc = run_chunks(m, s->spec.p, (size_t)T * d.F * 2, S, T, v.state, s->spec_e.p, nullptr, 0.f);
     if (rc) return rc;

@@ -95,6 +95,38 @@ struct PlainA {            // A[r][k] = src[r*lda + grp*gstride + k], zero for k
     }
 };
 
+// A[r][k] = a[r*lda + grp*gstride + k] + b[same]  (DF decoder: c = df_gru(emb) + df_skip(emb), reference onnx_model/dpdfnet.py:503-506,
+// added on the way into df_out instead of by a kernel of its own; small launches)
+template <int KP>
+struct SumA {
+    const float* src; const float* src2; size_t lda; int gstride; int kmax;
+    static constexpr int V = KP / 4, NI = (GEMM_BM * V + 255) / 256;
+    struct Regs { float4 v[NI]; };
+    __device__ __forceinline__ void load(Regs& R, int row0, int kp, int grp, int M) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx / V, c4 = (idx - r * V) * 4;
+            int row = row0 + r, k = kp + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < GEMM_BM * V && row < M && k + 3 < kmax) {
+                const size_t o = (size_t)row * lda + (size_t)grp * gstride + k;
+                const float4 x = *(const float4*)(src + o), y = *(const float4*)(src2 + o);
+                v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+            }
+            R.v[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*As)[KP + 4], const Regs& R, int, int, int, int) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx / V, c4 = (idx - r * V) * 4;
+            if (idx < GEMM_BM * V) *(float4*)&As[r][c4] = R.v[i];
+        }
+    }
+};
+
 // depthwise k(1,3) conv, zero pad 1, frequency stride S, fused in front of the pointwise GEMM
 // (reference Conv2dNormAct separable, onnx_model/layers.py:761-834).  K = C = 64.
 template <int S>
@@ -262,6 +294,8 @@ struct StftA {
     int causal = 0;        // 1: frame t = x[t*hop : t*hop+win] (StreamEnhancer), no centre/reflect padding
     const int* lens = nullptr;   // ragged batch: clip b holds lens[b] <= N valid samples (row stride stays N); its own tail pad,
                                  // reflection point and frame count T_b = 1 + (lens[b] + win) / hop; frames t >= T_b are zero
+    const float* tail = nullptr; // causal streaming: the stream's signal is [tail[b][0:hop] | wav[b][0:N - hop]] (N counts both) --
+                                 // the analysis buffer of the previous call and the new samples, read in place (no staging copy)
     static constexpr int NI = GEMM_BM * KP / 256;
     struct Regs { float v[NI]; };
     __device__ __forceinline__ void load(Regs& R, int row0, int kp, int, int M) const {
@@ -283,7 +317,8 @@ struct StftA {
                     if (j >= np_) j = 2 * (np_ - 1) - j;
                 }
                 const bool live = !lens || t < 1 + np_ / hop;
-                if (live && j >= 0 && j < nb_ && kk < win) v = wav[(size_t)b * N + j] * window[kk];
+                if (live && j >= 0 && j < nb_ && kk < win)
+                    v = (tail ? (j < hop ? tail[(size_t)b * hop + j] : wav[(size_t)b * (N - hop) + (j - hop)]) : wav[(size_t)b * N + j]) * window[kk];
             }
             R.v[i] = v;
         }

@@ -109,6 +109,86 @@ __global__ void feat_b_kernel(FeatBArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// feat_hop_kernel: features A + B for ONE frame per stream (single-hop streaming) as one launch, one workgroup per stream,
+// with the two chores around the analysis STFT of a hop folded in: the sum over the K-split partial spectra (part != null:
+// raw[f] = sum over z, in order, of part[row][z][2 f ..]) and the hand-over of the analysis buffer (in_tail <- the new hop,
+// after the STFT has read the old one; snap_in keeps the pre-call copy for the recovery path).  Same arithmetic, in the same
+// order, as feat_a_kernel + feat_b_kernel at Tc = 1.  A hop is a chain of dependent launches, each ~3 us of host time and
+// ~5 us on the GPU's critical path: three fewer.
+struct FeatHopArgs {
+    FeatAArgs a; FeatBArgs b;
+    const float* part; int ks, W;               // K-split STFT partials [row][ks][W] or null
+    const float* pcm_new; float* in_tail; float* snap_in; int hop;   // null pcm_new: no hand-over
+};
+__global__ __launch_bounds__(256) void feat_hop_kernel(FeatHopArgs h) {
+    __shared__ float pw[512];
+    __shared__ float2 xd_s[128];                 // scaled spectrum of the D lowest bins (SpecNorm input)
+    const FeatAArgs& a = h.a; const FeatBArgs& fb = h.b;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (h.pcm_new) {
+        for (int i = tid; i < h.hop; i += 256) {
+            const size_t o = (size_t)b * h.hop + i;
+            if (h.snap_in) h.snap_in[o] = h.in_tail[o];
+            h.in_tail[o] = h.pcm_new[o];
+        }
+    }
+    const float* src = a.raw + (size_t)b * a.raw_clip_stride;
+    float* xd = a.xs + ((size_t)b * 3 + 2) * a.F * 2;
+    float* fe = a.feat_erb + ((size_t)b * 3 + 2) * a.E;
+    for (int f = tid; f < a.F; f += 256) {
+        float2 v;
+        if (h.part) {
+            const float* p = h.part + (size_t)b * h.ks * h.W + 2 * f;
+            v = *(const float2*)p;
+            for (int z = 1; z < h.ks; ++z) { const float2 q = *(const float2*)(p + (size_t)z * h.W); v.x += q.x; v.y += q.y; }
+        } else v = *(const float2*)(src + 2 * f);
+        v.x *= a.wnorm; v.y *= a.wnorm;
+        *(float2*)(xd + 2 * f) = v;
+        if (f < fb.D) xd_s[f] = v;
+        const float p = v.x * v.x + v.y * v.y;
+        pw[f] = a.is48 ? 10.0f * log10f(sqrtf(p) + 1e-10f) : p;
+    }
+    __syncthreads();
+    const float al = 0.98f, be = (float)(1.0 - 0.98);
+    for (int j = tid; j < a.E + fb.D; j += 256) {
+        if (j < a.E) {
+            float x;
+            if (a.is48) x = pw[j];
+            else {
+                const int s = a.band_start[j], n = a.band_start[j + 1] - s;
+                const float inv = 1.0f / (float)n;
+                float acc = 0.f;
+                for (int k = 0; k < n; ++k) acc += pw[s + k] * inv;
+                x = 10.0f * log10f(acc + 1e-10f);
+            }
+            float mu = fb.state[b * fb.S + fb.off_erb + j];
+            mu = al * mu + be * x;
+            fe[j] = (x - mu) / 40.0f;
+            fb.state[b * fb.S + fb.off_erb + j] = mu;
+        } else {
+            const int f = j - a.E;
+            float s = fb.state[b * fb.S + fb.off_spec + f];
+            const float2 v = xd_s[f];
+            const float mag = sqrtf(v.x * v.x + v.y * v.y);
+            s = al * s + be * mag;
+            const float den = sqrtf(s + 1e-12f);
+            float* o = fb.feat_spec + ((size_t)b * 3 + 2) * 2 * fb.D + f;
+            o[0] = v.x / den; o[fb.D] = v.y / den;
+            fb.state[b * fb.S + fb.off_spec + f] = s;
+        }
+    }
+}
+// the hand-over of the analysis buffers alone, for calls of several hops (after the STFT has read the old tails)
+__global__ void stream_tail_update_kernel(const float* pcm_new, float* in_tail, float* snap_in, int n_hops, int hop) {
+    const int s = blockIdx.x;
+    for (int i = threadIdx.x; i < hop; i += blockDim.x) {
+        const size_t o = (size_t)s * hop + i;
+        if (snap_in) snap_in[o] = in_tail[o];
+        in_tail[o] = pcm_new[(size_t)s * n_hops * hop + (size_t)(n_hops - 1) * hop + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // erb_conv0: dense Conv2d 1->64 k(3,3) over (3 frames, bands) + folded BN + ReLU
 // (reference onnx_model/dpdfnet.py:74-81, 206-211; 48 kHz runs on bins [0,480) hr.py:263).
 struct Conv0ErbArgs {
@@ -281,6 +361,65 @@ __global__ void df_apply_kernel(DfApplyArgs a) {
     }
     o[0] = re; o[1] = im;
 }
+
+// mask_apply_kernel + df_apply_kernel as ONE launch for small launches (streaming hops, single clips: a dependent launch is
+// ~3 us of host time and ~5 us on the GPU's critical path, the arithmetic is nothing): thread (b, t, f) masks its own frame,
+// stores it (the masked-spectrum FIFO is exported from xm) and takes the five deep-filter taps from the imported history
+// (frames before the chunk) or by masking the chunk's frames again itself -- same products, same order as the two kernels.
+struct MaskDfArgs { MaskApplyArgs mk; DfApplyArgs df; };
+__global__ void mask_df_kernel(MaskDfArgs a) {
+    const MaskApplyArgs& k = a.mk; const DfApplyArgs& d = a.df;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)k.B * k.Tc * k.F;
+    if (idx >= total) return;
+    const int f = (int)(idx % k.F);
+    const size_t bt = idx / k.F;
+    const int b = (int)(bt / k.Tc), t = (int)(bt - (size_t)b * k.Tc);
+    const int band = k.band_of ? k.band_of[f] : f;
+    auto masked = [&](int tt) {                 // masked frame tt of the chunk (what mask_apply_kernel stores at xm index 4 + tt)
+        const float g = k.m[((size_t)b * k.Tc + tt) * k.Em + band];
+        float2 v = *(const float2*)(k.xs + (((size_t)b * (k.Tc + 2) + tt) * k.F + f) * 2);
+        v.x *= g; v.y *= g;
+        return v;
+    };
+    const float2 own = masked(t);
+    *(float2*)(k.xm + (((size_t)b * (k.Tc + 4) + 4 + t) * k.F + f) * 2) = own;
+    auto tap = [&](int n) {                     // xm index t + n
+        const int j = t + n;
+        if (n == 4) return own;
+        if (j < 4) return *(const float2*)(d.xm + (((size_t)b * (d.Tc + 4) + j) * d.F + f) * 2);
+        return masked(j - 4);
+    };
+    float re, im;
+    if (f < d.D) {
+        const float* c = d.coefs + (((size_t)b * (d.Tc + 2) + t) * d.D + f) * 10;
+        float rr = 0.f, ii = 0.f, ri = 0.f, ir = 0.f;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            const float2 s = tap(n);
+            const float cr = c[2 * n], ci = c[2 * n + 1];
+            rr += s.x * cr; ii += s.y * ci; ri += s.x * ci; ir += s.y * cr;
+        }
+        re = rr - ii; im = ri + ir;
+    } else {
+        const float2 s = tap(2);
+        re = s.x; im = s.y;
+    }
+    re *= d.inv_wnorm; im *= d.inv_wnorm;
+    const int tg = d.out_t0 + t;
+    float* o = d.out + (size_t)b * d.out_clip_stride + ((size_t)tg * d.F + f) * 2;
+    if (d.raw) {
+        float nr = 0.f, ni = 0.f;
+        if (tg >= 4) {
+            const float* r = d.raw + (size_t)b * d.out_clip_stride + ((size_t)(tg - 4) * d.F + f) * 2;
+            nr = r[0]; ni = r[1];
+        }
+        re = d.alpha * nr + d.beta * re;
+        im = d.alpha * ni + d.beta * im;
+    }
+    o[0] = re; o[1] = im;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // overlap-add + window-sum-square normalisation + centre trim + 2*win alignment shift + fit to N
