@@ -319,6 +319,7 @@ struct dpdf_model {
     // single-hop streaming: chores of the call's front end that the fused feature kernel of the hop picks up (feat_hop_kernel):
     // the sum over K-split STFT partials and the hand-over of the analysis buffers.  Set by streams_enqueue, consumed by stage 1.
     struct HopExtras { const float* part = nullptr; int ks = 0, W = 0; const float* pcm_new = nullptr; float* in_tail = nullptr; float* snap_in = nullptr; bool armed = false; } hx;
+    int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int hop_feat = 1;                  // single-hop calls: features A + B (+ those chores) as one launch (0: separate kernels, A/B)
     int* pin_progress = nullptr;       // pinned host word: frames of the running offline call whose stage 2 is complete (dpdf_progress)
@@ -337,7 +338,7 @@ struct dpdf_model {
     size_t window, stft_frag_s, istft_frag;
     int stft_groups_s, istft_groups, istft_K;
     DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state, stft_part;
-    int stft_ksplit = 3;               // few frames: bit 0 STFT split five ways over K (stft_small), bit 1 streaming iSTFT split seven ways (summed by the overlap-add kernel)
+    int stft_ksplit = 7;               // few frames: bit 0 STFT split five ways over K (stft_small), bit 1 streaming iSTFT split seven ways (summed by the overlap-add kernel)
     // profiling
     bool prof_on = false;
     std::map<std::string, ProfEntry> prof;
@@ -949,7 +950,11 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                                m->C(w.inter.wfrag), m->C(w.inter.bias), state + soff + (long)bi * Fp * 64, S, 64, Fp,
                                m->C(w.fce_frag), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b),
                                gibuf.p, next ? m->C(blocks[bi + 1].intra.ih_frag) : nullptr, next ? m->C(blocks[bi + 1].intra.ih_bias) : nullptr, M};
-                if (next) hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue_kernel<true>), dim3((M + 15) / 16), dim3(256), 0, m->cur, ha);
+                if (m->glue8) {      // eight waves per tile: half the dependent MFMAs and operand loads per wave (fcln_gi.h)
+                    if (next) hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue8_kernel<true>), dim3((M + 15) / 16), dim3(512), 0, m->cur, ha);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue8_kernel<false>), dim3((M + 15) / 16), dim3(512), 0, m->cur, ha);
+                }
+                else if (next) hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue_kernel<true>), dim3((M + 15) / 16), dim3(256), 0, m->cur, ha);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue_kernel<false>), dim3((M + 15) / 16), dim3(256), 0, m->cur, ha);
                 intra_gi_ready = next;
                 float* freed = x == xin ? xb : x;
@@ -1163,13 +1168,15 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     }
     m->cur = sA;
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_jn[c.parity], sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_jn[c.parity], 0)); }
+    // stage 2 may start here: the FIFO export below only reads stage-1 tensors that stage 2 does not write, and writes state
+    // segments stage 2 does not touch -- it runs beside the first kernels of stage 2 instead of in front of them
+    HIP_TRY(hipEventRecord(m->ln->ev_s1[c.parity], sA));
     {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;
         hipLaunchKernelGGL(state_io_kernel, dim3(B, 4, 5), dim3(256), 0, sA, sio);
     }
     m->ln->dbg_e3d = x.e3d; m->ln->dbg_c1d = x.c1d; m->ln->dbg_B = B; m->ln->dbg_Tc = Tc; m->ln->dbg_parity = c.parity;
-    HIP_TRY(hipEventRecord(m->ln->ev_s1[c.parity], sA));
     HIP_TRY(hipGetLastError());
     return DPDF_OK;
 }
@@ -1184,7 +1191,8 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
     TView dembv{dembp, Tc, 0, d.F3, 64};
     TView d3v{w.d3.p, Tc, 0, d.F2, 64}, d2v{w.d2.p, Tc, 0, d.F1, 64}, d1v{w.d1.p, Tc, 0, d.Ec, 64};
     const bool geo16 = m->fuse_mask && !d.is48 && d.s1 == 2 && d.s2 == 2 && d.s3 == 1 && d.Ec == 32 && d.F1 == 16 && d.F2 == 8 && d.F3 == 8;
-    const bool geo48 = m->dec_seg && d.is48 && m->fuse_mask && d.s3 == 2 && d.s2 == 2 && d.s1 == 3 && d.F2 % 80 == 0 && d.F1 % 80 == 0 && d.Ec % 96 == 0;
+    const bool geo48 = m->dec_seg && BT >= 1024 && d.is48 &&   // (few frames: the gemm_rows forms spread over more workgroups: 64 x 48 kHz streams, one hop 767 -> 753 us)
+                        m->fuse_mask && d.s3 == 2 && d.s2 == 2 && d.s1 == 3 && d.F2 % 80 == 0 && d.F1 % 80 == 0 && d.Ec % 96 == 0;
     if (geo48) {    // 48 kHz geometry: tiles of 80 / 80 / 96 output bands of one frame, inputs loaded once (dec_last.h: dec_seg_kernel)
         const long cap = 256 * 2 * 4;
         DecSegArgs a3{x.e3.p, dembp, w.d3.p, m->C(m->conv3p.ps), m->C(m->conv3p.pb), m->C(m->convt3.dw), m->C(m->convt3.pwfrag), m->C(m->convt3.bias),
@@ -1720,10 +1728,11 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "scan4_max_wgs") m->scan4_max_wgs = value < 0 ? 0 : value;
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
-    else if (n == "stft_ksplit") m->stft_ksplit = value & 3;
+    else if (n == "stft_ksplit") m->stft_ksplit = value & 7;
     else if (n == "gru256_step") m->gru256_step = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
     else if (n == "hop_feat") m->hop_feat = value != 0;
+    else if (n == "glue8") m->glue8 = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
@@ -1788,7 +1797,9 @@ extern "C" size_t dpdf_profile_report(dpdf_model* m, char* buf, size_t cap) {
 static int stft_small(dpdf_model* m, const StftA<64>& ap, float* spec, int M, bool defer_sum = false) {
     const dpdf_dims& d = m->d;
     // (16 kHz: 5 panels -- the extra summing launch costs what the split saves; 48 kHz: 15 panels, 1222 -> 1175 us per hop)
-    const int npan = d.win / 64, ks = ((m->stft_ksplit & 1) && npan >= 10 && npan % 5 == 0) ? 5 : 1, W = m->stft_groups_s * 32;
+    // a hop whose feature kernel adds the partials anyway (defer_sum): one K panel per workgroup, the summing is free there
+    const int npan = d.win / 64, W = m->stft_groups_s * 32;
+    const int ks = !(m->stft_ksplit & 1) ? 1 : (defer_sum && (m->stft_ksplit & 4)) ? npan : (npan >= 10 && npan % 5 == 0) ? 5 : 1;
     if (ks == 1) {
         BiasActStore<2> ep{spec, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
         ep.ncol_total = 2 * d.F;

@@ -298,3 +298,187 @@ __global__ __launch_bounds__(256) void dprnn_hop_glue_kernel(HopGlueArgs g) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// dprnn_hop_glue8_kernel<NEXT>: the same launch on EIGHT waves per 16-row tile.  A hop's glue launch is a chain of short
+// dependent phases on one workgroup per tile -- with four waves 240 MFMAs and 240 weight registers per wave, loaded up front;
+// here wave (wc = w & 3, wk = w >> 2) owns output columns [16 wc, 16 wc + 16) of every phase and half of its work:
+//   fc_intra: K half wk (16 MFMAs), halves summed by the LayerNorm pass;   inter-band GRU: wk = 0 the x part, wk = 1 the h part,
+//   the h part's three accumulators handed over through LDS;   fc_inter: K half wk (8 MFMAs);   next gi: three of the 24
+//   (direction x gate, column tile) pairs (48 MFMAs) -- 120 MFMAs and 120 weight registers per wave.
+// Same operands, same packings; sums are taken in a different order than the four-wave form (equal to rounding).
+template <bool NEXT>
+__global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[16][132];
+    __shared__ __attribute__((aligned(16))) float Fs[2][16][68];
+    __shared__ __attribute__((aligned(16))) float Ys[16][68];      // y1, later y2
+    __shared__ __attribute__((aligned(16))) float Hs[16][68];      // h, later h'
+    __shared__ __attribute__((aligned(16))) float Gs[4][3][4][64]; // h-part accumulators of the wk = 1 waves
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int wc = w & 3, wk = w >> 2;
+    const int cl = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    {
+        const int r = tid >> 5, c4 = tid & 31;
+        int row = row0 + r; if (row >= g.M) row = g.M - 1;
+        *(float4*)&As[r][4 * c4] = *(const float4*)(g.hcat + (size_t)row * 128 + 4 * c4);
+    }
+    const bool ln_role = tid < 256;                                  // row-contiguous pieces: row tid >> 4, columns 4 (tid & 15) .. + 3
+    const int rr = (tid >> 4) & 15, rc4 = 4 * (tid & 15);
+    const bool rok = row0 + rr < g.M;
+    const int grow = rok ? row0 + rr : g.M - 1;
+    float4 xres = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ln_role) {
+        xres = *(const float4*)(g.x + (size_t)grow * 64 + rc4);
+        const float* hp = g.hstate + (long)(grow / g.rdiv) * g.h_hi + (long)(grow % g.rdiv) * g.h_lo + rc4;
+        *(float4*)&Hs[rr][rc4] = *(const float4*)hp;
+    }
+    // operands of this wave, all up front
+    float wg[3][16];                                                 // wk = 0: W_ih, wk = 1: W_hh (units [16 wc, 16 wc + 16))
+    {
+        const float* wp = g.wfrag + ((size_t)wc * 2 + wk) * 3 * 16 * 64 + lane;
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wg[gt][j] = wp[(size_t)(gt * 16 + j) * 64];
+    }
+    const float b_r = g.bias[16 * wc + cl], b_z = g.bias[64 + 16 * wc + cl], b_in = g.bias[128 + 16 * wc + cl], b_hn = g.bias[192 + 16 * wc + cl];
+    float ffi[16], ffe[8], fih[NEXT ? 48 : 1];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int kk = 16 * wk + k; ffi[k] = g.fci_frag[(size_t)((((kk >> 2) * 4 + wc) * 4 + (kk & 3)) * 64) + lane]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int kk = 8 * wk + k; ffe[k] = g.fce_frag[(size_t)((((kk >> 2) * 4 + wc) * 4 + (kk & 3)) * 64) + lane]; }
+    if (NEXT) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int pr = w + 8 * p, gp = pr >> 2, tile = pr & 3;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) fih[p * 16 + k] = g.ih_frag[(size_t)gp * 4096 + (size_t)((((k >> 2) * 4 + tile) * 4 + (k & 3)) * 64) + lane];
+        }
+    }
+    const float bfi = g.fci_b[16 * wc + cl], bfe = g.fce_b[16 * wc + cl];
+    __syncthreads();
+    auto layer_norm_res = [&](const float4 v, const float4 res, const float* gam, const float* bet) {
+        const float mean = row16_allreduce_sum(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        const float s2 = row16_allreduce_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+        const float inv = rsqrtf(s2 * (1.0f / 64.0f) + 1e-5f);
+        const float4 gg = *(const float4*)(gam + rc4), bb = *(const float4*)(bet + rc4);
+        float4 o;
+        o.x = res.x + d0 * inv * gg.x + bb.x; o.y = res.y + d1 * inv * gg.y + bb.y;
+        o.z = res.z + d2 * inv * gg.z + bb.z; o.w = res.w + d3 * inv * gg.w + bb.w;
+        return o;
+    };
+    // ---- fc_intra: K half wk
+    {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            const float4 a4 = *(const float4*)&As[cl][64 * wk + 16 * c + 4 * q], b4 = *(const float4*)&As[cl][64 * wk + 16 * c + 16 + 4 * q];
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv4[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                acc0 = mfma16(av[kb], ffi[c * 4 + kb], acc0);
+                acc1 = mfma16(bv4[kb], ffi[(c + 1) * 4 + kb], acc1);
+            }
+        }
+        const float bv = wk ? 0.f : bfi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Fs[wk][4 * q + i][16 * wc + cl] = acc0[i] + acc1[i] + bv;
+    }
+    __syncthreads();
+    float4 y1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ln_role) {
+        const float4 u = *(const float4*)&Fs[0][rr][rc4], v2 = *(const float4*)&Fs[1][rr][rc4];
+        y1 = layer_norm_res(make_float4(u.x + v2.x, u.y + v2.y, u.z + v2.z, u.w + v2.w), xres, g.lni_g, g.lni_b);
+        *(float4*)&Ys[rr][rc4] = y1;
+    }
+    __syncthreads();
+    // ---- inter-band GRUCell step: wk = 0 the x part, wk = 1 the h part
+    float hn[4];
+    {
+        f32x4 a0, a1, a2;
+        if (wk == 0) { a0 = (f32x4){b_r, b_r, b_r, b_r}; a1 = (f32x4){b_z, b_z, b_z, b_z}; a2 = (f32x4){b_in, b_in, b_in, b_in}; }
+        else { a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0; a2 = (f32x4){b_hn, b_hn, b_hn, b_hn}; }
+        const float (*src)[68] = wk ? Hs : Ys;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 x4 = *(const float4*)&src[cl][16 * c + 4 * q];
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                a0 = mfma16(xv[kb], wg[0][c * 4 + kb], a0);
+                a1 = mfma16(xv[kb], wg[1][c * 4 + kb], a1);
+                a2 = mfma16(xv[kb], wg[2][c * 4 + kb], a2);
+            }
+        }
+        if (wk == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { Gs[wc][0][i][lane] = a0[i]; Gs[wc][1][i][lane] = a1[i]; Gs[wc][2][i][lane] = a2[i]; }
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                hn[i] = gru64_cell(a0[i] + Gs[wc][0][i][lane], a1[i] + Gs[wc][1][i][lane], a2[i], Gs[wc][2][i][lane], Hs[4 * q + i][16 * wc + cl]);
+        }
+        __syncthreads();                      // every wave has read h
+        if (wk == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Hs[4 * q + i][16 * wc + cl] = hn[i];
+        }
+    }
+    __syncthreads();
+    if (ln_role && rok) {      // h' back into the carried state (row-contiguous pieces)
+        float* hp = g.hstate + (long)(grow / g.rdiv) * g.h_hi + (long)(grow % g.rdiv) * g.h_lo + rc4;
+        *(float4*)hp = *(const float4*)&Hs[rr][rc4];
+    }
+    // ---- fc_inter on h': K half wk
+    {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        const float4 a4 = *(const float4*)&Hs[cl][32 * wk + 4 * q], b4 = *(const float4*)&Hs[cl][32 * wk + 16 + 4 * q];
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv4[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            acc0 = mfma16(av[kb], ffe[kb], acc0);
+            acc1 = mfma16(bv4[kb], ffe[4 + kb], acc1);
+        }
+        const float bv = wk ? 0.f : bfe;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Fs[wk][4 * q + i][16 * wc + cl] = acc0[i] + acc1[i] + bv;
+    }
+    __syncthreads();
+    if (ln_role) {
+        const float4 u = *(const float4*)&Fs[0][rr][rc4], v2 = *(const float4*)&Fs[1][rr][rc4];
+        const float4 y2 = layer_norm_res(make_float4(u.x + v2.x, u.y + v2.y, u.z + v2.z, u.w + v2.w), y1, g.lne_g, g.lne_b);
+        if (rok) *(float4*)(g.y2 + (size_t)(row0 + rr) * 64 + rc4) = y2;
+        if (NEXT) *(float4*)&Ys[rr][rc4] = y2;   // the x-part waves read y1 out of Ys three barriers ago
+    }
+    if (NEXT) {
+        __syncthreads();
+        float4 y4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y4[c] = *(const float4*)&Ys[cl][16 * c + 4 * q];
+        f32x4 acc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float yv[4] = {y4[c].x, y4[c].y, y4[c].z, y4[c].w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) acc[p] = mfma16(yv[kb], fih[NEXT ? p * 16 + c * 4 + kb : 0], acc[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int pr = w + 8 * p, col = (pr >> 2) * 64 + (pr & 3) * 16 + cl;
+            const float bv = g.ih_bias[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + 4 * q + i;
+                if (row < g.M) g.gi[(size_t)row * 384 + col] = acc[p][i] + bv;
+            }
+        }
+    }
+}
