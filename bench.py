@@ -558,7 +558,7 @@ def main() -> None:
                 "timing": f"HIP events on the launching stream around every launch of {psteps} steps run right after the timed "
                           "region in the same execution shape (the timed region itself runs with these events off: "
                           f"{1e3 * dt / args.steps:.2f} ms/step timed vs {prof_ms:.2f} ms/step with events)",
-                "reproduce": ("profiles/r2_serial_kernel_stats.csv" if serial_mode else "profiles/r2_pipelined_kernel_stats.csv")
+                "reproduce": ("profiles/r3_serial_kernel_stats.csv" if serial_mode else "profiles/r3_pipelined_kernel_stats.csv")
                              + ": rocprofv3 --kernel-trace --stats of `python bench.py --no-isolated --no-other-configs --no-cpu-baseline "
                                "--no-pcie" + (" --overlap 0`" if serial_mode else "`") + " -- every launch of that run has this execution "
                                "shape, so the CSV's AverageNs for the kernel is this avg_launch_ms (profiles/README.md)",
@@ -577,7 +577,7 @@ def main() -> None:
                 roofline["frac_note"] = ("`frac` divides by the launch duration seen INSIDE the 4-stream pipeline, where the kernel "
                                          "shares the CUs with three other streams (faster pipeline => longer individual launches); "
                                          "`frac_isolated` is the same kernel, same launches, run back to back in the extra serial "
-                                         "step (= profiles/r2_serial_kernel_stats.csv, the --overlap 0 run); `whole_path_frac` is "
+                                         "step (= profiles/r3_serial_kernel_stats.csv, the --overlap 0 run); `whole_path_frac` is "
                                          "frames/s x FLOP/frame over the fp32 MFMA peak")
                 roofline["roofline_isolated"] = {
                     "note": "one extra step AFTER the timed region with the stream pipeline switched off (kernels back to back)",

@@ -293,6 +293,7 @@ struct dpdf_model {
     // 0 = everything serial on the main stream (A/B timing).  (Bits 2 and 5 -- two lanes, five-stream sub-stage pipeline --
     // were measured slower and removed: DESIGN.md section 7; they are ignored.)
     int overlap = 27;
+    int inter_fuse_rows = 1024;        // inter-band scan: fused form (fc + LN inside the scan) from this many (stream, band) rows on, hoisted-input form below
     int scan4_max_wgs = 512;           // hoisted-input GRU-64 scans on 4-row tiles (gru_scan4.h) while the launch has at most this many workgroups (0 = never)
     int hoist_gi = 1;                  // small chunks: input-side GRU-64 GEMM hoisted out of the scans
     int gru256_stack = 1;              // one or two tiles: the two cells of each decoder stack as one wavefront launch (gru_stack.h)
@@ -693,8 +694,8 @@ int ensure_ws(dpdf_model* m, int B, int Tc) {
         // so checked on every call; growing waits for the streams like the rest of the workspace.
         const dpdf_dims& d = m->d;
         const size_t BT = (size_t)B * Tc, bt_small = std::min(BT, (size_t)3071);
-        const size_t need_d = std::max(bt_small * d.Fd * 384, (size_t)B * d.Fd < 64 * 16 ? BT * d.Fd * 192 : (size_t)0);
-        const size_t need_e = std::max(bt_small * d.F3 * 384, (size_t)B * d.F3 < 64 * 16 ? BT * d.F3 * 192 : (size_t)0);
+        const size_t need_d = std::max(bt_small * d.Fd * 384, (long)B * d.Fd < m->inter_fuse_rows ? BT * d.Fd * 192 : (size_t)0);
+        const size_t need_e = std::max(bt_small * d.F3 * 384, (long)B * d.F3 < m->inter_fuse_rows ? BT * d.F3 * 192 : (size_t)0);
         if (need_d > w.gi64.n || need_e > w.gi64_e.n) {
             m->ln->sync_all();
             int rc = w.gi64.ensure(need_d); if (rc) return rc;
@@ -896,7 +897,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
     float* x = xin; float* y = xa;
     const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0;
     const bool fuse_intra = can_fuse && (m->fuse_dprnn == 2 || (long)B * Tc >= 3072);
-    const bool fuse_inter = can_fuse && (m->fuse_dprnn == 2 || (long)B * Fp >= 64 * 16);
+    const bool fuse_inter = can_fuse && (m->fuse_dprnn == 2 || (long)B * Fp >= m->inter_fuse_rows);
     const bool gi_intra = !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
     const bool gi_inter = !fuse_inter && m->hoist_gi && Tc >= 4 && (size_t)M * 192 <= gibuf.n;
     const bool df = Fp >= 48;
@@ -1726,6 +1727,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
     else if (n == "scan4_max_wgs") m->scan4_max_wgs = value < 0 ? 0 : value;
+    else if (n == "inter_fuse_rows") m->inter_fuse_rows = value < 16 ? 16 : value;
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
     else if (n == "stft_ksplit") m->stft_ksplit = value & 7;
