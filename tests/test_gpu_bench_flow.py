@@ -40,9 +40,13 @@ def test_single_gpu_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "mfma" and 0.0 < rf["frac"] < 1.0
-    assert "profiles/r2_pipelined_kernel_stats.csv" in rf["reproduce"]
+    assert "profiles/r3_pipelined_kernel_stats.csv" in rf["reproduce"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["reference_runtime"]["kind"] == "ort"            # the optional onnxruntime leg: measured, or reported as absent with the reason
+    # the timed step's own output against the oracle, on the line (16 clips here: slots 0 / 8 / 15)
+    assert d["parity"]["ok"] is True and d["parity"]["rms_max"] < d["parity"]["tol"] and len(d["parity"]["clips"]) == 3
+    assert d["value_hbm_resident"] == d["value"]
     # the H2D/D2H-inclusive figure rides on the same line and can only be slower than the HBM-resident one
     assert 0 < d["value_incl_pcie"] <= d["value"] * 1.05 and d["pcie"]["finite_output"] is True
 
