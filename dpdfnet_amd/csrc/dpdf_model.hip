@@ -1436,6 +1436,13 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
         sizes.back() = last - m->tail_frames;
         sizes.push_back(m->tail_frames);
     }
+    // Stage 2 imports its FIFOs BEFORE it waits for stage 1 of the chunk (run_stage2), so nothing else orders the stage-2 stream
+    // behind what the caller queued on the main stream in front of this call -- the upload or the initialisation of the very
+    // state that import reads.  One event at the head of the call does.
+    if (m->overlap & 1) {
+        HIP_TRY(hipEventRecord(m->lanes[0].ev_fork, m->stream));
+        HIP_TRY(hipStreamWaitEvent(m->lanes[0].sB, m->lanes[0].ev_fork, 0));
+    }
     int i = 0, t0 = 0;
     for (size_t ci = 0; ci < sizes.size(); t0 += sizes[ci], ++ci, ++i) {
         ChunkArgs c{raw + (size_t)t0 * d.F * 2, clip_stride, B, sizes[ci], state, out, clip_stride, t0, attn_raw, alpha, i & 1};
