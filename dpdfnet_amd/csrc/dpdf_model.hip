@@ -934,7 +934,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                     BiasActStore<4> ep{gibuf.p, 384, 64, m->C(w.intra.ih_bias), 64, 64, ACT_NONE};
                     launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.intra.ih_frag), ep, M, 64, 6);
                 }
-                if (((ai.nrows + 3) / 4) * 2 <= m->scan4_max_wgs)
+                if (((ai.nrows + 3) / 4) * 2 <= m->scan4_max_wgs && (size_t)M * 384 < (1u << 30))     // (32-bit lane offsets in the kernel)
                     hipLaunchKernelGGL(gru64_scan4_gi_kernel, dim3((ai.nrows + 3) / 4, 2), dim3(256), 0, m->cur, ai, m->C(w.intra.hh4), (const float*)gibuf.p, 384);
                 else
                     hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const float*)gibuf.p, 384);
@@ -1000,7 +1000,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                     BiasActStore<4> ep{gibuf.p, 192, 64, m->C(w.inter.ih_bias), 64, 64, ACT_NONE};
                     launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.inter.ih_frag), ep, M, 64, 3);
                 }
-                if ((ae.nrows + 3) / 4 <= m->scan4_max_wgs)
+                if ((ae.nrows + 3) / 4 <= m->scan4_max_wgs && (size_t)M * 384 < (1u << 30))
                     hipLaunchKernelGGL(gru64_scan4_gi_kernel, dim3((ae.nrows + 3) / 4, 1), dim3(256), 0, m->cur, ae, m->C(w.inter.hh4), (const float*)gibuf.p, 192);
                 else
                     hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ae.nrows + 15) / 16, 1), dim3(256), 0, m->cur, ae, (const float*)gibuf.p, 192);

@@ -63,18 +63,24 @@ __global__ __launch_bounds__(256) void gru64_scan4_gi_kernel(Gru64Args a, const 
     }
     const int unit = 16 * w + u;
     const float b_hn = a.bias[(size_t)dir * 256 + 192 + unit];
-    // pre-transpose role of this lane: gate j of `unit` for rows 0..3 (register i = row i); j = 3 carries the candidate's x part
+    // pre-transpose role of this lane: gate j of `unit` for rows 0..3 (register i = row i); j = 3 carries the candidate's x part.
+    // Addressing: one wave-uniform base pointer per tensor, advanced by a scalar add per step, + a 32-bit lane offset (the host
+    // keeps these launches below 2^30 elements) -- recomputing 64-bit positions per step cost ~70 scalar instructions in front of
+    // the MFMA block of every step, a fifth of the step with one wave per SIMD and nothing to hide them under.
     const int gcol = dir * 192 + (j == 0 ? 0 : (j == 1 ? 64 : 128)) + unit;
-    long g_off[4];
+    unsigned g_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int rc = row0 + i; if (rc >= a.nrows) rc = a.nrows - 1;
-        g_off[i] = ((long)(rc / a.rdiv) * a.x_hi + (long)(rc % a.rdiv) * a.x_lo) / 64 * gw + gcol;
+        g_off[i] = (unsigned)(((long)(rc / a.rdiv) * a.x_hi + (long)(rc % a.rdiv) * a.x_lo) / 64 * gw + gcol);
     }
     const long gstep = a.x_step / 64 * gw;
+    const long gdelta = dir ? -gstep : gstep;
     // post-transpose role: (row j, unit)
     int rj = row0 + j; const bool ok = rj < a.nrows; if (!ok) rj = a.nrows - 1;
-    float* op = a.out + (long)(rj / a.rdiv) * a.o_hi + (long)(rj % a.rdiv) * a.o_lo + dir * a.o_dir_off + unit;
+    const unsigned o_off = (unsigned)((long)(rj / a.rdiv) * a.o_hi + (long)(rj % a.rdiv) * a.o_lo + dir * a.o_dir_off + unit);
+    const long odelta = dir ? -a.o_step : a.o_step;
+    float* ocur = a.out + (dir ? (long)(a.nsteps - 1) * a.o_step : 0);                  // wave-uniform
     float* hp = a.hstate ? a.hstate + (long)(rj / a.rdiv) * a.h_hi + (long)(rj % a.rdiv) * a.h_lo + unit : nullptr;
     float h_own = hp ? *hp : 0.f;
     Hs[0][lane * 4 + w] = h_own;
@@ -83,12 +89,12 @@ __global__ __launch_bounds__(256) void gru64_scan4_gi_kernel(Gru64Args a, const 
     // lookahead leaves the scan waiting on them at the top of every step
     constexpr int PF = 4;
     float g[PF][4];
+    const float* gnext = gi + (dir ? (long)(a.nsteps - 1) * gstep : 0);                 // wave-uniform: rows of the step being fetched
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-        const int sd = d < a.nsteps ? d : a.nsteps - 1;
-        const float* gp = gi + (long)(dir ? a.nsteps - 1 - sd : sd) * gstep;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[d][i] = gp[g_off[i]];
+        for (int i = 0; i < 4; ++i) g[d][i] = gnext[g_off[i]];
+        if (d + 1 < a.nsteps) gnext += gdelta;                                          // (clamped at the last step)
     }
     __syncthreads();
     int buf = 0;
@@ -96,12 +102,10 @@ __global__ __launch_bounds__(256) void gru64_scan4_gi_kernel(Gru64Args a, const 
         f32x4 acc0, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc0[i] = j == 2 ? b_hn : gs[i];
-        {   // refill this ring slot for step s + PF, in front of the MFMA block (see gru64_scan_gi_kernel)
-            const int sn = s + PF < a.nsteps ? s + PF : a.nsteps - 1;
-            const float* gp = gi + (long)(dir ? a.nsteps - 1 - sn : sn) * gstep;
+        // refill this ring slot for step s + PF, in front of the MFMA block (see gru64_scan_gi_kernel)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gs[i] = gp[g_off[i]];
-        }
+        for (int i = 0; i < 4; ++i) gs[i] = gnext[g_off[i]];
+        if (s + PF + 1 < a.nsteps) gnext += gdelta;
         __builtin_amdgcn_sched_barrier(0);
         const float4 h4 = *(const float4*)&Hs[buf][lane * 4];
         const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
@@ -111,7 +115,8 @@ __global__ __launch_bounds__(256) void gru64_scan4_gi_kernel(Gru64Args a, const 
         const float h = gru64_cell(acc[0], acc[1], acc[3], acc[2], h_own);
         h_own = h;
         Hs[buf ^ 1][lane * 4 + w] = h;
-        if (ok) op[(long)(dir ? a.nsteps - 1 - s : s) * a.o_step] = h;
+        if (ok) ocur[o_off] = h;
+        ocur += odelta;
         __syncthreads();
         buf ^= 1;
     };
