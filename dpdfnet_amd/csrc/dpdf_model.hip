@@ -271,6 +271,8 @@ struct Lane {
     hipEvent_t ev_fk[NRING] = {}, ev_jn[NRING] = {};   // ERB-branch fork/join, per chunk-ring slot
     hipEvent_t ev_dfk[NRING] = {}, ev_djn[NRING] = {}; // decoder fork/join inside stage 2
     bool s2_pending[NRING] = {};
+    hipEvent_t ev_x2 = nullptr; bool x2_pending = false;   // behind the stage-2 FIFO export of the latest chunk (joined at the END of a call: run_chunks / join_export)
+    bool mask_from_sums = false;                       // this chunk's mask is still three tap sums per band in ws.d1 (run_dec_convs -> run_mask_df)
     Workspace ws;
     // GRU-256 cluster exchange granules: [0] embedding + ERB-decoder cells, [1] DF-decoder cells (they may run concurrently)
     unsigned long long* gru_xbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int gru_xbuf_tiles[5] = {0, 0, 0, 0, 0}; unsigned gru_epoch[5] = {0, 0, 0, 0, 0};
@@ -431,6 +433,7 @@ static int init_lane(Lane& L) {
             HIP_TRY(hipEventCreateWithFlags(&L.ev_djn[p], hipEventDisableTiming));
         }
         HIP_TRY(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.ev_x2, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
     }
@@ -1189,6 +1192,7 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
     m->cur = st;
     TView e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
     ProfScope ps(m, "dec_convs");
+    m->ln->mask_from_sums = false;
     TView dembv{dembp, Tc, 0, d.F3, 64};
     TView d3v{w.d3.p, Tc, 0, d.F2, 64}, d2v{w.d2.p, Tc, 0, d.F1, 64}, d1v{w.d1.p, Tc, 0, d.Ec, 64};
     const bool geo16 = m->fuse_mask && !d.is48 && d.s1 == 2 && d.s2 == 2 && d.s3 == 1 && d.Ec == 32 && d.F1 == 16 && d.F2 == 8 && d.F3 == 8;
@@ -1231,8 +1235,12 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
         // w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
         if (d.s1 == 2) run_subpix_mask<2>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
         else run_subpix_mask<3>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
-        MaskFinArgs mf{w.d1.p, w.m.p, m->c0out_bias, BT * d.Ec, d.Ec, d.E, d.is48};
-        hipLaunchKernelGGL(mask_fin_kernel, dim3((BT * d.Ec + 255) / 256), dim3(256), 0, st, mf);
+        // small launches at 48 kHz: the tap sums are finished inside mask_df_kernel (one launch fewer on the hop's chain)
+        m->ln->mask_from_sums = m->fuse_small && d.is48 && BT <= SMALL_M_ROWS;
+        if (!m->ln->mask_from_sums) {
+            MaskFinArgs mf{w.d1.p, w.m.p, m->c0out_bias, BT * d.Ec, d.Ec, d.E, d.is48};
+            hipLaunchKernelGGL(mask_fin_kernel, dim3((BT * d.Ec + 255) / 256), dim3(256), 0, st, mf);
+        }
     } else {
         run_subpix_s(m, m->convt1, m->conv1p, e1v, d2v, d1v, B, Tc, d.s1);
         MaskOutArgs ma{x.e0.p, w.d1.p, w.m.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias,
@@ -1251,7 +1259,7 @@ void run_mask_df(dpdf_model* m, const ChunkArgs& c, XSet& x, hipStream_t st) {
     DfApplyArgs da{w.xm.p, w.coefs.p, c.out, c.out_clip_stride, c.out_t0, c.attn_raw, c.alpha, (float)(1.0 - (double)c.alpha),
                    B, Tc, d.F, d.D, (float)(1.0 / (double)d.wnorm)};
     if (m->fuse_small && BT <= SMALL_M_ROWS) {     // latency regime: one launch (mask_df_kernel)
-        MaskDfArgs md{mk, da};
+        MaskDfArgs md{mk, da, m->ln->mask_from_sums ? w.d1.p : nullptr, m->c0out_bias, d.Ec};
         hipLaunchKernelGGL(mask_df_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, md);
         return;
     }
@@ -1387,13 +1395,16 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     run_dec_convs(m, x, dembp, B, Tc, st);
     if (fork) { HIP_TRY(hipEventRecord(m->ln->ev_djn[c.parity], sd)); HIP_TRY(hipStreamWaitEvent(st, m->ln->ev_djn[c.parity], 0)); }
     run_mask_df(m, c, x, st);
+    if (m->progress_on && m->pin_progress) hipLaunchKernelGGL(progress_kernel, dim3(1), dim3(1), 0, st, m->pin_progress, c.out_t0 + Tc);
+    // the chunk's output is complete HERE: whoever waits for stage 2 (the next-but-one chunk's stage 1 for this XSet, the caller's
+    // iSTFT) does not wait for the FIFO export behind it, which only moves stage-2 tensors into stage-2 state segments
+    if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_s2[c.parity], st)); m->ln->s2_pending[c.parity] = true; }
     {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;
         hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, st, sio);
     }
-    if (m->progress_on && m->pin_progress) hipLaunchKernelGGL(progress_kernel, dim3(1), dim3(1), 0, st, m->pin_progress, c.out_t0 + Tc);
-    if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_s2[c.parity], st)); m->ln->s2_pending[c.parity] = true; }
+    if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_x2, st)); m->ln->x2_pending = true; }
     m->ln->dbg_emb = w.emb.p;
     HIP_TRY(hipGetLastError());
     m->cur = m->ln->sA;
@@ -1401,8 +1412,15 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
 }
 
 // all chunks of a [B][T] problem; on return every stream's work is ordered before the main stream
+// The main stream behind the last chunk's stage-2 FIFO export: the state is complete.  run_chunks does this itself unless the
+// caller asks to do it later (a streaming hop: after the iSTFT and the overlap-add, which do not need the state).
+int join_export(dpdf_model* m) {
+    Lane& L = m->lanes[0];
+    if (L.x2_pending) { HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_x2, 0)); L.x2_pending = false; }
+    return DPDF_OK;
+}
 int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T, float* state,
-               float* out, const float* attn_raw, float alpha) {
+               float* out, const float* attn_raw, float alpha, bool defer_export_join = false) {
     const dpdf_dims& d = m->d;
     // chunk_frames: >0 explicit, <0 whole sequence, 0 auto (below); small batches: 256 frames per
     // chunk -- a small batch is latency-bound and wants several chunks so that stage 2 of one runs under stage 1 of the
@@ -1452,6 +1470,7 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     for (int p = 0; p < NRING; ++p)
         if (L.s2_pending[p]) { HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_s2[p], 0)); L.s2_pending[p] = false; }
     m->cur = m->stream;
+    if (!defer_export_join) return join_export(m);
     return DPDF_OK;
 }
 
@@ -1663,6 +1682,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
         Lane& L = m->lanes[g];
         for (int p = 0; p < NRING; ++p) { if (L.ev_s1[p]) (void)hipEventDestroy(L.ev_s1[p]); if (L.ev_s2[p]) (void)hipEventDestroy(L.ev_s2[p]); if (L.ev_fk[p]) (void)hipEventDestroy(L.ev_fk[p]); if (L.ev_jn[p]) (void)hipEventDestroy(L.ev_jn[p]); if (L.ev_dfk[p]) (void)hipEventDestroy(L.ev_dfk[p]); if (L.ev_djn[p]) (void)hipEventDestroy(L.ev_djn[p]); }
         if (L.ev_fork) (void)hipEventDestroy(L.ev_fork);
+        if (L.ev_x2) (void)hipEventDestroy(L.ev_x2);
         if (L.ev_join) (void)hipEventDestroy(L.ev_join);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
         if (L.sB) (void)hipStreamDestroy(L.sB);
@@ -2057,7 +2077,7 @@ static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* sr
         m->hx.armed = true;
     } else if (in_place) hipLaunchKernelGGL(stream_tail_update_kernel, dim3(S), dim3(256), 0, m->stream, src, v.in_tail, v.snap_in, T, d.hop);
     if (v.ev_state) HIP_TRY(hipStreamWaitEvent(m->stream, v.ev_state, 0));
-    rc = run_chunks(m, s->spec.p, (size_t)T * d.F * 2, S, T, v.state, s->spec_e.p, nullptr, 0.f);
+    rc = run_chunks(m, s->spec.p, (size_t)T * d.F * 2, S, T, v.state, s->spec_e.p, nullptr, 0.f, true);
     if (rc) return rc;
     {
         PlainA<48> ap{s->spec_e.p, (size_t)2 * d.F, 0, 2 * d.F};
@@ -2079,7 +2099,7 @@ static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* sr
         }
     }
     HIP_TRY(hipGetLastError());
-    return DPDF_OK;
+    return join_export(m);          // the state is complete behind this point of the main stream
 }
 
 // The body of a streaming call on device-visible buffers (src / dst: device memory or pinned host memory), all streams or

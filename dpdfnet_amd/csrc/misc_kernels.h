@@ -366,7 +366,9 @@ __global__ void df_apply_kernel(DfApplyArgs a) {
 // ~3 us of host time and ~5 us on the GPU's critical path, the arithmetic is nothing): thread (b, t, f) masks its own frame,
 // stores it (the masked-spectrum FIFO is exported from xm) and takes the five deep-filter taps from the imported history
 // (frames before the chunk) or by masking the chunk's frames again itself -- same products, same order as the two kernels.
-struct MaskDfArgs { MaskApplyArgs mk; DfApplyArgs df; };
+// ssum != null (48 kHz, small launches): the mask itself is finished here as well (mask_fin_kernel's sum of the three taps +
+// sigmoid, reference dpdfnet_48khz_hr.py:428 incl. the reflect-padded last bin) and written to mk.m for the frame's own thread.
+struct MaskDfArgs { MaskApplyArgs mk; DfApplyArgs df; const float* ssum; float bias0; int Ec; };
 __global__ void mask_df_kernel(MaskDfArgs a) {
     const MaskApplyArgs& k = a.mk; const DfApplyArgs& d = a.df;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -376,8 +378,18 @@ __global__ void mask_df_kernel(MaskDfArgs a) {
     const size_t bt = idx / k.F;
     const int b = (int)(bt / k.Tc), t = (int)(bt - (size_t)b * k.Tc);
     const int band = k.band_of ? k.band_of[f] : f;
+    auto gain = [&](int tt) {
+        if (!a.ssum) return k.m[((size_t)b * k.Tc + tt) * k.Em + band];
+        const int fe = f == a.Ec ? a.Ec - 2 : f;                         // F.pad reflect (0, 1): m[Ec] = m[Ec - 2]
+        const size_t row = ((size_t)b * k.Tc + tt) * a.Ec + fe;
+        float acc = a.ssum[row * 4 + 1];
+        if (fe > 0) acc += a.ssum[(row - 1) * 4 + 0];
+        if (fe + 1 < a.Ec) acc += a.ssum[(row + 1) * 4 + 2];
+        return sigmoid_f(acc + a.bias0);
+    };
     auto masked = [&](int tt) {                 // masked frame tt of the chunk (what mask_apply_kernel stores at xm index 4 + tt)
-        const float g = k.m[((size_t)b * k.Tc + tt) * k.Em + band];
+        const float g = gain(tt);
+        if (a.ssum && tt == t) const_cast<float*>(k.m)[((size_t)b * k.Tc + tt) * k.Em + band] = g;
         float2 v = *(const float2*)(k.xs + (((size_t)b * (k.Tc + 2) + tt) * k.F + f) * 2);
         v.x *= g; v.y *= g;
         return v;
