@@ -33,7 +33,7 @@
 #include "gru_stack.h"
 #include "fcln_gi.h"
 #include "gru_scan4.h"
-#include "small_fused.h"
+#include "small_fused_mfma.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -202,7 +202,7 @@ struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs;
                 size_t hh4;                   // W_hh for the 4-row scan (gru_scan4.h): [dir][wave 4][k 64][lane 4u+j]: gate j of unit 16 wave + u (j = 3: zero)
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
-struct GlW { size_t frag, bias, raw; int G, Og, Ig, NT; };   // raw: [G][Ig][Og] (k-major: lanes of one group read consecutive outputs) for the per-row VALU forms (small_fused.h)
+struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
 struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn, ih_as_hh; };   // ih_as_hh: W_ih packed like hh_frag (second cell of a stacked pair, gru_stack.h)   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
                 size_t fci_epi, fce_epi; };   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
@@ -248,7 +248,7 @@ struct Workspace {
     // stage-2 temporaries
     DevBuf embin, g256a, g256b, g256c, gi, emb, demb, demb2, d3, d2, d1, m, dfo, coefs, xm;
     DevBuf g256d, g256e, g256f, gi2;   // DF-decoder chain's own scratch (runs beside the ERB decoder)
-    DevBuf skipb;                      // df_skip(emb) of the fused small-launch form (emb_out_kernel)
+    DevBuf skipb;                      // df_skip(emb) of the fused small-launch form (emb_out_mfma_kernel)
     void release() {
         for (int k = 0; k < NRING; ++k) x[k].release();
         DevBuf* all[] = {&feat_erb, &feat_spec, &hcat, &hin, &hcat_e, &hin_e, &gi64, &gi64_e,
@@ -322,6 +322,7 @@ struct dpdf_model {
     // single-hop streaming: chores of the call's front end that the fused feature kernel of the hop picks up (feat_hop_kernel):
     // the sum over K-split STFT partials and the hand-over of the analysis buffers.  Set by streams_enqueue, consumed by stage 1.
     struct HopExtras { const float* part = nullptr; int ks = 0, W = 0; const float* pcm_new = nullptr; float* in_tail = nullptr; float* snap_in = nullptr; bool armed = false; } hx;
+    int fuse_gl = 1;                   // small launches: grouped linears around the GRU-256 cells chained per 16-row tile in one launch each (0: A/B)
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int hop_feat = 1;                  // single-hop calls: features A + B (+ those chores) as one launch (0: separate kernels, A/B)
@@ -557,12 +558,6 @@ GlW build_gl(Arena& A, const Blob& B, const std::string& p, int G, int Og, int I
     }
     g.frag = A.add(frag);
     g.bias = A.add(std::vector<float>(b, b + (size_t)G * Og));
-    {
-        std::vector<float> wt((size_t)G * Og * Ig);
-        for (int gi = 0; gi < G; ++gi) for (int o = 0; o < Og; ++o) for (int k = 0; k < Ig; ++k)
-            wt[((size_t)gi * Ig + k) * Og + o] = w[((size_t)gi * Og + o) * Ig + k];
-        g.raw = A.add(wt);
-    }
     return g;
 }
 Gru256W build_gru256(Arena& A, const Blob& B, const std::string& p) {
@@ -672,7 +667,7 @@ void erb_bands(int nfft, int fs, std::vector<int>& start, std::vector<int>& band
 
 // Row count below which the wide-N GEMMs switch to their narrow-column packing: with <= 8 row tiles the launch is a
 // handful of workgroups walking all K panels one after the other; narrower column blocks multiply the workgroups.
-// Also the limit of the fused small-launch forms (small_fused.h, mask_df_kernel).
+// Also the limit of the fused small-launch forms (small_fused_mfma.h, mask_df_kernel).
 constexpr int SMALL_M_ROWS = 512;
 
 int ensure_xset(dpdf_model* m, XSet& x, int B, int Tc) {
@@ -1286,16 +1281,22 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     TView e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
     TView c0v{x.c0.p, Tc + 4, 4, d.D, 64};
     // ---- embedding (dpdfnet.py:233-241; 48k hr.py:285-293).  channels-last [f][c] IS the (f,c) flatten ----
-    // small launches (streaming hops, single clips): the grouped linears chained per row in one launch each (small_fused.h)
-    // (per-row workgroups re-read every weight per row: a gain for a handful of rows -- one 16 kHz stream 212 -> 205 us per hop --
-    // and a loss from a few dozen on -- 64 x 48 kHz streams 313 -> 340 us -- where the 64-row MFMA tiles of gemm_rows stay)
-    const bool small = m->fuse_small && BT <= 8 && d.Fd * 64 <= 3072 && d.F3 * 64 <= 3072;
-    auto glrow = [&](const GlW& g) { return GlRow{m->C(g.raw), m->C(g.bias), g.G, g.Og, g.Ig}; };
-    if (small) {
+    // Small launches (<= 512 rows): the grouped linears chained in one launch each, per 16-row tile on the matrix cores
+    // (small_fused_mfma.h).  (A per-row VALU form was measured too: equal for one row, worse from a few dozen rows on -- every
+    // row's workgroup re-reads all weights: 64 x 48 kHz streams 313 -> 340 us -- and is gone.)
+    const bool gl_dims = m->enc_lin_in.Ig == 64 && m->enc_lin_in.Og == 16 && m->df_fc_emb.Og == 16 && m->df_fc_emb.Ig == 96 &&
+                         (!d.is48 || (m->enc_erb_fc.Og == 16 && m->enc_erb_fc.Ig == 80)) &&
+                         m->enc_lin_out.Ig == 16 && m->enc_lin_out.Og == 32 && m->ed_lin_in.Ig == 32 && m->ed_lin_in.Og == 16 &&
+                         m->df_skip.Ig == 32 && m->df_skip.Og == 16 && m->df_lin_in.Ig == 64 && m->df_lin_in.Og == 32 && m->df_lin_in.G == 8 &&
+                         m->ed_lin_out.Ig == 16 && m->ed_lin_out.Og == 32 && (!d.is48 || (m->ed_erb_fc.Ig == 16 && m->ed_erb_fc.Og == 80)) &&
+                         (d.is48 || d.F3 * 64 == 512);
+    const bool smallm = m->fuse_small && m->fuse_gl && BT <= SMALL_M_ROWS && gl_dims;
+    auto glfrag = [&](const GlW& g) { return GlFrag{m->C(g.frag), m->C(g.bias), g.G, g.Og, g.Ig, g.NT}; };
+    const GlFrag nofrag{nullptr, nullptr, 0, 0, 0, 0};
+    if (smallm) {
         ProfScope ps(m, "grouped_linear");
-        EmbInArgs ea{c1d, d.Fd * 64, e3d, d.F3 * 64, glrow(m->df_fc_emb), d.is48 ? glrow(m->enc_erb_fc) : GlRow{nullptr, nullptr, 0, 0, 0},
-                     glrow(m->enc_lin_in), w.g256a.p, BT};
-        hipLaunchKernelGGL(emb_in_kernel, dim3(BT), dim3(256), 0, st, ea);
+        EmbInMArgs ea{c1d, d.Fd * 64, e3d, d.F3 * 64, glfrag(m->df_fc_emb), d.is48 ? glfrag(m->enc_erb_fc) : nofrag, glfrag(m->enc_lin_in), w.g256a.p, BT};
+        hipLaunchKernelGGL(emb_in_mfma_kernel, dim3((BT + 63) / 64, 16), dim3(256), 0, st, ea);
     } else {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->df_fc_emb, c1d, (size_t)d.Fd * 64, w.embin.p + 512, 1024, BT, ACT_RELU);
@@ -1307,16 +1308,16 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc);
     const bool fork = (m->overlap & 8) && st != m->ln->sA;
     float* df_ga = fork ? w.g256d.p : w.g256a.p;
-    if (small && fork) {    // emb, both decoders' linear_in and df_skip in one launch (needs the DF decoder's own scratch: the fork)
+    if (smallm && fork) {
         ProfScope ps(m, "grouped_linear");
-        EmbOutArgs ea{w.g256b.p, glrow(m->enc_lin_out), glrow(m->df_lin_in), glrow(m->ed_lin_in), glrow(m->df_skip),
-                      w.emb.p, df_ga, w.g256a.p, w.skipb.p, BT};
-        hipLaunchKernelGGL(emb_out_kernel, dim3(BT), dim3(256), 0, st, ea);
+        EmbOutMArgs ea{w.g256b.p, glfrag(m->enc_lin_out), glfrag(m->df_lin_in), glfrag(m->ed_lin_in), glfrag(m->df_skip),
+                       w.emb.p, df_ga, w.g256a.p, w.skipb.p, BT};
+        hipLaunchKernelGGL(emb_out_mfma_kernel, dim3((BT + 63) / 64, 8), dim3(256), 0, st, ea);
     } else {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->enc_lin_out, w.g256b.p, 256, w.emb.p, 512, BT, ACT_RELU);
     }
-    const bool fanned = small && fork;
+    const bool fanned = smallm && fork;
     // The two decoders only share `emb`: the DF decoder (2 GRU-256 cells, df_out, pathway conv) runs on its own stream
     // beside the ERB decoder (2 cells, transposed convs, mask) -- the five latency-bound cell scans become three deep.
     hipStream_t sd = fork ? m->ln->sD : st;
@@ -1383,10 +1384,10 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         run_gru256(m, m->ed_gru1, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc);
     }
     float* dembp = d.is48 ? w.demb2.p : w.demb.p;
-    if (small) {
+    if (smallm) {
         ProfScope ps(m, "grouped_linear");
-        DecInArgs da{w.g256c.p, glrow(m->ed_lin_out), d.is48 ? glrow(m->ed_erb_fc) : GlRow{nullptr, nullptr, 0, 0, 0}, w.demb.p, w.demb2.p, d.F3 * 64, BT};
-        hipLaunchKernelGGL(dec_in_kernel, dim3(BT), dim3(256), 0, st, da);
+        DecInMArgs da{w.g256c.p, glfrag(m->ed_lin_out), d.is48 ? glfrag(m->ed_erb_fc) : nofrag, w.demb.p, w.demb2.p, d.F3 * 64, BT};
+        hipLaunchKernelGGL(dec_in_mfma_kernel, dim3((BT + 63) / 64, 16), dim3(256), 0, st, da);
     } else {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->ed_lin_out, w.g256c.p, 256, w.demb.p, 512, BT, ACT_RELU);
@@ -1762,6 +1763,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "hop_glue") m->hop_glue = value != 0;
     else if (n == "hop_feat") m->hop_feat = value != 0;
     else if (n == "glue8") m->glue8 = value != 0;
+    else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;

@@ -1,0 +1,198 @@
+// small_fused_mfma.h -- the grouped linears around the GRU-256 cells for launches of up to a few hundred rows (streaming hops,
+// single clips), chained per 16-row tile on the matrix cores, one launch per chain:
+//   emb_in:  c1d (+ e3d) -> df_fc_emb (+ erb_fc_emb at 48 kHz | copy at 16 kHz) -> concat -> emb_gru.linear_in        (3 launches -> 1)
+//   emb_out: h_enc -> emb_gru.linear_out -> { df_gru.linear_in, erb_dec.linear_in, df_skip }                           (4 -> 1)
+//   dec_in:  h_erb -> erb_dec.linear_out (-> erb_fc_emb at 48 kHz)                                                    (2 -> 1)
+// With few rows every kernel of stage 2 is a dependent launch that costs ~3 us of host time and ~5 us on the GPU's critical
+// chain whatever it computes (tools/hop_nb_sweep.py: 225 us of a one-stream 16 kHz hop and 353 us of a 64-stream 48 kHz hop
+// were NOT the DPRNN chain).  A workgroup is (64 rows, one group of the LAST layer of the chain): grouped linears are
+// block-diagonal, so a group of the second layer needs only the few groups of the first layer that feed it; a wave owns 16
+// rows, computes those first-layer tiles straight from global memory (the A fragment of lane (row, q) is four consecutive
+// floats of the row), parks them in its own LDS rows and runs the second layer on them.  Weights in gemm_rows' fragment packing
+// (pack_frag: [chunk][tile][kb][lane] per group), read once per wave.  The DF decoder's `c = gru(emb) + skip(emb)` is added by
+// df_out's A producer (SumA) instead of a kernel of its own.  Measured (interleaved, tools/hop_ab2.py): 64 x 48 kHz streams
+// -15 us, one 16 kHz stream -14 us, eight streams -18 us per hop.  Reference: onnx_model/layers.py:1035-1046; dpdfnet.py:233-241,
+// 343-360, 486-519.
+#pragma once
+#include "common.h"
+
+struct GlFrag { const float* frag; const float* bias; int G, Og, Ig, NT; };     // build_gl: frag of group g at g * ceil(Ig/16) * NT * 256
+
+// acc[nt] (16 rows x 16 cols each) += A[16 rows][Ig] . W_g  with A rows at `arow` (this lane's row, + 4 q applied by the caller):
+// arow points at element [row = lane & 15][k = 4 * (lane >> 4)] of the group's input slice; row pitch irrelevant (pointer per lane)
+// NCH = ceil(Ig / 16) is a template parameter so that the loop unrolls completely: every A fragment and every weight fragment
+// of the tile is requested before the first MFMA -- one memory latency per tile instead of one per 16-wide K chunk (a hop's
+// kernels are chains of latencies: emb_in at 48 kHz is 4 x 5..6 chunks deep).
+template <int NT, int NCH, bool FROM_LDS>
+__device__ __forceinline__ void gl_tile(const GlFrag& g, int grp, const float* arow, f32x4 (&acc)[NT], int lane) {
+    const float* wf = g.frag + (size_t)grp * NCH * NT * 256 + lane;
+    float4 a4[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) a4[c] = *(const float4*)(arow + 16 * c);
+    float wv[NCH][NT][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) wv[c][nt][kb] = wf[(size_t)((c * NT + nt) * 4 + kb) * 64];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const float av[4] = {a4[c].x, a4[c].y, a4[c].z, a4[c].w};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[nt] = mfma16(av[kb], wv[c][nt][kb], acc[nt]);
+    }
+}
+
+struct EmbInMArgs {
+    const float* c1d; int n_c1; const float* e3d; int n_e3;
+    GlFrag df_fc, erb_fc, lin_in;       // erb_fc.frag == null: the first 512 inputs of linear_in are e3d itself (16 kHz)
+    float* out; int M;                  // [M][256]
+};
+// grid (ceil(M / 64), 16 groups of linear_in): group g2 reads embin[64 g2, 64 g2 + 64) = four 16-wide first-layer groups
+__global__ __launch_bounds__(256) void emb_in_mfma_kernel(EmbInMArgs a) {
+    __shared__ __attribute__((aligned(16))) float Es[4][16][68];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
+    const int g2 = blockIdx.y;
+    const int row0 = blockIdx.x * 64 + 16 * w;
+    int row = row0 + cl; if (row >= a.M) row = a.M - 1;
+    for (int j = 0; j < 4; ++j) {
+        const int g1 = 4 * g2 + j;                        // 0..31: ERB half, 32..63: DF half
+        if (g1 < 32 && !a.erb_fc.frag) {                  // 16 kHz: copy e3d[row][16 g1 ..]
+            if (q == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(float4*)&Es[w][cl][16 * j + 4 * i] = *(const float4*)(a.e3d + (size_t)row * a.n_e3 + 16 * g1 + 4 * i);
+            }
+            continue;
+        }
+        const bool erb = g1 < 32;
+        const GlFrag& g = erb ? a.erb_fc : a.df_fc;
+        const int gg = erb ? g1 : g1 - 32;
+        const float* x = (erb ? a.e3d + (size_t)row * a.n_e3 : a.c1d + (size_t)row * a.n_c1) + (size_t)gg * g.Ig + 4 * q;
+        f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        if (erb) gl_tile<1, 5, false>(g, gg, x, acc, lane);        // 2560 / 32 = 80 inputs per group
+        else gl_tile<1, 6, false>(g, gg, x, acc, lane);            // 3072 / 32 = 96
+        const float bv = g.bias[gg * 16 + cl];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Es[w][4 * q + i][16 * j + cl] = fmaxf(acc[0][i] + bv, 0.f);
+    }
+    __syncthreads();
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    gl_tile<1, 4, true>(a.lin_in, g2, &Es[w][cl][4 * q], acc, lane);
+    const float bv = a.lin_in.bias[g2 * 16 + cl];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * q + i;
+        if (r < a.M) a.out[(size_t)r * 256 + g2 * 16 + cl] = fmaxf(acc[0][i] + bv, 0.f);
+    }
+}
+
+struct EmbOutMArgs {
+    const float* h;                     // [M][256]
+    GlFrag lin_out, df_in, ed_in, skip; // 16 x (16 -> 32), 8 x (64 -> 32), 16 x (32 -> 16), 16 x (32 -> 16)
+    float* emb; float* df_x; float* ed_x; float* skip_out;
+    int M;
+};
+// grid (ceil(M / 64), 8): block g owns linear_out groups 2g, 2g + 1 (emb columns [64 g, 64 g + 64)), the ERB decoder's
+// linear_in / df_skip groups 2g, 2g + 1 and the DF decoder's linear_in group g
+__global__ __launch_bounds__(256) void emb_out_mfma_kernel(EmbOutMArgs a) {
+    __shared__ __attribute__((aligned(16))) float Es[4][16][68];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
+    const int g = blockIdx.y;
+    const int row0 = blockIdx.x * 64 + 16 * w;
+    int row = row0 + cl; if (row >= a.M) row = a.M - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g1 = 2 * g + j;
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        gl_tile<2, 1, false>(a.lin_out, g1, a.h + (size_t)row * 256 + 16 * g1 + 4 * q, acc, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bv = a.lin_out.bias[g1 * 32 + nt * 16 + cl];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = fmaxf(acc[nt][i] + bv, 0.f);
+                Es[w][4 * q + i][32 * j + 16 * nt + cl] = v;
+                const int r = row0 + 4 * q + i;
+                if (r < a.M) a.emb[(size_t)r * 512 + g1 * 32 + nt * 16 + cl] = v;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g1 = 2 * g + j;
+        f32x4 ae[1] = {{0.f, 0.f, 0.f, 0.f}}, as[1] = {{0.f, 0.f, 0.f, 0.f}};
+        gl_tile<1, 2, true>(a.ed_in, g1, &Es[w][cl][32 * j + 4 * q], ae, lane);
+        gl_tile<1, 2, true>(a.skip, g1, &Es[w][cl][32 * j + 4 * q], as, lane);
+        const float be = a.ed_in.bias[g1 * 16 + cl], bs = a.skip.bias[g1 * 16 + cl];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + 4 * q + i;
+            if (r < a.M) {
+                a.ed_x[(size_t)r * 256 + g1 * 16 + cl] = fmaxf(ae[0][i] + be, 0.f);
+                a.skip_out[(size_t)r * 256 + g1 * 16 + cl] = as[0][i] + bs;
+            }
+        }
+    }
+    f32x4 ad[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    gl_tile<2, 4, true>(a.df_in, g, &Es[w][cl][4 * q], ad, lane);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float bv = a.df_in.bias[g * 32 + nt * 16 + cl];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + 4 * q + i;
+            if (r < a.M) a.df_x[(size_t)r * 256 + g * 32 + nt * 16 + cl] = fmaxf(ad[nt][i] + bv, 0.f);
+        }
+    }
+}
+
+struct DecInMArgs {
+    const float* h; GlFrag lin_out, erb_fc;     // 16 x (16 -> 32); 48 kHz: 32 x (16 -> 80), NT = 5.  erb_fc.frag == null: demb is the output
+    float* demb; float* demb2; int n2; int M;
+};
+// grid (ceil(M / 64), 16): block g owns linear_out group g (demb columns [32 g, 32 g + 32)) and erb_fc_emb groups 2g, 2g + 1
+__global__ __launch_bounds__(256) void dec_in_mfma_kernel(DecInMArgs a) {
+    __shared__ __attribute__((aligned(16))) float Es[4][16][36];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
+    const int g = blockIdx.y;
+    const int row0 = blockIdx.x * 64 + 16 * w;
+    int row = row0 + cl; if (row >= a.M) row = a.M - 1;
+    {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        gl_tile<2, 1, false>(a.lin_out, g, a.h + (size_t)row * 256 + 16 * g + 4 * q, acc, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bv = a.lin_out.bias[g * 32 + nt * 16 + cl];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = fmaxf(acc[nt][i] + bv, 0.f);
+                Es[w][4 * q + i][16 * nt + cl] = v;
+                const int r = row0 + 4 * q + i;
+                if (!a.erb_fc.frag && r < a.M) a.demb[(size_t)r * 512 + g * 32 + nt * 16 + cl] = v;
+            }
+        }
+    }
+    if (!a.erb_fc.frag) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g2 = 2 * g + j;
+        f32x4 acc[5];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gl_tile<5, 1, true>(a.erb_fc, g2, &Es[w][cl][16 * j + 4 * q], acc, lane);
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) {
+            const float bv = a.erb_fc.bias[g2 * 80 + nt * 16 + cl];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = row0 + 4 * q + i;
+                if (r < a.M) a.demb2[(size_t)r * a.n2 + g2 * 80 + nt * 16 + cl] = fmaxf(acc[nt][i] + bv, 0.f);
+            }
+        }
+    }
+}
