@@ -34,6 +34,7 @@
 #include "fcln_gi.h"
 #include "gru_scan4.h"
 #include "small_fused_mfma.h"
+#include "enc_seg.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -325,6 +326,8 @@ struct dpdf_model {
     int fuse_gl = 1;                   // small launches: grouped linears around the GRU-256 cells chained per 16-row tile in one launch each (0: A/B)
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
+    int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int interleave = 1;                // the two encoder branches' blocks enqueued alternately (0: one branch after the other; A/B)
     int hop_feat = 1;                  // single-hop calls: features A + B (+ those chores) as one launch (0: separate kernels, A/B)
     int* pin_progress = nullptr;       // pinned host word: frames of the running offline call whose stage 2 is complete (dpdf_progress)
     bool progress_on = false;          // set by the offline entry points only (a streaming hop does not pay for the extra launch)
@@ -889,22 +892,33 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
 // stream pipeline of a big batch (256 clips, ERB branch, 128 tiles: 125.6 -> 128.7 ms/step), so it is used below 64.
 // xin is read only (it stays valid for its other consumers: e3 is the decoder's skip input); the blocks ping-pong
 // between xa and xb, so no staging copy of the input is needed.
-float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, float* xa, float* xb, float* hcat, float* hin, DevBuf& gibuf, int Fp,
-                 float* state, long S, int soff, int B, int Tc) {
-    const int M = B * Tc * Fp;
-    float* x = xin; float* y = xa;
-    const bool can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0;
-    const bool fuse_intra = can_fuse && (m->fuse_dprnn == 2 || (long)B * Tc >= 3072);
-    const bool fuse_inter = can_fuse && (m->fuse_dprnn == 2 || (long)B * Fp >= m->inter_fuse_rows);
-    const bool gi_intra = !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
-    const bool gi_inter = !fuse_inter && m->hoist_gi && Tc >= 4 && (size_t)M * 192 <= gibuf.n;
-    const bool df = Fp >= 48;
-    // small batches: each fc + LayerNorm GEMM also computes the input projection of the recurrence that follows it
-    // (fcln_gi.h) -- two dependent launches per block fewer
-    const bool chain_gi = m->fcln_gi != 0;
-    const bool hop_glue = m->hop_glue && Tc == 1 && gi_intra;      // one frame per stream: everything between two intra scans in one launch
-    bool intra_gi_ready = false;
-    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+// One DPRNN stack as a walk over its blocks: block(bi) enqueues block bi on m->cur.  The two encoder branches are walked
+// alternately by run_stage1 (the DF stack on the main stream, the ERB stack on its own), so that in the latency regime -- where
+// the host is only just ahead of the GPU -- neither chain waits for the other one's ~20 launches to be enqueued.
+struct DprnnWalk {
+    dpdf_model* m; const std::vector<DprnnW>& blocks; float* xin; float* xa; float* xb; float* hcat; float* hin; DevBuf& gibuf; int Fp;
+    float* state; long S; int soff, B, Tc;
+    int M; float* x; float* y;
+    bool can_fuse, fuse_intra, fuse_inter, gi_intra, gi_inter, df, chain_gi, hop_glue, intra_gi_ready = false;
+    DprnnWalk(dpdf_model* m_, const std::vector<DprnnW>& blocks_, float* xin_, float* xa_, float* xb_, float* hcat_, float* hin_, DevBuf& gibuf_, int Fp_,
+              float* state_, long S_, int soff_, int B_, int Tc_)
+        : m(m_), blocks(blocks_), xin(xin_), xa(xa_), xb(xb_), hcat(hcat_), hin(hin_), gibuf(gibuf_), Fp(Fp_), state(state_), S(S_), soff(soff_), B(B_), Tc(Tc_) {
+        M = B * Tc * Fp;
+        x = xin; y = xa;
+        can_fuse = (Fp % 4 == 0) && m->fuse_dprnn != 0;
+        fuse_intra = can_fuse && (m->fuse_dprnn == 2 || (long)B * Tc >= 3072);
+        fuse_inter = can_fuse && (m->fuse_dprnn == 2 || (long)B * Fp >= m->inter_fuse_rows);
+        gi_intra = !fuse_intra && m->hoist_gi && (size_t)M * 384 <= gibuf.n;
+        gi_inter = !fuse_inter && m->hoist_gi && Tc >= 4 && (size_t)M * 192 <= gibuf.n;
+        df = Fp >= 48;
+        // small batches: each fc + LayerNorm GEMM also computes the input projection of the recurrence that follows it
+        // (fcln_gi.h) -- two dependent launches per block fewer
+        chain_gi = m->fcln_gi != 0;
+        hop_glue = m->hop_glue && Tc == 1 && gi_intra;      // one frame per stream: everything between two intra scans in one launch
+    }
+    size_t size() const { return blocks.size(); }
+    float* result() const { return x; }
+    void block(size_t bi) {
         const DprnnW& w = blocks[bi];
         bool inter_gi_ready = false;
         Gru64Args ai{};     // intra-band bi-GRU over frequency, h0 = 0: rows = frames, steps = band positions
@@ -958,7 +972,7 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
                 intra_gi_ready = next;
                 float* freed = x == xin ? xb : x;
                 x = y; y = freed;
-                continue;
+                return;
             }
             {   // fc_intra + ln_intra + residual (+ the inter-band cell's input projection)
                 ProfScope ps(m, "dprnn_fc_ln");
@@ -1024,7 +1038,12 @@ float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, f
         std::swap(x, y);
         if (y == xin) y = xb;
     }
-    return x;
+};
+float* run_dprnn(dpdf_model* m, const std::vector<DprnnW>& blocks, float* xin, float* xa, float* xb, float* hcat, float* hin, DevBuf& gibuf, int Fp,
+                 float* state, long S, int soff, int B, int Tc) {
+    DprnnWalk wk(m, blocks, xin, xa, xb, hcat, hin, gibuf, Fp, state, S, soff, B, Tc);
+    for (size_t bi = 0; bi < wk.size(); ++bi) wk.block(bi);
+    return wk.result();
 }
 
 template <int S>
@@ -1116,10 +1135,10 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
             hipLaunchKernelGGL(feat_b_kernel, dim3(B), dim3(nth), 0, sA, fb);
         }
     }
-    // The DF branch is the longer dependent chain (48 band positions per intra-band scan against 8 / 40) and its kernels are
-    // ENQUEUED first: in the latency regime the host is only just ahead of the GPU (~2.5 us per launch), and the ~20 launches of
-    // the branch that is enqueued first delay the start of the other one by ~50 us -- which the shorter ERB chain can afford
-    // and the DF chain cannot (64 x 48 kHz streams, one hop: 757 -> see DESIGN.md).  The fork point is the same either way.
+    // Two independent chains from here: the DF branch on the main stream, the ERB branch on its own.  They are ENQUEUED
+    // alternately, block by block (DprnnWalk): in the latency regime the host is only just ahead of the GPU (~3 us per launch),
+    // and a branch whose ~20 launches are enqueued behind the other one's starts that much later -- with 48 band positions
+    // against 40 (48 kHz) both chains are critical.  The fork point is the same either way.
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fk[c.parity], sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fk[c.parity], 0)); }
     // ---- encoder, DF branch (dpdfnet.py:221-234) on the main stream ----
     m->cur = sA;
@@ -1145,25 +1164,43 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
             run_dwconv_s(m, m->df_conv1, c0v, c1v, B, Tc, 2);
         }
     }
-    x.c1d = x.c1.p;
-    if (d.nb > 0) {
-        x.c1d = run_dprnn(m, m->dprnn_df, x.c1.p, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
-    }
     // ---- encoder, ERB branch (reference onnx_model/dpdfnet.py:206-219) on its own stream ----
     m->cur = sC;
     TView e0v{x.e0.p, Tc, 0, d.Ec, 64}, e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
     {
         ProfScope ps(m, "enc_convs_erb");
-        Conv0ErbArgs ca{w.feat_erb.p, x.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
-        size_t rows16 = ((size_t)BT * d.Ec + 15) / 16;
-        hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)std::min<size_t>(rows16, 8192)), dim3(256), 0, sC, ca);
-        run_dwconv_s(m, m->erb_conv1, e0v, e1v, B, Tc, d.s1);
-        run_dwconv_s(m, m->erb_conv2, e1v, e2v, B, Tc, d.s2);
-        run_dwconv_s(m, m->erb_conv3, e2v, e3v, B, Tc, d.s3);
+        const bool exact = d.F2 == d.F3 * d.s3 && d.F1 == d.F2 * d.s2 && d.Ec == d.F1 * d.s1 && d.F3 % 8 == 0;
+        const int geo = !exact ? 0 : (d.s1 == 2 && d.s2 == 2 && d.s3 == 1) ? 16 : (d.s1 == 3 && d.s2 == 2 && d.s3 == 2) ? 48 : 0;
+        if (m->fuse_small && m->fuse_enc && geo && BT <= SMALL_M_ROWS) {       // latency regime: four dependent launches -> one (enc_seg.h)
+            ErbEncArgs ea{w.feat_erb.p, x.e0.p, x.e1.p, x.e2.p, x.e3.p, m->C(m->conv0_w), m->C(m->conv0_b),
+                          m->C(m->erb_conv1.dw), m->C(m->erb_conv1.pwfrag), m->C(m->erb_conv1.bias),
+                          m->C(m->erb_conv2.dw), m->C(m->erb_conv2.pwfrag), m->C(m->erb_conv2.bias),
+                          m->C(m->erb_conv3.dw), m->C(m->erb_conv3.pwfrag), m->C(m->erb_conv3.bias), B, Tc, d.E, d.Ec, d.F1, d.F2, d.F3};
+            if (geo == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(erb_enc_seg_kernel<2, 2, 1, 8>), dim3(d.F3 / 8, BT), dim3(256), 0, sC, ea);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(erb_enc_seg_kernel<3, 2, 2, 8>), dim3(d.F3 / 8, BT), dim3(256), 0, sC, ea);
+        } else {
+            Conv0ErbArgs ca{w.feat_erb.p, x.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
+            size_t rows16 = ((size_t)BT * d.Ec + 15) / 16;
+            hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)std::min<size_t>(rows16, 8192)), dim3(256), 0, sC, ca);
+            run_dwconv_s(m, m->erb_conv1, e0v, e1v, B, Tc, d.s1);
+            run_dwconv_s(m, m->erb_conv2, e1v, e2v, B, Tc, d.s2);
+            run_dwconv_s(m, m->erb_conv3, e2v, e3v, B, Tc, d.s3);
+        }
     }
-    x.e3d = x.e3.p;
+    x.c1d = x.c1.p; x.e3d = x.e3.p;
     if (d.nb > 0) {
-        x.e3d = run_dprnn(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
+        DprnnWalk wdf(m, m->dprnn_df, x.c1.p, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
+        DprnnWalk werb(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
+        if (m->interleave) {
+            for (size_t bi = 0; bi < wdf.size(); ++bi) {
+                m->cur = sA; wdf.block(bi);
+                m->cur = sC; werb.block(bi);
+            }
+        } else {
+            m->cur = sA; for (size_t bi = 0; bi < wdf.size(); ++bi) wdf.block(bi);
+            m->cur = sC; for (size_t bi = 0; bi < werb.size(); ++bi) werb.block(bi);
+        }
+        x.c1d = wdf.result(); x.e3d = werb.result();
     }
     m->cur = sA;
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_jn[c.parity], sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_jn[c.parity], 0)); }
@@ -1765,6 +1802,8 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "glue8") m->glue8 = value != 0;
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
+    else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "interleave") m->interleave = value != 0;
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_c16_tiles") m->gru256_c16_tiles = value < 0 ? 0 : value;

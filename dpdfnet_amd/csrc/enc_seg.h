@@ -1,0 +1,132 @@
+// enc_seg.h -- the ERB encoder's four convolutions as ONE launch for small launches (streaming hops, short clips).
+//
+// erb_conv0 (dense 1 -> 64, k(3,3) over three frames of band features) and erb_conv1..3 (depthwise k(1,3) with stride S along
+// the band axis + pointwise 64 x 64 + BN + ReLU) -- reference onnx_model/dpdfnet.py:74-95, 206-219 -- are four dependent
+// launches of 8-13 us each in front of the ERB branch's DPRNN when a launch holds a few frames, and with 40 band positions at
+// 48 kHz that branch is as long as the DF one: they are the head of the hop's critical path.  Here a workgroup owns R3 output
+// positions of ONE frame and walks the whole pyramid for them through LDS: the e2 / e1 / e0 positions those R3 outputs depend
+// on (k = 3 halos, recomputed by the neighbouring workgroups: 106 conv0 rows for 96 owned at 48 kHz), conv0 on the VALU from
+// an LDS copy of the feature window, each separable layer as depthwise (straight into the MFMA A-operand registers) +
+// pointwise on the matrix cores (wave w = output channels [16w, 16w + 16)).  Positions outside [0, F) are the convolutions'
+// zero padding and are written as zeros into LDS; every e-tensor is stored to HBM by its owner (the decoder's skip inputs).
+// Same arithmetic and summation order as conv0_erb_kernel + gemm_rows<DwConvA<S>> (explicit fmaf chains, fp32 MFMA 16x16x4 with k
+// ascending): bit-identical results, so a clip enhanced alone equals the same clip inside a big batch.
+#pragma once
+#include "common.h"
+
+struct ErbEncArgs {
+    const float* feat;                  // [B][2 + Tc][E]
+    float* e0; float* e1; float* e2; float* e3;     // [B*Tc][Ec | F1 | F2 | F3][64]
+    const float* w0; const float* b0;   // erb_conv0 [64][9] (BN folded), shift [64]
+    const float* dw1; const float* pw1; const float* bs1;      // depthwise [64][3], pointwise fragments (pack_frag 64 x 64, NT 4), BN shift
+    const float* dw2; const float* pw2; const float* bs2;
+    const float* dw3; const float* pw3; const float* bs3;
+    int B, Tc, E, Ec, F1, F2, F3;
+};
+
+// one separable layer over NROW local output rows: src row ro * S + j is input position (lo_out + ro) * S + j - 1
+template <int S, int NROW, int NSRC>
+__device__ __forceinline__ void enc_seg_layer(const float (*src)[68], const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ bs,
+                                              int lo_out, int Fout, int own_lo, int own_hi, float* __restrict__ out, float (*dst)[68]) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
+    float frag[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) frag[k] = pw[(size_t)(((k >> 2) * 4 + w) * 4 + (k & 3)) * 64 + lane];
+    float dq[16][3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dq[4 * c + k][j] = dw[(16 * c + 4 * q + k) * 3 + j];
+    const float bv = bs[16 * w + cl];
+    constexpr int NT = (NROW + 15) / 16;
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+        const int ro = rt * 16 + cl;
+        float av[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) av[i] = 0.f;
+        if (ro < NROW) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 x = *(const float4*)&src[ro * S + j][16 * c + 4 * q];
+                    av[4 * c + 0] = __builtin_fmaf(dq[4 * c + 0][j], x.x, av[4 * c + 0]); av[4 * c + 1] = __builtin_fmaf(dq[4 * c + 1][j], x.y, av[4 * c + 1]);
+                    av[4 * c + 2] = __builtin_fmaf(dq[4 * c + 2][j], x.z, av[4 * c + 2]); av[4 * c + 3] = __builtin_fmaf(dq[4 * c + 3][j], x.w, av[4 * c + 3]);
+                }
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = mfma16(av[k], frag[k], acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = rt * 16 + 4 * q + i, g = lo_out + row;
+            const bool valid = row < NROW && g >= 0 && g < Fout;
+            const float v = valid ? fmaxf(acc[i] + bv, 0.f) : 0.f;
+            if (dst && row < NROW) dst[row][16 * w + cl] = v;
+            if (valid && g >= own_lo && g < own_hi) out[(size_t)g * 64 + 16 * w + cl] = v;
+        }
+    }
+    static_assert((NROW - 1) * S + 2 < NSRC, "source rows");
+}
+
+template <int S1, int S2, int S3, int R3>
+__global__ __launch_bounds__(256) void erb_enc_seg_kernel(ErbEncArgs a) {
+    // rows of each level this workgroup computes: from the lower k = 3 halo of its first output up to whichever is further, the
+    // upper halo of its last output or the last row it OWNS (stride 3: the owned rows reach one past the halo).  H = end of the
+    // range relative to the first owned row, N = row count including the lower halos
+    constexpr int O2 = R3 * S3, H2 = ((R3 - 1) * S3 + 2 > O2) ? (R3 - 1) * S3 + 2 : O2, N2 = H2 + 1;
+    constexpr int O1 = O2 * S2, H1 = ((H2 - 1) * S2 + 2 > O1) ? (H2 - 1) * S2 + 2 : O1, N1 = H1 + S2 + 1;
+    constexpr int O0 = O1 * S1, H0 = ((H1 - 1) * S1 + 2 > O0) ? (H1 - 1) * S1 + 2 : O0, N0 = H0 + (S2 + 1) * S1 + 1;
+    __shared__ __attribute__((aligned(16))) float E0[N0][68];
+    __shared__ __attribute__((aligned(16))) float E1[N1][68];
+    __shared__ __attribute__((aligned(16))) float E2[N2][68];
+    __shared__ float Fw[3][N0 + 2];          // features of positions lo0 - 1 .. lo0 + N0, frames t .. t + 2 (zeros outside [0, Ec))
+    const int tid = threadIdx.x;
+    const int bt = blockIdx.y, b = bt / a.Tc, t = bt - b * a.Tc;
+    const int a3 = blockIdx.x * R3, lo2 = a3 * S3 - 1, lo1 = lo2 * S2 - 1, lo0 = lo1 * S1 - 1;
+    for (int i = tid; i < 3 * (N0 + 2); i += 256) {
+        const int kt = i / (N0 + 2), r = i - kt * (N0 + 2), fi = lo0 - 1 + r;
+        Fw[kt][r] = (fi >= 0 && fi < a.Ec) ? a.feat[((size_t)b * (a.Tc + 2) + t + kt) * a.E + fi] : 0.f;
+    }
+    const int c4 = (tid & 15) * 4, r16 = tid >> 4;
+    float w0[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w0[j][k] = a.w0[(c4 + j) * 9 + k];
+    const float4 bias = *(const float4*)(a.b0 + c4);
+    __syncthreads();
+    // ---- erb_conv0 (as conv0_erb_kernel): local row r = band lo0 + r
+    {
+        float* e0 = a.e0 + (size_t)bt * a.Ec * 64;
+        const int own_lo = a3 * S3 * S2 * S1, own_hi = own_lo + R3 * S3 * S2 * S1;
+#pragma unroll 2
+        for (int r = r16; r < N0; r += 16) {
+            const int f = lo0 + r;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f >= 0 && f < a.Ec) {
+                acc = bias;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                    for (int kf = 0; kf < 3; ++kf) {
+                        const float x = Fw[kt][r + kf];      // band f + kf - 1
+                        acc.x = __builtin_fmaf(w0[0][kt * 3 + kf], x, acc.x); acc.y = __builtin_fmaf(w0[1][kt * 3 + kf], x, acc.y);
+                        acc.z = __builtin_fmaf(w0[2][kt * 3 + kf], x, acc.z); acc.w = __builtin_fmaf(w0[3][kt * 3 + kf], x, acc.w);
+                    }
+                acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+                if (f >= own_lo && f < own_hi) *(float4*)(e0 + (size_t)f * 64 + c4) = acc;
+            }
+            *(float4*)&E0[r][c4] = acc;
+        }
+    }
+    __syncthreads();
+    enc_seg_layer<S1, N1, N0>(E0, a.dw1, a.pw1, a.bs1, lo1, a.F1, a3 * S3 * S2, (a3 + R3) * S3 * S2, a.e1 + (size_t)bt * a.F1 * 64, E1);
+    __syncthreads();
+    enc_seg_layer<S2, N2, N1>(E1, a.dw2, a.pw2, a.bs2, lo2, a.F2, a3 * S3, (a3 + R3) * S3, a.e2 + (size_t)bt * a.F2 * 64, E2);
+    __syncthreads();
+    enc_seg_layer<S3, R3, N2>(E2, a.dw3, a.pw3, a.bs3, a3, a.F3, a3, a3 + R3, a.e3 + (size_t)bt * a.F3 * 64, nullptr);
+}

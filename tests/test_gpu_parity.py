@@ -405,6 +405,34 @@ def test_big_batch_kernel_forms_match_small_batch_forms_and_oracle(be, sr, nb):
     m.close()
 
 
+@pytest.mark.parametrize("sr,nb", [(16000, 2), (48000, 1)])
+def test_small_launch_kernel_forms_equal_the_plain_forms(be, sr, nb):
+    """Launch shapes that only small launches select (<= 512 frame rows: the ERB encoder pyramid as one launch -- enc_seg.h --
+    the grouped linears chained per tile, mask + deep filter in one launch) against the plain forms, each on a FRESH model
+    (a row one form forgets to write must not be inherited from the other's run).  The encoder pyramid repeats the plain
+    kernels' arithmetic exactly, so its outputs are bit-identical -- which is what makes a clip enhanced alone equal the
+    same clip inside a big batch; the others agree to rounding."""
+    from dpdfnet_amd.weights import synth_blob
+    blob = synth_blob(be.manifest(sr, nb), 31337)
+    wav = np.stack([synth_clip(int(0.3 * sr) + 11, sr, 4000 + i) for i in range(5)]).astype(np.float32)
+    outs, probes = {}, {}
+    for tag, opts in (("fused", {}), ("plain_enc", {"fuse_enc": 0}), ("plain", {"fuse_small": 0})):
+        m = be.HipModel(sr, nb, blob, 0)
+        m.set_chunk_frames(16)
+        for k, v in opts.items():
+            m.set_option(k, v)
+        outs[tag] = m.enhance_batch(wav, 100.0)
+        probes[tag] = {k: m.debug_fetch(k) for k in ("e0", "e1", "e2", "e3", "m", "coefs")}
+        m.close()
+    np.testing.assert_array_equal(outs["fused"], outs["plain_enc"])
+    for k in ("e0", "e1", "e2", "e3"):
+        np.testing.assert_array_equal(probes["fused"][k], probes["plain_enc"][k])
+    assert rms(outs["fused"] - outs["plain"]) < 1e-6
+    for k in ("m", "coefs"):
+        a_, b_ = probes["fused"][k], probes["plain"][k]
+        assert np.abs(a_ - b_).max() < 2e-5 * max(1.0, float(np.abs(b_).max())), k
+
+
 def test_every_gru256_scan_form_agrees(be):
     """The forms of the GRU-256 recurrence -- single-workgroup scan (`gru256_cluster` = 0), 4-workgroup cluster, 8- and
     16-workgroup clusters for small launches, the two cells of a decoder stack as one wavefront launch (gru_stack.h) -- on
