@@ -35,6 +35,7 @@
 #include "gru_scan4.h"
 #include "small_fused_mfma.h"
 #include "enc_seg.h"
+#include "dec_pyr.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -327,6 +328,7 @@ struct dpdf_model {
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int fuse_dec = 1;                  // ... and the ERB decoder's three stages + mask head (dec_pyr_kernel; 0: A/B)
     int interleave = 1;                // the two encoder branches' blocks enqueued alternately (0: one branch after the other; A/B)
     int hop_feat = 1;                  // single-hop calls: features A + B (+ those chores) as one launch (0: separate kernels, A/B)
     int* pin_progress = nullptr;       // pinned host word: frames of the running offline call whose stage 2 is complete (dpdf_progress)
@@ -1230,6 +1232,20 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
     const bool geo16 = m->fuse_mask && !d.is48 && d.s1 == 2 && d.s2 == 2 && d.s3 == 1 && d.Ec == 32 && d.F1 == 16 && d.F2 == 8 && d.F3 == 8;
     const bool geo48 = m->dec_seg && BT >= 1024 && d.is48 &&   // (few frames: the gemm_rows forms spread over more workgroups: 64 x 48 kHz streams, one hop 767 -> 753 us)
                         m->fuse_mask && d.s3 == 2 && d.s2 == 2 && d.s1 == 3 && d.F2 % 80 == 0 && d.F1 % 80 == 0 && d.Ec % 96 == 0;
+    const bool exact = d.F2 == d.F3 * d.s3 && d.F1 == d.F2 * d.s2 && d.Ec == d.F1 * d.s1;
+    const int pyr = !(m->fuse_small && m->fuse_dec && m->fuse_mask && exact && BT <= SMALL_M_ROWS) ? 0
+                    : geo16 ? 16 : (d.is48 && d.s1 == 3 && d.s2 == 2 && d.s3 == 2 && d.F3 % 8 == 0) ? 48 : 0;
+    if (pyr) {      // latency regime: the three stages + the mask head's tap sums as one launch (dec_pyr.h)
+        DecPyrArgs pa{x.e3.p, dembp, x.e2.p, x.e1.p, x.e0.p, pyr == 48 ? w.d1.p : nullptr, pyr == 16 ? w.m.p : nullptr,
+                      m->C(m->conv3p.ps), m->C(m->conv3p.pb), m->C(m->convt3.dw), m->C(m->convt3.pwfrag), m->C(m->convt3.bias),
+                      m->C(m->conv2p.ps), m->C(m->conv2p.pb), m->C(m->convt2.dw), m->C(m->convt2.pwfrag), m->C(m->convt2.bias),
+                      m->C(m->conv1p.ps), m->C(m->conv1p.pb), m->C(m->convt1.dw), m->C(m->convt1.pwfrag), m->C(m->convt1.bias),
+                      m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias, BT, d.F3, d.F2, d.F1, d.Ec, d.E};
+        if (pyr == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_pyr_kernel<2, 2, 1, 8, true>), dim3(1, BT), dim3(256), 0, st, pa);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_pyr_kernel<3, 2, 2, 8, false>), dim3(d.F3 / 8, BT), dim3(256), 0, st, pa);
+        m->ln->mask_from_sums = pyr == 48;      // (the tap sums are finished inside mask_df_kernel)
+        return;
+    }
     if (geo48) {    // 48 kHz geometry: tiles of 80 / 80 / 96 output bands of one frame, inputs loaded once (dec_last.h: dec_seg_kernel)
         const long cap = 256 * 2 * 4;
         DecSegArgs a3{x.e3.p, dembp, w.d3.p, m->C(m->conv3p.ps), m->C(m->conv3p.pb), m->C(m->convt3.dw), m->C(m->convt3.pwfrag), m->C(m->convt3.bias),
@@ -1803,6 +1819,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "fuse_dec") m->fuse_dec = value != 0;
     else if (n == "interleave") m->interleave = value != 0;
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
