@@ -1142,6 +1142,8 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     // and a branch whose ~20 launches are enqueued behind the other one's starts that much later -- with 48 band positions
     // against 40 (48 kHz) both chains are critical.  The fork point is the same either way.
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fk[c.parity], sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fk[c.parity], 0)); }
+    DprnnWalk wdf(m, m->dprnn_df, x.c1.p, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
+    DprnnWalk werb(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
     // ---- encoder, DF branch (dpdfnet.py:221-234) on the main stream ----
     m->cur = sA;
     TView c0v{x.c0.p, Tc + 4, 4, d.D, 64}, c1v{x.c1.p, Tc, 0, d.Fd, 64};
@@ -1151,13 +1153,22 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         // fill the chip, else the time-parallel gemm_rows forms (df_ring.h)
         x.have_pconv = m->df_ring && B * 3 >= 192;
         const bool conv0_in_ring = x.have_pconv && m->df_ring >= 2;
-        if (!conv0_in_ring) {
+        const bool enc_seg = !x.have_pconv && m->fuse_small && m->fuse_enc && BT <= SMALL_M_ROWS && d.D == 2 * d.Fd && d.Fd % 16 == 0;
+        if (enc_seg) {      // latency regime: df_conv0 + df_conv1 + the first block's input projection as one launch (enc_seg.h)
+            const bool with_gi = d.nb > 0 && wdf.gi_intra;
+            DfEncArgs ea{w.feat_spec.p, x.c0.p, x.c1.p, with_gi ? w.gi64.p : nullptr, m->C(m->dfc0_pwfrag), m->C(m->dfc0_bias),
+                         m->C(m->df_conv1.dw), m->C(m->df_conv1.pwfrag), m->C(m->df_conv1.bias),
+                         with_gi ? m->C(m->dprnn_df[0].intra.ih_frag) : nullptr, with_gi ? m->C(m->dprnn_df[0].intra.ih_bias) : nullptr, B, Tc, d.D, d.Fd};
+            hipLaunchKernelGGL(df_enc_seg_kernel, dim3(d.Fd / 16, BT), dim3(256), 0, sA, ea);
+            wdf.intra_gi_ready = with_gi;
+        } else if (!conv0_in_ring) {
             RowMap rm = RowMap::make(Tc, d.D);
             Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm};
             BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
             launch_gemm_rows<4, 32, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 32, 1);
         }
-        if (x.have_pconv) {
+        if (enc_seg) {
+        } else if (x.have_pconv) {
             DfRingArgs ra{x.c0.p, x.c1.p, x.pconv.p, m->C(m->df_conv1.dw), m->C(m->df_conv1.pwfrag), m->C(m->df_conv1.bias),
                           m->C(m->convp_frag), m->C(m->convp_bias), B, Tc, w.feat_spec.p, m->C(m->dfc0_pwfrag), m->C(m->dfc0_bias)};
             if (conv0_in_ring) hipLaunchKernelGGL(HIP_KERNEL_NAME(df_ring_kernel<true>), dim3(B * 3), dim3(256), 0, sA, ra);
@@ -1191,8 +1202,6 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     }
     x.c1d = x.c1.p; x.e3d = x.e3.p;
     if (d.nb > 0) {
-        DprnnWalk wdf(m, m->dprnn_df, x.c1.p, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
-        DprnnWalk werb(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
         if (m->interleave) {
             for (size_t bi = 0; bi < wdf.size(); ++bi) {
                 m->cur = sA; wdf.block(bi);

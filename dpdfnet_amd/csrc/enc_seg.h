@@ -130,3 +130,101 @@ __global__ __launch_bounds__(256) void erb_enc_seg_kernel(ErbEncArgs a) {
     __syncthreads();
     enc_seg_layer<S3, R3, N2>(E2, a.dw3, a.pw3, a.bs3, a3, a.F3, a3, a3 + R3, a.e3 + (size_t)bt * a.F3 * 64, nullptr);
 }
+
+// ---------------------------------------------------------------------------------------------
+// df_enc_seg_kernel: the DF branch's front end for small launches as ONE launch -- df_conv0 (the folded [18 -> 64] im2col GEMM,
+// gemm_rows.h: Conv0DfA), df_conv1 (depthwise k(1,3) stride 2 + pointwise + BN + ReLU) and the first DPRNN block's intra-band
+// input projection gi = W_ih c1 + b (both directions, 64 -> 384; run_dprnn's hoisted GEMM) -- reference
+// onnx_model/dpdfnet.py:94-101, 221-234.  Three dependent launches (4-8 us each) at the head of the longest chain of a
+// streaming hop become one.  A workgroup owns 16 c1 positions of one frame: 33 c0 rows (one halo row below) on the matrix
+// cores straight from the feature window, c0 and c1 stored for their other consumers (the DF decoder's pathway conv, the
+// DPRNN's residual), c1 handed to the projection through LDS.  Wave w = output columns [16w, 16w + 16) of the two convolutions
+// and column tiles 6w .. 6w + 5 of the projection; k ascending as in the gemm_rows forms (bit-identical results).
+struct DfEncArgs {
+    const float* fs;        // feat_spec [B][2 + Tc][2][D]
+    float* c0;              // [B][Tc + 4][D][64], frame t at index 4 + t
+    float* c1;              // [B*Tc][Fd][64]
+    float* gi;              // [B*Tc*Fd][384] or null
+    const float* w0; const float* b0;       // df_conv0 fragments (pack_frag 32 x 64, NT 4), BN shift [64]
+    const float* dw1; const float* pw1; const float* bs1;
+    const float* ih; const float* ihb;      // W_ih fragments [6][chunk 4][nt 4][kb 4][lane], bias [6][64]
+    int B, Tc, D, Fd;
+};
+__global__ __launch_bounds__(256) void df_enc_seg_kernel(DfEncArgs a) {
+    constexpr int R1 = 16, N0 = 2 * R1 + 1;
+    __shared__ __attribute__((aligned(16))) float C0[N0][68];       // row r = band 2 a1 - 1 + r
+    __shared__ __attribute__((aligned(16))) float C1[R1][68];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
+    const int bt = blockIdx.y, b = bt / a.Tc, t = bt - b * a.Tc;
+    const int a1 = blockIdx.x * R1, lo0 = 2 * a1 - 1;
+    // ---- df_conv0: column k = 16 c + 4 q + kb of the im2col row = frame t - 2 + kt, group g, band f + kb - 1 with kt = 2 c + (q >> 1), g = q & 1
+    {
+        float frag[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) frag[k] = a.w0[(size_t)(((k >> 2) * 4 + w) * 4 + (k & 3)) * 64 + lane];
+        const float bv = a.b0[16 * w + cl];
+        constexpr int NT = (N0 + 15) / 16;
+        float av[NT][8];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            const int r = rt * 16 + cl, f = lo0 + r;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int kt = 2 * c + (q >> 1), g = q & 1;
+                const float* p = a.fs + (((size_t)b * (a.Tc + 2) + t + kt) * 2 + g) * a.D + f;
+                const bool row_ok = r < N0 && f >= 0 && f < a.D && kt < 3;
+                av[rt][4 * c + 0] = (row_ok && f > 0) ? p[-1] : 0.f;
+                av[rt][4 * c + 1] = row_ok ? p[0] : 0.f;
+                av[rt][4 * c + 2] = (row_ok && f + 1 < a.D) ? p[1] : 0.f;
+                av[rt][4 * c + 3] = 0.f;
+            }
+        }
+        float* c0 = a.c0 + ((size_t)b * (a.Tc + 4) + 4 + t) * a.D * 64;
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc = mfma16(av[rt][k], frag[k], acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rt * 16 + 4 * q + i, f = lo0 + r;
+                const bool valid = r < N0 && f >= 0 && f < a.D;
+                const float v = valid ? fmaxf(acc[i] + bv, 0.f) : 0.f;
+                if (r < N0) C0[r][16 * w + cl] = v;
+                if (valid && f >= 2 * a1) c0[(size_t)f * 64 + 16 * w + cl] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- df_conv1 (stride 2): c1 position a1 + ro reads C0 rows 2 ro .. 2 ro + 2
+    enc_seg_layer<2, R1, N0>(C0, a.dw1, a.pw1, a.bs1, a1, a.Fd, a1, a1 + R1, a.c1 + (size_t)bt * a.Fd * 64, C1);
+    if (!a.gi) return;
+    __syncthreads();
+    // ---- gi = W_ih c1 + b: 24 column tiles of 16 (group = direction * 3 + gate, 4 tiles each), 6 per wave
+    {
+        float av[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 x = *(const float4*)&C1[cl][16 * c + 4 * q];
+            av[4 * c + 0] = x.x; av[4 * c + 1] = x.y; av[4 * c + 2] = x.z; av[4 * c + 3] = x.w;
+        }
+        float* gi = a.gi + ((size_t)bt * a.Fd + a1) * 384;
+#pragma unroll
+        for (int i6 = 0; i6 < 6; ++i6) {
+            const int tt = w * 6 + i6, grp = tt >> 2, nt = tt & 3;
+            const float* fp = a.ih + (size_t)grp * 4096 + (size_t)nt * 256 + lane;        // [grp][c][nt][kb][lane]
+            float frag[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) frag[k] = fp[(size_t)(k >> 2) * 1024 + (k & 3) * 64];
+            const float bv = a.ihb[grp * 64 + nt * 16 + cl];
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc = mfma16(av[k], frag[k], acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * q + i;
+                if (a1 + row < a.Fd) gi[(size_t)row * 384 + grp * 64 + nt * 16 + cl] = acc[i] + bv;
+            }
+        }
+    }
+}
