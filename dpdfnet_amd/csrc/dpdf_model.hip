@@ -273,6 +273,7 @@ struct Lane {
     hipEvent_t ev_fk[NRING] = {}, ev_jn[NRING] = {};   // ERB-branch fork/join, per chunk-ring slot
     hipEvent_t ev_dfk[NRING] = {}, ev_djn[NRING] = {}; // decoder fork/join inside stage 2
     bool s2_pending[NRING] = {};
+    bool single_chunk = false;          // this call is one chunk: stage 2 on the main stream (run_stage2)
     hipEvent_t ev_x2 = nullptr; bool x2_pending = false;   // behind the stage-2 FIFO export of the latest chunk (joined at the END of a call: run_chunks / join_export)
     bool mask_from_sums = false;                       // this chunk's mask is still three tap sums per band in ws.d1 (run_dec_convs -> run_mask_df)
     Workspace ws;
@@ -328,6 +329,7 @@ struct dpdf_model {
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int single_chunk_inline = 1;       // one-chunk calls: stage 2 on the main stream instead of the stage-2 stream (0: A/B)
     int fuse_dec = 1;                  // ... and the ERB decoder's three stages + mask head (dec_pyr_kernel; 0: A/B)
     int interleave = 1;                // the two encoder branches' blocks enqueued alternately (0: one branch after the other; A/B)
     int hop_feat = 1;                  // single-hop calls: features A + B (+ those chores) as one launch (0: separate kernels, A/B)
@@ -1330,7 +1332,10 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     const int B = c.B, Tc = c.Tc, BT = B * Tc;
     const long S = d.state_size;
     float* state = c.state;
-    hipStream_t st = (m->overlap & 1) ? m->ln->sB : m->ln->sA;
+    // A call of ONE chunk (a streaming hop, a short clip) has no next chunk whose stage 1 stage 2 could run under: stage 2 stays on
+    // the main stream -- the two cross-stream handoffs (into the stage-2 stream, back for the iSTFT) cost ~10 us each against
+    // ~4 us of a same-stream dependent launch (one 16 kHz stream 248 -> 221 us/hop, 64 x 48 kHz streams 638 -> 612).
+    hipStream_t st = ((m->overlap & 1) && !m->ln->single_chunk) ? m->ln->sB : m->ln->sA;
     m->cur = st;
     StateIoArgs sio = make_sio(m, c, x);
     sio.seg_lo = 4; sio.seg_hi = 6;                    // DF coefs delay / masked-spec FIFOs
@@ -1520,7 +1525,8 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     // Stage 2 imports its FIFOs BEFORE it waits for stage 1 of the chunk (run_stage2), so nothing else orders the stage-2 stream
     // behind what the caller queued on the main stream in front of this call -- the upload or the initialisation of the very
     // state that import reads.  One event at the head of the call does.
-    if (m->overlap & 1) {
+    m->ln->single_chunk = sizes.size() == 1 && m->single_chunk_inline;
+    if ((m->overlap & 1) && !m->ln->single_chunk) {
         HIP_TRY(hipEventRecord(m->lanes[0].ev_fork, m->stream));
         HIP_TRY(hipStreamWaitEvent(m->lanes[0].sB, m->lanes[0].ev_fork, 0));
     }
@@ -1828,6 +1834,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "single_chunk_inline") m->single_chunk_inline = value != 0;
     else if (n == "fuse_dec") m->fuse_dec = value != 0;
     else if (n == "interleave") m->interleave = value != 0;
     else if (n == "fcln_gi") m->fcln_gi = value != 0;
