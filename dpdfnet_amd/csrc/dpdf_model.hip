@@ -324,11 +324,13 @@ struct dpdf_model {
     int use_gru256_cluster = 1;
     // single-hop streaming: chores of the call's front end that the fused feature kernel of the hop picks up (feat_hop_kernel):
     // the sum over K-split STFT partials and the hand-over of the analysis buffers.  Set by streams_enqueue, consumed by stage 1.
+    float* snap_dst = nullptr;         // pending pre-call state copy of a streaming call (consumed by the first stage-1 import)
     struct HopExtras { const float* part = nullptr; int ks = 0, W = 0; const float* pcm_new = nullptr; float* in_tail = nullptr; float* snap_in = nullptr; bool armed = false; } hx;
     int fuse_gl = 1;                   // small launches: grouped linears around the GRU-256 cells chained per 16-row tile in one launch each (0: A/B)
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int snapshot = 1;                  // streaming calls keep a pre-call copy of state and tails for the re-run after a device-side timeout (0: A/B only)
     int single_chunk_inline = 1;       // one-chunk calls: stage 2 on the main stream instead of the stage-2 stream (0: A/B)
     int fuse_dec = 1;                  // ... and the ERB decoder's three stages + mask head (dec_pyr_kernel; 0: A/B)
     int interleave = 1;                // the two encoder branches' blocks enqueued alternately (0: one branch after the other; A/B)
@@ -1104,7 +1106,7 @@ StateIoArgs make_sio(dpdf_model* m, const ChunkArgs& c, XSet& x) {
     const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L; Workspace& w = m->ln->ws;
     return StateIoArgs{c.state, (long)d.state_size, w.feat_erb.p, w.feat_spec.p, x.c0.p, x.xs.p, w.coefs.p, w.xm.p,
                        L.erb_conv0_buf, L.df_conv0_buf, L.df_convp_buf, L.mask_buf, L.df_coefs_buf, L.df_spec_buf,
-                       c.B, c.Tc, d.E, d.D, d.F, 0, 0, 0};
+                       c.B, c.Tc, d.E, d.D, d.F, 0, 0, 0, nullptr, 0};
 }
 
 int run_stage1(dpdf_model* m, const ChunkArgs& c) {
@@ -1123,7 +1125,10 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     sio.seg_lo = 0; sio.seg_hi = 4;                    // erb_conv0 / df_conv0 / mask(spec) / df_convp FIFOs
     {
         ProfScope ps(m, "state_io");
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 4, 5), dim3(256), 0, sA, sio);
+        // (a streaming call's pre-call copy of the state rides along in the first import of the call: StateIoArgs.snap)
+        if (m->snap_dst) { sio.snap = m->snap_dst; sio.snap_y = 4; m->snap_dst = nullptr; }
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, 4 + sio.snap_y, 5), dim3(256), 0, sA, sio);
+        sio.snap = nullptr; sio.snap_y = 0;
     }
     {
         ProfScope ps(m, "features");
@@ -1834,6 +1839,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "snapshot") m->snapshot = value != 0;
     else if (n == "single_chunk_inline") m->single_chunk_inline = value != 0;
     else if (n == "fuse_dec") m->fuse_dec = value != 0;
     else if (n == "interleave") m->interleave = value != 0;
@@ -2183,7 +2189,10 @@ static int streams_run(dpdf_streams* s, const float* src, int T, float* dst, int
     dpdf_model* m = s->m;
     const dpdf_dims& d = m->d;
     hipEvent_t ev_state = nullptr;
-    if (snap) {
+    m->snap_dst = nullptr;
+    if (snap && n_act == s->S) {
+        m->snap_dst = s->snap_state.p;       // all streams: the copy rides in the call's first state import (run_stage1)
+    } else if (snap) {
         // the state copy runs on the stage-2 stream (idle until stage 1 of this call is through) beside the staging kernel and
         // the STFT; only the frame function waits for it
         const size_t ns = (size_t)s->S * d.state_size;
@@ -2194,7 +2203,9 @@ static int streams_run(dpdf_streams* s, const float* src, int T, float* dst, int
     }
     if (n_act == s->S) {
         StreamView v{s->S, s->state.p, s->in_tail.p, s->ola_tail.p, snap ? s->snap_in.p : nullptr, snap ? s->snap_ola.p : nullptr, ev_state};
-        return streams_enqueue(s, v, src, T, dst, host_err);
+        const int rc = streams_enqueue(s, v, src, T, dst, host_err);
+        m->snap_dst = nullptr;
+        return rc;
     }
     if (snap) {     // masked call: the packed copies are what the kernels overwrite; the full-set tails are copied here (rare path)
         const size_t nt = (size_t)s->S * d.hop;
@@ -2287,7 +2298,7 @@ extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in,
         if ((rc = s->snap_state.ensure(ns)) || (rc = s->snap_in.ensure(nt)) || (rc = s->snap_ola.ensure(nt))) return rc;
         if (!s->ev_snap) HIP_TRY(hipEventCreateWithFlags(&s->ev_snap, hipEventDisableTiming));
     }
-    if ((rc = streams_run(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx, s->pin_err, true))) return rc;
+    if ((rc = streams_run(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx, s->pin_err, m->snapshot != 0))) return rc;
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (*s->pin_err) {
         *s->pin_err = 0;

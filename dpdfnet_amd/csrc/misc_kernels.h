@@ -482,6 +482,9 @@ struct StateIoArgs {
     int B, Tc, E, D, F;
     int do_export;
     int seg_lo, seg_hi;    // this launch handles segments [seg_lo, seg_hi): 0 erb_conv0, 1 df_conv0, 2 mask spec, 3 df_convp | 4 coefs, 5 masked spec
+    float* snap; int snap_y;   // import only: grid.y rows behind the segments copy the whole state to `snap` (the streaming calls' pre-call copy,
+                               // taken by the first launch that touches the state instead of by a copy on another stream: a cross-stream wait
+                               // on the hop's chain costs ~10 us)
 };
 __device__ __forceinline__ void fifo_io(float* st, float* tensor_frame0 /* frame t=0 of clip */, long frame_sz,
                                         int cap, int Tc, int do_export, int tid, int nthreads, int j) {
@@ -498,8 +501,16 @@ __device__ __forceinline__ void fifo_io(float* st, float* tensor_frame0 /* frame
 __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
     const int b = blockIdx.x, seg = a.seg_lo + blockIdx.y, tid = threadIdx.x;
     const int jz = blockIdx.z;         // FIFO frame handled by this workgroup (grid.z = 5 = deepest FIFO)
-    if (seg >= a.seg_hi) return;
     float* st = a.state + (long)b * a.S;
+    if (seg >= a.seg_hi) {
+        if (a.snap) {
+            const int bid = (seg - a.seg_hi) * gridDim.z + jz, nb = a.snap_y * gridDim.z;
+            float* dp = a.snap + (long)b * a.S;
+            if ((a.S & 3) == 0) for (long i = (long)bid * 256 + tid; i < a.S / 4; i += (long)nb * 256) ((float4*)dp)[i] = ((const float4*)st)[i];
+            else for (long i = (long)bid * 256 + tid; i < a.S; i += (long)nb * 256) dp[i] = st[i];
+        }
+        return;
+    }
     const int Tc = a.Tc;
     if (seg == 0) {
         fifo_io(st + a.off_erb_buf, a.feat_erb + ((size_t)b * (Tc + 2) + 2) * a.E, a.E, 3, Tc, a.do_export, tid, 256, jz);
