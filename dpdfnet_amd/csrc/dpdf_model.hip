@@ -1148,9 +1148,25 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     // alternately, block by block (DprnnWalk): in the latency regime the host is only just ahead of the GPU (~3 us per launch),
     // and a branch whose ~20 launches are enqueued behind the other one's starts that much later -- with 48 band positions
     // against 40 (48 kHz) both chains are critical.  The fork point is the same either way.
-    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fk[c.parity], sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fk[c.parity], 0)); }
     DprnnWalk wdf(m, m->dprnn_df, x.c1.p, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
     DprnnWalk werb(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
+    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fk[c.parity], sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fk[c.parity], 0)); }
+    // the small-launch forms of the two front ends (enc_seg.h), with the first DPRNN block's input projection riding along
+    const bool small_enc = m->fuse_small && m->fuse_enc && BT <= SMALL_M_ROWS;
+    const bool df_seg_ok = small_enc && d.D == 2 * d.Fd && d.Fd % 16 == 0;
+    x.have_pconv = m->df_ring && B * 3 >= 192;
+    const bool df_seg = df_seg_ok && !x.have_pconv;
+    const bool erb_exact = d.F2 == d.F3 * d.s3 && d.F1 == d.F2 * d.s2 && d.Ec == d.F1 * d.s1 && d.F3 % 8 == 0;
+    const int erb_geo = !(small_enc && erb_exact) ? 0 : (d.s1 == 2 && d.s2 == 2 && d.s3 == 1) ? 16 : (d.s1 == 3 && d.s2 == 2 && d.s3 == 2) ? 48 : 0;
+    const bool df_gi = d.nb > 0 && wdf.gi_intra, erb_gi = d.nb > 0 && werb.gi_intra;
+    DfEncArgs dfa{w.feat_spec.p, x.c0.p, x.c1.p, df_gi ? w.gi64.p : nullptr, m->C(m->dfc0_pwfrag), m->C(m->dfc0_bias),
+                  m->C(m->df_conv1.dw), m->C(m->df_conv1.pwfrag), m->C(m->df_conv1.bias),
+                  df_gi ? m->C(m->dprnn_df[0].intra.ih_frag) : nullptr, df_gi ? m->C(m->dprnn_df[0].intra.ih_bias) : nullptr, B, Tc, d.D, d.Fd};
+    ErbEncArgs era{w.feat_erb.p, x.e0.p, x.e1.p, x.e2.p, x.e3.p, m->C(m->conv0_w), m->C(m->conv0_b),
+                   m->C(m->erb_conv1.dw), m->C(m->erb_conv1.pwfrag), m->C(m->erb_conv1.bias),
+                   m->C(m->erb_conv2.dw), m->C(m->erb_conv2.pwfrag), m->C(m->erb_conv2.bias),
+                   m->C(m->erb_conv3.dw), m->C(m->erb_conv3.pwfrag), m->C(m->erb_conv3.bias), B, Tc, d.E, d.Ec, d.F1, d.F2, d.F3,
+                   erb_gi ? w.gi64_e.p : nullptr, erb_gi ? m->C(m->dprnn_erb[0].intra.ih_frag) : nullptr, erb_gi ? m->C(m->dprnn_erb[0].intra.ih_bias) : nullptr};
     // ---- encoder, DF branch (dpdfnet.py:221-234) on the main stream ----
     m->cur = sA;
     TView c0v{x.c0.p, Tc + 4, 4, d.D, 64}, c1v{x.c1.p, Tc, 0, d.Fd, 64};
@@ -1158,23 +1174,17 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         ProfScope ps(m, "enc_convs_df");
         // df_conv1 (+ the DF decoder's pathway conv, + df_conv0 itself): one time-walking pass when clips x 3 workgroups
         // fill the chip, else the time-parallel gemm_rows forms (df_ring.h)
-        x.have_pconv = m->df_ring && B * 3 >= 192;
         const bool conv0_in_ring = x.have_pconv && m->df_ring >= 2;
-        const bool enc_seg = !x.have_pconv && m->fuse_small && m->fuse_enc && BT <= SMALL_M_ROWS && d.D == 2 * d.Fd && d.Fd % 16 == 0;
-        if (enc_seg) {      // latency regime: df_conv0 + df_conv1 + the first block's input projection as one launch (enc_seg.h)
-            const bool with_gi = d.nb > 0 && wdf.gi_intra;
-            DfEncArgs ea{w.feat_spec.p, x.c0.p, x.c1.p, with_gi ? w.gi64.p : nullptr, m->C(m->dfc0_pwfrag), m->C(m->dfc0_bias),
-                         m->C(m->df_conv1.dw), m->C(m->df_conv1.pwfrag), m->C(m->df_conv1.bias),
-                         with_gi ? m->C(m->dprnn_df[0].intra.ih_frag) : nullptr, with_gi ? m->C(m->dprnn_df[0].intra.ih_bias) : nullptr, B, Tc, d.D, d.Fd};
-            hipLaunchKernelGGL(df_enc_seg_kernel, dim3(d.Fd / 16, BT), dim3(256), 0, sA, ea);
-            wdf.intra_gi_ready = with_gi;
+        if (df_seg) {       // latency regime: df_conv0 + df_conv1 + the first block's input projection as one launch (enc_seg.h)
+            hipLaunchKernelGGL(df_enc_seg_kernel, dim3(d.Fd / 16, BT), dim3(256), 0, sA, dfa);
+            wdf.intra_gi_ready = df_gi;
         } else if (!conv0_in_ring) {
             RowMap rm = RowMap::make(Tc, d.D);
             Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm};
             BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
             launch_gemm_rows<4, 32, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 32, 1);
         }
-        if (enc_seg) {
+        if (df_seg) {
         } else if (x.have_pconv) {
             DfRingArgs ra{x.c0.p, x.c1.p, x.pconv.p, m->C(m->df_conv1.dw), m->C(m->df_conv1.pwfrag), m->C(m->df_conv1.bias),
                           m->C(m->convp_frag), m->C(m->convp_bias), B, Tc, w.feat_spec.p, m->C(m->dfc0_pwfrag), m->C(m->dfc0_bias)};
@@ -1189,15 +1199,10 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     TView e0v{x.e0.p, Tc, 0, d.Ec, 64}, e1v{x.e1.p, Tc, 0, d.F1, 64}, e2v{x.e2.p, Tc, 0, d.F2, 64}, e3v{x.e3.p, Tc, 0, d.F3, 64};
     {
         ProfScope ps(m, "enc_convs_erb");
-        const bool exact = d.F2 == d.F3 * d.s3 && d.F1 == d.F2 * d.s2 && d.Ec == d.F1 * d.s1 && d.F3 % 8 == 0;
-        const int geo = !exact ? 0 : (d.s1 == 2 && d.s2 == 2 && d.s3 == 1) ? 16 : (d.s1 == 3 && d.s2 == 2 && d.s3 == 2) ? 48 : 0;
-        if (m->fuse_small && m->fuse_enc && geo && BT <= SMALL_M_ROWS) {       // latency regime: four dependent launches -> one (enc_seg.h)
-            ErbEncArgs ea{w.feat_erb.p, x.e0.p, x.e1.p, x.e2.p, x.e3.p, m->C(m->conv0_w), m->C(m->conv0_b),
-                          m->C(m->erb_conv1.dw), m->C(m->erb_conv1.pwfrag), m->C(m->erb_conv1.bias),
-                          m->C(m->erb_conv2.dw), m->C(m->erb_conv2.pwfrag), m->C(m->erb_conv2.bias),
-                          m->C(m->erb_conv3.dw), m->C(m->erb_conv3.pwfrag), m->C(m->erb_conv3.bias), B, Tc, d.E, d.Ec, d.F1, d.F2, d.F3};
-            if (geo == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(erb_enc_seg_kernel<2, 2, 1, 8>), dim3(d.F3 / 8, BT), dim3(256), 0, sC, ea);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(erb_enc_seg_kernel<3, 2, 2, 8>), dim3(d.F3 / 8, BT), dim3(256), 0, sC, ea);
+        if (erb_geo) {      // latency regime: four dependent launches -> one (enc_seg.h)
+            if (erb_geo == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(erb_enc_seg_kernel<2, 2, 1, 8>), dim3(d.F3 / 8, BT), dim3(256), 0, sC, era);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(erb_enc_seg_kernel<3, 2, 2, 8>), dim3(d.F3 / 8, BT), dim3(256), 0, sC, era);
+            werb.intra_gi_ready = erb_gi;
         } else {
             Conv0ErbArgs ca{w.feat_erb.p, x.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
             size_t rows16 = ((size_t)BT * d.Ec + 15) / 16;
@@ -1224,7 +1229,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_jn[c.parity], sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_jn[c.parity], 0)); }
     // stage 2 may start here: the FIFO export below only reads stage-1 tensors that stage 2 does not write, and writes state
     // segments stage 2 does not touch -- it runs beside the first kernels of stage 2 instead of in front of them
-    HIP_TRY(hipEventRecord(m->ln->ev_s1[c.parity], sA));
+    if ((m->overlap & 1) && !m->ln->single_chunk) HIP_TRY(hipEventRecord(m->ln->ev_s1[c.parity], sA));      // (its only waiter: stage 2 on the stage-2 stream)
     {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;

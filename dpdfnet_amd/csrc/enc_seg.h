@@ -22,7 +22,41 @@ struct ErbEncArgs {
     const float* dw2; const float* pw2; const float* bs2;
     const float* dw3; const float* pw3; const float* bs3;
     int B, Tc, E, Ec, F1, F2, F3;
+    float* gi; const float* ih; const float* ihb;      // (optional) the first DPRNN block's intra-band input projection: [B*Tc*F3][384], W_ih fragments, bias
 };
+
+// gi = W_ih x + b for one 16-row tile held in LDS (rows >= nrows are padding): 24 column tiles of 16 (group = direction * 3 + gate,
+// 4 tiles each; fragments [6][chunk 4][nt 4][kb 4][lane]), 6 per wave; every load is issued before the first MFMA
+__device__ __forceinline__ void enc_seg_gi(const float (*X)[68], const float* __restrict__ ih, const float* __restrict__ ihb, float* __restrict__ gi, int nrows) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
+    float frag[6][16], bv[6];
+#pragma unroll
+    for (int i6 = 0; i6 < 6; ++i6) {
+        const int tt = w * 6 + i6, grp = tt >> 2, nt = tt & 3;
+        const float* fp = ih + (size_t)grp * 4096 + (size_t)nt * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) frag[i6][k] = fp[(size_t)(k >> 2) * 1024 + (k & 3) * 64];
+        bv[i6] = ihb[grp * 64 + nt * 16 + cl];
+    }
+    float av[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 x = *(const float4*)&X[cl][16 * c + 4 * q];
+        av[4 * c + 0] = x.x; av[4 * c + 1] = x.y; av[4 * c + 2] = x.z; av[4 * c + 3] = x.w;
+    }
+#pragma unroll
+    for (int i6 = 0; i6 < 6; ++i6) {
+        const int tt = w * 6 + i6, grp = tt >> 2, nt = tt & 3;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = mfma16(av[k], frag[i6][k], acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * q + i;
+            if (row < nrows) gi[(size_t)row * 384 + grp * 64 + nt * 16 + cl] = acc[i] + bv[i6];
+        }
+    }
+}
 
 // one separable layer over NROW local output rows: src row ro * S + j is input position (lo_out + ro) * S + j - 1
 template <int S, int NROW, int NSRC>
@@ -84,9 +118,12 @@ __global__ __launch_bounds__(256) void erb_enc_seg_kernel(ErbEncArgs a) {
     __shared__ __attribute__((aligned(16))) float E1[N1][68];
     __shared__ __attribute__((aligned(16))) float E2[N2][68];
     __shared__ float Fw[3][N0 + 2];          // features of positions lo0 - 1 .. lo0 + N0, frames t .. t + 2 (zeros outside [0, Ec))
+    __shared__ __attribute__((aligned(16))) float E3[16][68];
+    static_assert(R3 <= 16, "one projection tile");
     const int tid = threadIdx.x;
     const int bt = blockIdx.y, b = bt / a.Tc, t = bt - b * a.Tc;
     const int a3 = blockIdx.x * R3, lo2 = a3 * S3 - 1, lo1 = lo2 * S2 - 1, lo0 = lo1 * S1 - 1;
+    if (a.gi) for (int i = tid; i < (16 - R3) * 68; i += 256) (&E3[R3][0])[i] = 0.f;
     for (int i = tid; i < 3 * (N0 + 2); i += 256) {
         const int kt = i / (N0 + 2), r = i - kt * (N0 + 2), fi = lo0 - 1 + r;
         Fw[kt][r] = (fi >= 0 && fi < a.Ec) ? a.feat[((size_t)b * (a.Tc + 2) + t + kt) * a.E + fi] : 0.f;
@@ -128,7 +165,10 @@ __global__ __launch_bounds__(256) void erb_enc_seg_kernel(ErbEncArgs a) {
     __syncthreads();
     enc_seg_layer<S2, N2, N1>(E1, a.dw2, a.pw2, a.bs2, lo2, a.F2, a3 * S3, (a3 + R3) * S3, a.e2 + (size_t)bt * a.F2 * 64, E2);
     __syncthreads();
-    enc_seg_layer<S3, R3, N2>(E2, a.dw3, a.pw3, a.bs3, a3, a.F3, a3, a3 + R3, a.e3 + (size_t)bt * a.F3 * 64, nullptr);
+    enc_seg_layer<S3, R3, N2>(E2, a.dw3, a.pw3, a.bs3, a3, a.F3, a3, a3 + R3, a.e3 + (size_t)bt * a.F3 * 64, a.gi ? E3 : nullptr);
+    if (!a.gi) return;
+    __syncthreads();
+    enc_seg_gi(E3, a.ih, a.ihb, a.gi + ((size_t)bt * a.F3 + a3) * 384, a.F3 - a3 < R3 ? a.F3 - a3 : R3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -200,31 +240,5 @@ __global__ __launch_bounds__(256) void df_enc_seg_kernel(DfEncArgs a) {
     enc_seg_layer<2, R1, N0>(C0, a.dw1, a.pw1, a.bs1, a1, a.Fd, a1, a1 + R1, a.c1 + (size_t)bt * a.Fd * 64, C1);
     if (!a.gi) return;
     __syncthreads();
-    // ---- gi = W_ih c1 + b: 24 column tiles of 16 (group = direction * 3 + gate, 4 tiles each), 6 per wave
-    {
-        float av[16];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 x = *(const float4*)&C1[cl][16 * c + 4 * q];
-            av[4 * c + 0] = x.x; av[4 * c + 1] = x.y; av[4 * c + 2] = x.z; av[4 * c + 3] = x.w;
-        }
-        float* gi = a.gi + ((size_t)bt * a.Fd + a1) * 384;
-#pragma unroll
-        for (int i6 = 0; i6 < 6; ++i6) {
-            const int tt = w * 6 + i6, grp = tt >> 2, nt = tt & 3;
-            const float* fp = a.ih + (size_t)grp * 4096 + (size_t)nt * 256 + lane;        // [grp][c][nt][kb][lane]
-            float frag[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) frag[k] = fp[(size_t)(k >> 2) * 1024 + (k & 3) * 64];
-            const float bv = a.ihb[grp * 64 + nt * 16 + cl];
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc = mfma16(av[k], frag[k], acc);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 4 * q + i;
-                if (a1 + row < a.Fd) gi[(size_t)row * 384 + grp * 64 + nt * 16 + cl] = acc[i] + bv;
-            }
-        }
-    }
+    enc_seg_gi(C1, a.ih, a.ihb, a.gi + ((size_t)bt * a.Fd + a1) * 384, a.Fd - a1 < R1 ? a.Fd - a1 : R1);
 }
