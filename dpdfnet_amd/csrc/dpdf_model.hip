@@ -274,6 +274,7 @@ struct Lane {
     hipEvent_t ev_dfk[NRING] = {}, ev_djn[NRING] = {}; // decoder fork/join inside stage 2
     bool s2_pending[NRING] = {};
     bool single_chunk = false;          // this call is one chunk: stage 2 on the main stream (run_stage2)
+    bool defer_export = false, export_pending = false; StateIoArgs pending_sio{}; int pending_B = 0;   // a one-chunk call whose caller launches the export later (join_export)
     hipEvent_t ev_x2 = nullptr; bool x2_pending = false;   // behind the stage-2 FIFO export of the latest chunk (joined at the END of a call: run_chunks / join_export)
     bool mask_from_sums = false;                       // this chunk's mask is still three tap sums per band in ws.d1 (run_dec_convs -> run_mask_df)
     Workspace ws;
@@ -330,6 +331,7 @@ struct dpdf_model {
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int late_export = 1;               // streaming hops: the FIFO export behind the overlap-add, the host waits for the output only (0: A/B)
     int snapshot = 1;                  // streaming calls keep a pre-call copy of state and tails for the re-run after a device-side timeout (0: A/B only)
     int single_chunk_inline = 1;       // one-chunk calls: stage 2 on the main stream instead of the stage-2 stream (0: A/B)
     int fuse_dec = 1;                  // ... and the ERB decoder's three stages + mask head (dec_pyr_kernel; 0: A/B)
@@ -376,6 +378,7 @@ struct dpdf_streams {
     // do not spin (recover_and_rerun)
     DevBuf snap_state, snap_in, snap_ola;
     hipEvent_t ev_snap = nullptr;
+    hipEvent_t ev_out = nullptr;       // behind the overlap-add of the latest call: the output is in place (the state export follows it)
     // (Measured and dropped: replaying a captured hipGraph of the hop -- ~110 launches over four streams -- instead of
     // enqueueing them: 781 / 319 / 446 us per hop against 748 / 307 / 433 us with plain launches for 64 x 48 kHz dpdfnet8,
     // one 16 kHz dpdfnet2 and eight dpdfnet4 streams: the hop is bound by the dependent kernels on the GPU, not by the
@@ -1230,11 +1233,11 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     // stage 2 may start here: the FIFO export below only reads stage-1 tensors that stage 2 does not write, and writes state
     // segments stage 2 does not touch -- it runs beside the first kernels of stage 2 instead of in front of them
     if ((m->overlap & 1) && !m->ln->single_chunk) HIP_TRY(hipEventRecord(m->ln->ev_s1[c.parity], sA));      // (its only waiter: stage 2 on the stage-2 stream)
-    {
+    if (!m->ln->single_chunk) {
         ProfScope ps(m, "state_io");
         sio.do_export = 1;
         hipLaunchKernelGGL(state_io_kernel, dim3(B, 4, 5), dim3(256), 0, sA, sio);
-    }
+    }       // (a one-chunk call exports all six FIFOs in one launch at the end of stage 2)
     m->ln->dbg_e3d = x.e3d; m->ln->dbg_c1d = x.c1d; m->ln->dbg_B = B; m->ln->dbg_Tc = Tc; m->ln->dbg_parity = c.parity;
     HIP_TRY(hipGetLastError());
     return DPDF_OK;
@@ -1477,12 +1480,22 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     // the chunk's output is complete HERE: whoever waits for stage 2 (the next-but-one chunk's stage 1 for this XSet, the caller's
     // iSTFT) does not wait for the FIFO export behind it, which only moves stage-2 tensors into stage-2 state segments
     if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_s2[c.parity], st)); m->ln->s2_pending[c.parity] = true; }
-    {
+    if (m->ln->single_chunk) {
+        // One chunk: stage 1's export waited until here (it reads stage-1 tensors that stage 2 does not write) and both go out as one
+        // launch, on the main stream.  (Measured: the same launch on the stage-2 stream, beside the caller's iSTFT instead of in front
+        // of it -- one 16 kHz stream 197 -> 225 us per hop: a cross-stream handoff costs more than the launch it hides.)
         ProfScope ps(m, "state_io");
-        sio.do_export = 1;
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, st, sio);
+        sio.seg_lo = 0; sio.seg_hi = 6; sio.do_export = 1;
+        if (m->ln->defer_export) { m->ln->pending_sio = sio; m->ln->pending_B = B; m->ln->export_pending = true; }     // (join_export)
+        else hipLaunchKernelGGL(state_io_kernel, dim3(B, 6, 5), dim3(256), 0, st, sio);
+    } else {
+        {
+            ProfScope ps(m, "state_io");
+            sio.do_export = 1;
+            hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, st, sio);
+        }
+        if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_x2, st)); m->ln->x2_pending = true; }
     }
-    if (st != m->ln->sA) { HIP_TRY(hipEventRecord(m->ln->ev_x2, st)); m->ln->x2_pending = true; }
     m->ln->dbg_emb = w.emb.p;
     HIP_TRY(hipGetLastError());
     m->cur = m->ln->sA;
@@ -1494,6 +1507,10 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
 // caller asks to do it later (a streaming hop: after the iSTFT and the overlap-add, which do not need the state).
 int join_export(dpdf_model* m) {
     Lane& L = m->lanes[0];
+    if (L.export_pending) {     // a streaming hop: the FIFO export goes BEHIND the iSTFT and the overlap-add -- the caller's wait for the output does not include it
+        hipLaunchKernelGGL(state_io_kernel, dim3(L.pending_B, 6, 5), dim3(256), 0, m->stream, L.pending_sio);
+        L.export_pending = false;
+    }
     if (L.x2_pending) { HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_x2, 0)); L.x2_pending = false; }
     return DPDF_OK;
 }
@@ -1536,6 +1553,7 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     // behind what the caller queued on the main stream in front of this call -- the upload or the initialisation of the very
     // state that import reads.  One event at the head of the call does.
     m->ln->single_chunk = sizes.size() == 1 && m->single_chunk_inline;
+    m->ln->defer_export = defer_export_join && m->late_export;
     if ((m->overlap & 1) && !m->ln->single_chunk) {
         HIP_TRY(hipEventRecord(m->lanes[0].ev_fork, m->stream));
         HIP_TRY(hipStreamWaitEvent(m->lanes[0].sB, m->lanes[0].ev_fork, 0));
@@ -1844,6 +1862,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "late_export") m->late_export = value != 0;
     else if (n == "snapshot") m->snapshot = value != 0;
     else if (n == "single_chunk_inline") m->single_chunk_inline = value != 0;
     else if (n == "fuse_dec") m->fuse_dec = value != 0;
@@ -2091,6 +2110,7 @@ extern "C" void dpdf_streams_destroy(dpdf_streams* s) {
     for (DevBuf* b : bufs) b->release();
     if (s->pin_idx) (void)hipHostFree(s->pin_idx);
     if (s->ev_snap) (void)hipEventDestroy(s->ev_snap);
+    if (s->ev_out) (void)hipEventDestroy(s->ev_out);
     if (s->pin_in) (void)hipHostFree(s->pin_in);
     if (s->pin_out) (void)hipHostFree(s->pin_out);
     if (s->pin_err) (void)hipHostFree(s->pin_err);
@@ -2184,6 +2204,7 @@ static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* sr
         }
     }
     HIP_TRY(hipGetLastError());
+    if (s->ev_out) HIP_TRY(hipEventRecord(s->ev_out, m->stream));
     return join_export(m);          // the state is complete behind this point of the main stream
 }
 
@@ -2302,9 +2323,13 @@ extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in,
         const size_t ns = (size_t)S * d.state_size, nt = (size_t)S * d.hop;
         if ((rc = s->snap_state.ensure(ns)) || (rc = s->snap_in.ensure(nt)) || (rc = s->snap_ola.ensure(nt))) return rc;
         if (!s->ev_snap) HIP_TRY(hipEventCreateWithFlags(&s->ev_snap, hipEventDisableTiming));
+        if (!s->ev_out) HIP_TRY(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
     }
     if ((rc = streams_run(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx, s->pin_err, m->snapshot != 0))) return rc;
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    // all streams active: the output (and the error flag's mirror) is in place behind the overlap-add; the state export that follows it
+    // on the stream is not waited for -- whatever touches the state next is ordered behind it, and the getters synchronise the stream
+    if (n_act == S && m->late_export) HIP_TRY(hipEventSynchronize(s->ev_out));
+    else HIP_TRY(hipStreamSynchronize(m->stream));
     if (*s->pin_err) {
         *s->pin_err = 0;
         if ((rc = streams_recover_and_rerun(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx))) return rc;
