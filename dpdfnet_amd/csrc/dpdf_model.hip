@@ -331,6 +331,9 @@ struct dpdf_model {
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int enc_seg_rows = 512, dec_pyr_rows = 512;      // frame rows up to which the pyramid kernels (enc_seg.h, dec_pyr.h) replace the per-layer launches.  They are latency forms
+                                                      // (weights re-read per workgroup): at 256 clips x 10 s they are bit-identical but not faster (tools/offline_ab.py: 48 kHz 152.9 -> 153.5 /
+                                                      // 162.8 ms per step, 16 kHz 107.0 -> 109.2 / 109.6)
     int late_export = 1;               // streaming hops: the FIFO export behind the overlap-add, the host waits for the output only (0: A/B)
     int snapshot = 1;                  // streaming calls keep a pre-call copy of state and tails for the re-run after a device-side timeout (0: A/B only)
     int single_chunk_inline = 1;       // one-chunk calls: stage 2 on the main stream instead of the stage-2 stream (0: A/B)
@@ -1155,7 +1158,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     DprnnWalk werb(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fk[c.parity], sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fk[c.parity], 0)); }
     // the small-launch forms of the two front ends (enc_seg.h), with the first DPRNN block's input projection riding along
-    const bool small_enc = m->fuse_small && m->fuse_enc && BT <= SMALL_M_ROWS;
+    const bool small_enc = m->fuse_small && m->fuse_enc && BT <= m->enc_seg_rows;
     const bool df_seg_ok = small_enc && d.D == 2 * d.Fd && d.Fd % 16 == 0;
     x.have_pconv = m->df_ring && B * 3 >= 192;
     const bool df_seg = df_seg_ok && !x.have_pconv;
@@ -1257,7 +1260,7 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
     const bool geo48 = m->dec_seg && BT >= 1024 && d.is48 &&   // (few frames: the gemm_rows forms spread over more workgroups: 64 x 48 kHz streams, one hop 767 -> 753 us)
                         m->fuse_mask && d.s3 == 2 && d.s2 == 2 && d.s1 == 3 && d.F2 % 80 == 0 && d.F1 % 80 == 0 && d.Ec % 96 == 0;
     const bool exact = d.F2 == d.F3 * d.s3 && d.F1 == d.F2 * d.s2 && d.Ec == d.F1 * d.s1;
-    const int pyr = !(m->fuse_small && m->fuse_dec && m->fuse_mask && exact && BT <= SMALL_M_ROWS) ? 0
+    const int pyr = !(m->fuse_small && m->fuse_dec && m->fuse_mask && exact && BT <= m->dec_pyr_rows) ? 0
                     : geo16 ? 16 : (d.is48 && d.s1 == 3 && d.s2 == 2 && d.s3 == 2 && d.F3 % 8 == 0) ? 48 : 0;
     if (pyr) {      // latency regime: the three stages + the mask head's tap sums as one launch (dec_pyr.h)
         DecPyrArgs pa{x.e3.p, dembp, x.e2.p, x.e1.p, x.e0.p, pyr == 48 ? w.d1.p : nullptr, pyr == 16 ? w.m.p : nullptr,
@@ -1267,7 +1270,11 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
                       m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias, BT, d.F3, d.F2, d.F1, d.Ec, d.E};
         if (pyr == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_pyr_kernel<2, 2, 1, 8, true>), dim3(1, BT), dim3(256), 0, st, pa);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_pyr_kernel<3, 2, 2, 8, false>), dim3(d.F3 / 8, BT), dim3(256), 0, st, pa);
-        m->ln->mask_from_sums = pyr == 48;      // (the tap sums are finished inside mask_df_kernel)
+        m->ln->mask_from_sums = pyr == 48 && BT <= SMALL_M_ROWS;      // (the tap sums are finished inside mask_df_kernel)
+        if (pyr == 48 && !m->ln->mask_from_sums) {
+            MaskFinArgs mf{w.d1.p, w.m.p, m->c0out_bias, BT * d.Ec, d.Ec, d.E, d.is48};
+            hipLaunchKernelGGL(mask_fin_kernel, dim3((BT * d.Ec + 255) / 256), dim3(256), 0, st, mf);
+        }
         return;
     }
     if (geo48) {    // 48 kHz geometry: tiles of 80 / 80 / 96 output bands of one frame, inputs loaded once (dec_last.h: dec_seg_kernel)
@@ -1862,6 +1869,8 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "enc_seg_rows") m->enc_seg_rows = value;
+    else if (n == "dec_pyr_rows") m->dec_pyr_rows = value;
     else if (n == "late_export") m->late_export = value != 0;
     else if (n == "snapshot") m->snapshot = value != 0;
     else if (n == "single_chunk_inline") m->single_chunk_inline = value != 0;
