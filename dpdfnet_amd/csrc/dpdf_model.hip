@@ -274,6 +274,7 @@ struct Lane {
     hipEvent_t ev_dfk[NRING] = {}, ev_djn[NRING] = {}; // decoder fork/join inside stage 2
     bool s2_pending[NRING] = {};
     bool single_chunk = false;          // this call is one chunk: stage 2 on the main stream (run_stage2)
+    bool s1_imported = false;           // stage 1's FIFO import of the coming one-frame chunk was done by the caller's prologue launch
     bool defer_export = false, export_pending = false; StateIoArgs pending_sio{}; int pending_B = 0;   // a one-chunk call whose caller launches the export later (join_export)
     hipEvent_t ev_x2 = nullptr; bool x2_pending = false;   // behind the stage-2 FIFO export of the latest chunk (joined at the END of a call: run_chunks / join_export)
     bool mask_from_sums = false;                       // this chunk's mask is still three tap sums per band in ws.d1 (run_dec_convs -> run_mask_df)
@@ -331,6 +332,7 @@ struct dpdf_model {
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int hop_prologue = 1;              // single hops of > 4 streams: staging + stage-1 FIFO import + state copy as one launch in front of the STFT (0: A/B)
     int enc_seg_rows = 512, dec_pyr_rows = 512;      // frame rows up to which the pyramid kernels (enc_seg.h, dec_pyr.h) replace the per-layer launches.  They are latency forms
                                                       // (weights re-read per workgroup): at 256 clips x 10 s they are bit-identical but not faster (tools/offline_ab.py: 48 kHz 152.9 -> 153.5 /
                                                       // 162.8 ms per step, 16 kHz 107.0 -> 109.2 / 109.6)
@@ -1112,7 +1114,7 @@ StateIoArgs make_sio(dpdf_model* m, const ChunkArgs& c, XSet& x) {
     const dpdf_dims& d = m->d; const dpdf_state_layout& L = m->L; Workspace& w = m->ln->ws;
     return StateIoArgs{c.state, (long)d.state_size, w.feat_erb.p, w.feat_spec.p, x.c0.p, x.xs.p, w.coefs.p, w.xm.p,
                        L.erb_conv0_buf, L.df_conv0_buf, L.df_convp_buf, L.mask_buf, L.df_coefs_buf, L.df_spec_buf,
-                       c.B, c.Tc, d.E, d.D, d.F, 0, 0, 0, nullptr, 0};
+                       c.B, c.Tc, d.E, d.D, d.F, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
 }
 
 int run_stage1(dpdf_model* m, const ChunkArgs& c) {
@@ -1129,7 +1131,9 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     }
     StateIoArgs sio = make_sio(m, c, x);
     sio.seg_lo = 0; sio.seg_hi = 4;                    // erb_conv0 / df_conv0 / mask(spec) / df_convp FIFOs
-    {
+    if (m->ln->s1_imported) {       // a streaming hop's prologue launch did it (streams_enqueue)
+        m->ln->s1_imported = false;
+    } else {
         ProfScope ps(m, "state_io");
         // (a streaming call's pre-call copy of the state rides along in the first import of the call: StateIoArgs.snap)
         if (m->snap_dst) { sio.snap = m->snap_dst; sio.snap_y = 4; m->snap_dst = nullptr; }
@@ -1869,6 +1873,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "hop_prologue") m->hop_prologue = value != 0;
     else if (n == "enc_seg_rows") m->enc_seg_rows = value;
     else if (n == "dec_pyr_rows") m->dec_pyr_rows = value;
     else if (n == "late_export") m->late_export = value != 0;
@@ -2174,6 +2179,21 @@ static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* sr
     const bool in_place = S * T <= 4;
     m->hx = dpdf_model::HopExtras{};
     float* xbuf = s->pcm_in.p;                       // [S][(T+1)*hop]
+    // Single hops with staging: ONE prologue launch in front of the STFT does the staging, stage 1's FIFO import (it depends on the
+    // previous call only) and the pre-call state copy -- instead of a staging launch here and an import launch behind the STFT.
+    m->lanes[0].s1_imported = false;
+    const bool prologue = !in_place && T == 1 && m->hop_prologue && !m->prof_on && S <= SMALL_M_ROWS;
+    if (prologue) {
+        m->ln = &m->lanes[0];
+        if ((rc = init_lane(m->lanes[0])) || (rc = ensure_ws(m, S, 1))) return rc;
+        ChunkArgs c{s->spec.p, (size_t)T * d.F * 2, S, 1, v.state, s->spec_e.p, (size_t)T * d.F * 2, 0, nullptr, 0.f, 0};
+        StateIoArgs sio = make_sio(m, c, m->ln->ws.x[0]);
+        sio.seg_lo = 0; sio.seg_hi = 4;
+        if (m->snap_dst) { sio.snap = m->snap_dst; sio.snap_y = 4; m->snap_dst = nullptr; }
+        sio.si_pcm = src; sio.si_tail = v.in_tail; sio.si_xbuf = xbuf; sio.si_snap = v.snap_in; sio.si_hops = T; sio.si_hop = d.hop;
+        hipLaunchKernelGGL(state_io_kernel, dim3(S, 4 + sio.snap_y + 1, 5), dim3(256), 0, m->stream, sio);
+        m->ln->s1_imported = true;
+    } else
     if (!in_place) hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, v.in_tail, xbuf, S, T, d.hop, v.snap_in);
     {
         StftA<64> ap{in_place ? src : xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};

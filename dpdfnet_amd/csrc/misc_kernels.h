@@ -482,6 +482,9 @@ struct StateIoArgs {
     int B, Tc, E, D, F;
     int do_export;
     int seg_lo, seg_hi;    // this launch handles segments [seg_lo, seg_hi): 0 erb_conv0, 1 df_conv0, 2 mask spec, 3 df_convp | 4 coefs, 5 masked spec
+    // import only, a streaming call's prologue (streams_enqueue): one more grid.y row behind the snapshot rows stages [analysis tail | new samples]
+    // of every stream for the STFT and hands the tails over (stream_stage_in_kernel's work: one dependent launch less in front of the STFT)
+    const float* si_pcm; float* si_tail; float* si_xbuf; float* si_snap; int si_hops, si_hop;
     float* snap; int snap_y;   // import only: grid.y rows behind the segments copy the whole state to `snap` (the streaming calls' pre-call copy,
                                // taken by the first launch that touches the state instead of by a copy on another stream: a cross-stream wait
                                // on the hop's chain costs ~10 us)
@@ -502,6 +505,21 @@ __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
     const int b = blockIdx.x, seg = a.seg_lo + blockIdx.y, tid = threadIdx.x;
     const int jz = blockIdx.z;         // FIFO frame handled by this workgroup (grid.z = 5 = deepest FIFO)
     float* st = a.state + (long)b * a.S;
+    if (seg >= a.seg_hi + a.snap_y) {
+        if (a.si_xbuf && seg == a.seg_hi + a.snap_y && jz == 0) {
+            const int hop = a.si_hop, n = a.si_hops * hop;
+            float* xb = a.si_xbuf + (size_t)b * (n + hop);
+            for (int i = tid; i < hop; i += 256) {
+                const float v = a.si_tail[(size_t)b * hop + i];
+                xb[i] = v;
+                if (a.si_snap) a.si_snap[(size_t)b * hop + i] = v;
+            }
+            for (int i = tid; i < n; i += 256) xb[hop + i] = a.si_pcm[(size_t)b * n + i];
+            __syncthreads();
+            for (int i = tid; i < hop; i += 256) a.si_tail[(size_t)b * hop + i] = xb[n + i];
+        }
+        return;
+    }
     if (seg >= a.seg_hi) {
         if (a.snap) {
             const int bid = (seg - a.seg_hi) * gridDim.z + jz, nb = a.snap_y * gridDim.z;
