@@ -1130,16 +1130,17 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         m->ln->s2_pending[c.parity] = false;
     }
     StateIoArgs sio = make_sio(m, c, x);
-    sio.seg_lo = 0; sio.seg_hi = 4;                    // erb_conv0 / df_conv0 / mask(spec) / df_convp FIFOs
+    sio.seg_lo = 0; sio.seg_hi = m->ln->single_chunk ? 6 : 4;      // erb_conv0 / df_conv0 / mask(spec) / df_convp FIFOs (+ stage 2's two in a one-chunk call: one launch less on its chain)
     if (m->ln->s1_imported) {       // a streaming hop's prologue launch did it (streams_enqueue)
         m->ln->s1_imported = false;
     } else {
         ProfScope ps(m, "state_io");
         // (a streaming call's pre-call copy of the state rides along in the first import of the call: StateIoArgs.snap)
         if (m->snap_dst) { sio.snap = m->snap_dst; sio.snap_y = 4; m->snap_dst = nullptr; }
-        hipLaunchKernelGGL(state_io_kernel, dim3(B, 4 + sio.snap_y, 5), dim3(256), 0, sA, sio);
+        hipLaunchKernelGGL(state_io_kernel, dim3(B, sio.seg_hi + sio.snap_y, 5), dim3(256), 0, sA, sio);
         sio.snap = nullptr; sio.snap_y = 0;
     }
+    sio.seg_hi = 4;
     {
         ProfScope ps(m, "features");
         FeatAArgs fa{c.raw, c.raw_clip_stride, x.xs.p, w.feat_erb.p, d.is48 ? nullptr : m->iconsts, B, Tc, d.F, d.E, d.is48, d.wnorm};
@@ -1363,7 +1364,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     m->cur = st;
     StateIoArgs sio = make_sio(m, c, x);
     sio.seg_lo = 4; sio.seg_hi = 6;                    // DF coefs delay / masked-spec FIFOs
-    {   // the FIFO import touches stage-2 tensors and stage-2 state only: it runs BEFORE the wait for stage 1 (off the hop's critical chain)
+    if (!m->ln->single_chunk) {   // the FIFO import touches stage-2 tensors and stage-2 state only: it runs BEFORE the wait for stage 1 (a one-chunk call: done by stage 1's import launch)
         ProfScope ps(m, "state_io");
         hipLaunchKernelGGL(state_io_kernel, dim3(B, 2, 5), dim3(256), 0, st, sio);
     }
@@ -2188,10 +2189,10 @@ static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* sr
         if ((rc = init_lane(m->lanes[0])) || (rc = ensure_ws(m, S, 1))) return rc;
         ChunkArgs c{s->spec.p, (size_t)T * d.F * 2, S, 1, v.state, s->spec_e.p, (size_t)T * d.F * 2, 0, nullptr, 0.f, 0};
         StateIoArgs sio = make_sio(m, c, m->ln->ws.x[0]);
-        sio.seg_lo = 0; sio.seg_hi = 4;
+        sio.seg_lo = 0; sio.seg_hi = m->single_chunk_inline ? 6 : 4;      // (as run_stage1's import of a one-chunk call)
         if (m->snap_dst) { sio.snap = m->snap_dst; sio.snap_y = 4; m->snap_dst = nullptr; }
         sio.si_pcm = src; sio.si_tail = v.in_tail; sio.si_xbuf = xbuf; sio.si_snap = v.snap_in; sio.si_hops = T; sio.si_hop = d.hop;
-        hipLaunchKernelGGL(state_io_kernel, dim3(S, 4 + sio.snap_y + 1, 5), dim3(256), 0, m->stream, sio);
+        hipLaunchKernelGGL(state_io_kernel, dim3(S, sio.seg_hi + sio.snap_y + 1, 5), dim3(256), 0, m->stream, sio);
         m->ln->s1_imported = true;
     } else
     if (!in_place) hipLaunchKernelGGL(stream_stage_in_kernel, dim3(S), dim3(256), 0, m->stream, src, v.in_tail, xbuf, S, T, d.hop, v.snap_in);
