@@ -332,6 +332,7 @@ struct dpdf_model {
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int hop_dec_fork = 1;              // one-chunk calls: the DF decoder still forks onto its own stream beside the ERB decoder (0: A/B)
     int hop_prologue = 1;              // single hops of > 4 streams: staging + stage-1 FIFO import + state copy as one launch in front of the STFT (0: A/B)
     int enc_seg_rows = 512, dec_pyr_rows = 512;      // frame rows up to which the pyramid kernels (enc_seg.h, dec_pyr.h) replace the per-layer launches.  They are latency forms
                                                       // (weights re-read per workgroup): at 256 clips x 10 s they are bit-identical but not faster (tools/offline_ab.py: 48 kHz 152.9 -> 153.5 /
@@ -1398,9 +1399,14 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         run_gl_auto(m, m->enc_lin_in, w.embin.p, 1024, w.g256a.p, 256, BT, ACT_RELU);
     }
     run_gru256(m, m->enc_gru, w.g256a.p, w.g256b.p, state, S, L.emb_gru, B, Tc);
-    const bool fork = (m->overlap & 8) && st != m->ln->sA;
-    float* df_ga = fork ? w.g256d.p : w.g256a.p;
-    if (smallm && fork) {
+    const bool fork = (m->overlap & 8) && (st != m->ln->sA || (m->ln->single_chunk && m->hop_dec_fork));
+    // fanned: the four linears behind the embedding GRU in one launch (emb_out_mfma_kernel) and the DF decoder's sum in df_out's A
+    // producer -- with the decoders side by side, and in a one-chunk call also when they run one after the other on the main stream
+    // (four dependent launches less); the DF decoder then works in its own granule buffers either way
+    const bool fanned = smallm && (fork || m->ln->single_chunk);
+    const bool sep = fork || fanned;
+    float* df_ga = sep ? w.g256d.p : w.g256a.p;
+    if (fanned) {
         ProfScope ps(m, "grouped_linear");
         EmbOutMArgs ea{w.g256b.p, glfrag(m->enc_lin_out), glfrag(m->df_lin_in), glfrag(m->ed_lin_in), glfrag(m->df_skip),
                        w.emb.p, df_ga, w.g256a.p, w.skipb.p, BT};
@@ -1409,7 +1415,6 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->enc_lin_out, w.g256b.p, 256, w.emb.p, 512, BT, ACT_RELU);
     }
-    const bool fanned = smallm && fork;
     // The two decoders only share `emb`: the DF decoder (2 GRU-256 cells, df_out, pathway conv) runs on its own stream
     // beside the ERB decoder (2 cells, transposed convs, mask) -- the five latency-bound cell scans become three deep.
     hipStream_t sd = fork ? m->ln->sD : st;
@@ -1417,7 +1422,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     // ---- DF decoder (dpdfnet.py:486-519) ----
     {
         m->cur = sd;
-        float* ga = fork ? w.g256d.p : w.g256a.p; float* gb = fork ? w.g256e.p : w.g256b.p; float* gc = fork ? w.g256f.p : w.g256c.p;
+        float* ga = sep ? w.g256d.p : w.g256a.p; float* gb = sep ? w.g256e.p : w.g256b.p; float* gc = sep ? w.g256f.p : w.g256c.p;
         const int which = fork ? 1 : 0;
         if (!fanned) {
             ProfScope ps(m, "grouped_linear");
@@ -1874,6 +1879,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "hop_dec_fork") m->hop_dec_fork = value != 0;
     else if (n == "hop_prologue") m->hop_prologue = value != 0;
     else if (n == "enc_seg_rows") m->enc_seg_rows = value;
     else if (n == "dec_pyr_rows") m->dec_pyr_rows = value;
