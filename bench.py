@@ -227,11 +227,15 @@ def other_configs() -> dict:
         # GRU-64 steps + one glue launch); the DF branch (F' = 48) is the longer one.  Measured minima on this chip
         # (rocprofv3 trace of single hops, profiles/r3_stream_hop_*): 0.55 us per 4-row scan step (64 x 8.4-cycle
         # v_mfma_f32_4x4x1 + one LDS round trip + the gate chain), ~1.5 us per dependent kernel boundary.
+        # Launches on the chain of a one-chunk call (main stream; the decoders one after the other): prologue / import, STFT,
+        # features, encoder front end (+ projection at 48 kHz x 64), nb x (scan, glue), emb_in, 5 GRU-256 steps, emb_out, df_out,
+        # pathway conv, dec_in, decoder pyramid, mask + deep filter, iSTFT, overlap-add = 2 nb + 19 (it was 2 nb + 30 at mid-round).
         steps = nb_ * d.Fd
-        bound_us = steps * 0.55 + (2 * nb_ + 30) * 1.5
+        chain = 2 * nb_ + 19
+        bound_us = steps * 0.55 + chain * 1.5
         return {"us_per_call": round(1e6 * dt, 1), "frames_per_s": round(S / dt), "rtf": round(dt / (hop / sr_), 4),
                 "mfma_frac": mfma(S / dt, sr_, nb_),
-                "latency_model": {"dependent_gru64_steps": steps, "dependent_launches_on_critical_path": 2 * nb_ + 30,
+                "latency_model": {"dependent_gru64_steps": steps, "dependent_launches_on_critical_path": chain,
                                   "bound_us": round(bound_us, 1), "achieved_over_bound": round(1e6 * dt / bound_us, 2)},
                 "io": "host PCM in, host PCM out (pinned staging, zero-copy), one device call per hop"}
 
