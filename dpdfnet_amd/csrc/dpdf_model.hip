@@ -332,7 +332,8 @@ struct dpdf_model {
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
-    int hop_dec_fork = 1;              // one-chunk calls: the DF decoder still forks onto its own stream beside the ERB decoder (0: A/B)
+    int dual_step = 1;                 // streaming hops with the decoders in series: the two decoders' GRU-256 steps pairwise in one launch (0: A/B)
+    int hop_dec_fork = 0;              // one-chunk calls: 1 = the DF decoder forks onto its own stream beside the ERB decoder (measured 4-14 us slower per hop than in series: two handoffs)
     int hop_prologue = 1;              // single hops of > 4 streams: staging + stage-1 FIFO import + state copy as one launch in front of the STFT (0: A/B)
     int enc_seg_rows = 512, dec_pyr_rows = 512;      // frame rows up to which the pyramid kernels (enc_seg.h, dec_pyr.h) replace the per-layer launches.  They are latency forms
                                                       // (weights re-read per workgroup): at 256 clips x 10 s they are bit-identical but not faster (tools/offline_ab.py: 48 kHz 152.9 -> 153.5 /
@@ -834,7 +835,7 @@ bool run_gru256_stack(dpdf_model* m, const Gru256W& g0, const Gru256W& g1, const
 }
 
 // One frame per stream: input projection + cell step as ONE launch (gru_stack.h: gru256_step_kernel)
-bool run_gru256_step(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int which) {
+bool prep_gru256_step(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int which, Gru256StepArgs& a) {
     if (!m->gru256_step || !m->use_gru256_cluster || which < 0 || which > 4) return false;
     Lane& L = *m->ln;
     const int ntiles = (B + 15) / 16;
@@ -853,10 +854,26 @@ bool run_gru256_step(dpdf_model* m, const Gru256W& g, const float* x, float* out
         L.arrive_count[which] = 0;
     }
     L.arrive_count[which] += 16;
+    a = Gru256StepArgs{x, out, m->C(g.ih_as_hh), m->C(g.hh_frag), m->C(g.ih_bias), m->C(g.b_hn), state + hoff, S, B, L.arrive[which], m->d_err};
+    return true;
+}
+bool run_gru256_step(dpdf_model* m, const Gru256W& g, const float* x, float* out, float* state, long S, int hoff, int B, int which) {
+    Gru256StepArgs a{};
+    if (!prep_gru256_step(m, g, x, out, state, S, hoff, B, which, a)) return false;
     ProfScope ps(m, "gru256_scan");
-    Gru256StepArgs a{x, out, m->C(g.ih_as_hh), m->C(g.hh_frag), m->C(g.ih_bias), m->C(g.b_hn), state + hoff, S, B,
-                     L.arrive[which], m->d_err};
-    hipLaunchKernelGGL(gru256_step_kernel, dim3(ntiles * 16), dim3(256), 0, m->cur, a);
+    hipLaunchKernelGGL(gru256_step_kernel, dim3(((B + 15) / 16) * 16), dim3(256), 0, m->cur, a);
+    return true;
+}
+// two independent cells' steps as one launch (arrival counter sets wa / wb); false: not eligible, nothing launched
+bool run_gru256_step_dual(dpdf_model* m, const Gru256W& ga, const float* xa, float* oa, int ha, int wa,
+                          const Gru256W& gb, const float* xb, float* ob, int hb, int wb, float* state, long S, int B) {
+    if (!m->gru256_step || !m->use_gru256_cluster) return false;
+    Gru256StepArgs a{}, b{};
+    if (!prep_gru256_step(m, ga, xa, oa, state, S, ha, B, wa, a)) return false;
+    if (!prep_gru256_step(m, gb, xb, ob, state, S, hb, B, wb, b)) { m->ln->arrive_count[wa] -= 16; return false; }
+    ProfScope ps(m, "gru256_scan");
+    const int n0 = ((B + 15) / 16) * 16;
+    hipLaunchKernelGGL(gru256_step_dual_kernel, dim3(2 * n0), dim3(256), 0, m->cur, a, b, n0);
     return true;
 }
 
@@ -1418,6 +1435,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     // The two decoders only share `emb`: the DF decoder (2 GRU-256 cells, df_out, pathway conv) runs on its own stream
     // beside the ERB decoder (2 cells, transposed convs, mask) -- the five latency-bound cell scans become three deep.
     hipStream_t sd = fork ? m->ln->sD : st;
+    bool dec_steps_done = false;
     if (fork) { HIP_TRY(hipEventRecord(m->ln->ev_dfk[c.parity], st)); HIP_TRY(hipStreamWaitEvent(sd, m->ln->ev_dfk[c.parity], 0)); }
     // ---- DF decoder (dpdfnet.py:486-519) ----
     {
@@ -1428,6 +1446,13 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
             ProfScope ps(m, "grouped_linear");
             run_gl_auto(m, m->df_lin_in, w.emb.p, 512, ga, 256, BT, ACT_RELU);
         }
+        // one frame per stream, the decoders one after the other on this stream: their first cells step in one launch, then their
+        // second cells (they only share `emb`) -- four dependent step launches become two
+        if (fanned && !fork && Tc == 1 && m->dual_step &&
+            run_gru256_step_dual(m, m->df_gru0, ga, gb, L.df_dec_gru, 1, m->ed_gru0, w.g256a.p, w.g256b.p, L.erb_dec_gru, 0, state, S, B) &&
+            run_gru256_step_dual(m, m->df_gru1, gb, gc, L.df_dec_gru + 256, 1, m->ed_gru1, w.g256b.p, w.g256c.p, L.erb_dec_gru + 256, 0, state, S, B)) {
+            dec_steps_done = true;
+        } else
         if (!run_gru256_stack(m, m->df_gru0, m->df_gru1, ga, gb, gc, state, S, L.df_dec_gru, B, Tc, which)) {
             run_gru256(m, m->df_gru0, ga, gb, state, S, L.df_dec_gru, B, Tc, which);
             run_gru256(m, m->df_gru1, gb, gc, state, S, L.df_dec_gru + 256, B, Tc, which);
@@ -1476,7 +1501,8 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->ed_lin_in, w.emb.p, 512, w.g256a.p, 256, BT, ACT_RELU);
     }
-    if (!run_gru256_stack(m, m->ed_gru0, m->ed_gru1, w.g256a.p, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru, B, Tc, 0)) {
+    if (dec_steps_done) {
+    } else if (!run_gru256_stack(m, m->ed_gru0, m->ed_gru1, w.g256a.p, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru, B, Tc, 0)) {
         run_gru256(m, m->ed_gru0, w.g256a.p, w.g256b.p, state, S, L.erb_dec_gru, B, Tc);
         run_gru256(m, m->ed_gru1, w.g256b.p, w.g256c.p, state, S, L.erb_dec_gru + 256, B, Tc);
     }
@@ -1879,6 +1905,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "dual_step") m->dual_step = value != 0;
     else if (n == "hop_dec_fork") m->hop_dec_fork = value != 0;
     else if (n == "hop_prologue") m->hop_prologue = value != 0;
     else if (n == "enc_seg_rows") m->enc_seg_rows = value;

@@ -250,13 +250,13 @@ struct Gru256StepArgs {
     int* err;
 };
 
-__global__ __launch_bounds__(256, 1) void gru256_step_kernel(Gru256StepArgs a) {
+__device__ __forceinline__ void gru256_step_body(const Gru256StepArgs& a, const int bx) {
     __shared__ __attribute__((aligned(16))) float Xs[16][260];
     __shared__ __attribute__((aligned(16))) float Hs[16][260];
     __shared__ float Ps[4][4][4][64];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int cl = lane & 15, q = lane >> 4;
-    const int rt = blockIdx.x >> 4, j = blockIdx.x & 15;
+    const int rt = bx >> 4, j = bx & 15;
     const int row0 = rt * 16, u0 = 16 * j;
     for (int idx = tid; idx < 16 * 64; idx += 256) {
         const int r = idx >> 6, c4 = (idx & 63) * 4;
@@ -326,4 +326,11 @@ __global__ __launch_bounds__(256, 1) void gru256_step_kernel(Gru256StepArgs a) {
     }
     __syncthreads();
     if (ok) a.hstate[(long)r_own * a.h_stride + u0 + cl] = h_new;
+}
+__global__ __launch_bounds__(256, 1) void gru256_step_kernel(Gru256StepArgs a) { gru256_step_body(a, blockIdx.x); }
+// Two independent cells' steps (the DF and the ERB decoder's first -- then second -- cell of a streaming hop; each with its own
+// arrival counters) as ONE launch: the decoders' four dependent step launches become two.
+__global__ __launch_bounds__(256, 1) void gru256_step_dual_kernel(Gru256StepArgs a0, Gru256StepArgs a1, int n0) {
+    if ((int)blockIdx.x < n0) gru256_step_body(a0, blockIdx.x);
+    else gru256_step_body(a1, blockIdx.x - n0);
 }
