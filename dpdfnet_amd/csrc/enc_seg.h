@@ -189,14 +189,34 @@ struct DfEncArgs {
     const float* dw1; const float* pw1; const float* bs1;
     const float* ih; const float* ihb;      // W_ih fragments [6][chunk 4][nt 4][kb 4][lane], bias [6][64]
     int B, Tc, D, Fd;
+    // Tc == 1 only (a streaming hop: the four older frames are the imported halo of c0, written before this launch): the DF decoder's
+    // pathway conv df_convp -- grouped k(5,1) over the last five c0 frames + pointwise + BN + ReLU, folded into one [320 -> 10] matrix
+    // (reference dpdfnet.py:424-431, 508-515) -- for the 32 bands this workgroup owns, as in df_ring_kernel (df_ring.h: same operand
+    // order, so the same p): one launch less in stage 2, where df_out's epilogue then only ADDS p
+    float* p; const float* cpfrag; const float* cpbias;     // p [B*Tc][D][10]; fragments [chunk 20][kb 4][lane]; bias [10]
 };
 __global__ __launch_bounds__(256) void df_enc_seg_kernel(DfEncArgs a) {
     constexpr int R1 = 16, N0 = 2 * R1 + 1;
     __shared__ __attribute__((aligned(16))) float C0[N0][68];       // row r = band 2 a1 - 1 + r
     __shared__ __attribute__((aligned(16))) float C1[R1][68];
+    __shared__ float Pz[2][4][64];                                  // pathway partial sums of the upper K half
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
     const int bt = blockIdx.y, b = bt / a.Tc, t = bt - b * a.Tc;
     const int a1 = blockIdx.x * R1, lo0 = 2 * a1 - 1;
+    // pathway conv operands, up front: wave (mt = row tile, kh = K half); chunk cg = 4 kt + cc <-> frame t - 4 + kt, channels 16 cc ..
+    const int mt = w & 1, kh = w >> 1;
+    float cp[40]; float4 hist[10];
+    if (a.p) {
+#pragma unroll
+        for (int i = 0; i < 40; ++i) cp[i] = a.cpfrag[(size_t)(40 * kh + i) * 64 + lane];
+        const int band = 2 * a1 + mt * 16 + cl;
+#pragma unroll
+        for (int ci = 0; ci < 10; ++ci) {
+            const int cg = 10 * kh + ci, kt = cg >> 2, cc = cg & 3;
+            hist[ci] = (kt < 4 && band < a.D) ? *(const float4*)(a.c0 + (((size_t)b * (a.Tc + 4) + t + kt) * a.D + band) * 64 + cc * 16 + 4 * q)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     // ---- df_conv0: column k = 16 c + 4 q + kb of the im2col row = frame t - 2 + kt, group g, band f + kb - 1 with kt = 2 c + (q >> 1), g = q & 1
     {
         float frag[8];
@@ -236,6 +256,32 @@ __global__ __launch_bounds__(256) void df_enc_seg_kernel(DfEncArgs a) {
         }
     }
     __syncthreads();
+    // ---- pathway conv over frames t - 4 .. t of the owned bands (the newest frame from C0)
+    if (a.p) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ci = 0; ci < 10; ++ci) {
+            const int cg = 10 * kh + ci, kt = cg >> 2, cc = cg & 3;
+            const float4 a4 = kt < 4 ? hist[ci] : *(const float4*)&C0[1 + mt * 16 + cl][cc * 16 + 4 * q];
+            acc = mfma16(a4.x, cp[ci * 4 + 0], acc);
+            acc = mfma16(a4.y, cp[ci * 4 + 1], acc);
+            acc = mfma16(a4.z, cp[ci * 4 + 2], acc);
+            acc = mfma16(a4.w, cp[ci * 4 + 3], acc);
+        }
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Pz[mt][i][lane] = acc[i];
+        }
+        __syncthreads();
+        if (kh == 0 && cl < 10) {
+            const float cpb = a.cpbias[cl];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int band = 2 * a1 + mt * 16 + q * 4 + i;
+                if (band < a.D) a.p[((size_t)bt * a.D + band) * 10 + cl] = fmaxf(acc[i] + Pz[mt][i][lane] + cpb, 0.f);
+            }
+        }
+    }
     // ---- df_conv1 (stride 2): c1 position a1 + ro reads C0 rows 2 ro .. 2 ro + 2
     enc_seg_layer<2, R1, N0>(C0, a.dw1, a.pw1, a.bs1, a1, a.Fd, a1, a1 + R1, a.c1 + (size_t)bt * a.Fd * 64, C1);
     if (!a.gi) return;

@@ -433,6 +433,36 @@ def test_small_launch_kernel_forms_equal_the_plain_forms(be, sr, nb):
         assert np.abs(a_ - b_).max() < 2e-5 * max(1.0, float(np.abs(b_).max())), k
 
 
+@pytest.mark.parametrize("sr,nb,S", [(16000, 2, 1), (16000, 4, 8), (48000, 1, 5), (48000, 2, 64)])
+def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
+    """Everything a single streaming hop does differently from a general call -- stage 2 on the main stream, staging + FIFO import
+    + state copy as one prologue launch, one combined FIFO export behind the overlap-add (the host waits for the output event
+    only), the decoders' GRU-256 steps pairwise in one launch, the DF decoder's pathway conv inside the front-end launch, the
+    encoder / decoder pyramids -- against the same streams with all of it switched off, on fresh models: audio equal to rounding
+    hop by hop, and so is every stream's state afterwards (read right after the last hop: the getter must see the late export)."""
+    from dpdfnet_amd.weights import synth_blob
+    blob = synth_blob(be.manifest(sr, nb), 4711)
+    rng = np.random.default_rng(5)
+    runs = {}
+    for tag, opts in (("hop", {}), ("plain", {"single_chunk_inline": 0, "hop_prologue": 0, "late_export": 0, "dual_step": 0, "hop_pconv": 0,
+                                               "fuse_enc": 0, "fuse_dec": 0, "snapshot": 0})):
+        m = be.HipModel(sr, nb, blob, 0)
+        for k, v in opts.items():
+            m.set_option(k, v)
+        st = be.HipStreams(m, S)
+        r = np.random.default_rng(5)
+        st.prime((0.05 * r.standard_normal((S, m.hop))).astype(np.float32))
+        outs = [st.process((0.05 * r.standard_normal((S, m.hop))).astype(np.float32)).copy() for _ in range(9)]
+        outs.append(st.process((0.05 * r.standard_normal((S, 3 * m.hop))).astype(np.float32)).copy())      # a three-hop call in between
+        outs.append(st.process((0.05 * r.standard_normal((S, m.hop))).astype(np.float32)).copy())
+        states = np.stack([st.get_state(i) for i in range(S)])
+        runs[tag] = (outs, states)
+        st.close(); m.close()
+    for a_, b_ in zip(runs["hop"][0], runs["plain"][0]):
+        assert a_.shape == b_.shape and rms(a_ - b_) < 1e-6
+    assert np.abs(runs["hop"][1] - runs["plain"][1]).max() < 5e-5
+
+
 def test_every_gru256_scan_form_agrees(be):
     """The forms of the GRU-256 recurrence -- single-workgroup scan (`gru256_cluster` = 0), 4-workgroup cluster, 8- and
     16-workgroup clusters for small launches, the two cells of a decoder stack as one wavefront launch (gru_stack.h) -- on
