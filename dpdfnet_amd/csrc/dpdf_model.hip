@@ -332,6 +332,7 @@ struct dpdf_model {
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int dfout_in_decin = 1;            // decoders in series: df_out shares the ERB decoder's dec_in launch (0: A/B)
     int hop_pconv = 1;                 // streaming hops: the DF decoder's pathway conv inside df_enc_seg_kernel (0: its own launch in stage 2; A/B)
     int dual_step = 1;                 // streaming hops with the decoders in series: the two decoders' GRU-256 steps pairwise in one launch (0: A/B)
     int hop_dec_fork = 0;              // one-chunk calls: 1 = the DF decoder forks onto its own stream beside the ERB decoder (measured 4-14 us slower per hop than in series: two handoffs)
@@ -1440,7 +1441,7 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     // The two decoders only share `emb`: the DF decoder (2 GRU-256 cells, df_out, pathway conv) runs on its own stream
     // beside the ERB decoder (2 cells, transposed convs, mask) -- the five latency-bound cell scans become three deep.
     hipStream_t sd = fork ? m->ln->sD : st;
-    bool dec_steps_done = false;
+    bool dec_steps_done = false, dfout_in_decin = false;
     if (fork) { HIP_TRY(hipEventRecord(m->ln->ev_dfk[c.parity], st)); HIP_TRY(hipStreamWaitEvent(sd, m->ln->ev_dfk[c.parity], 0)); }
     // ---- DF decoder (dpdfnet.py:486-519) ----
     {
@@ -1469,7 +1470,10 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
         {
             ProfScope ps(m, "df_coefs");
             size_t n = (size_t)BT * 256;
-            if (fanned && x.have_pconv) {            // the sum rides in df_out's A producer
+            const GlW& go = m->df_out;
+            dfout_in_decin = fanned && !fork && x.have_pconv && m->dfout_in_decin && go.G == 16 && go.Ig == 16 && go.Og == 60 && go.NT == 4 && d.D * 10 == 960;
+            if (dfout_in_decin) {                    // rides in the ERB decoder's dec_in launch below (decoders in series)
+            } else if (fanned && x.have_pconv) {     // the sum rides in df_out's A producer
                 const GlW& g = m->df_out;
                 SumA<16> ap{gc, w.skipb.p, 256, g.Ig, g.Ig};
                 DfOutEpi ep{w.coefs.p, Tc, FastDiv::make(Tc), x.pconv.p, m->C(g.bias), g.Og};
@@ -1514,8 +1518,9 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     float* dembp = d.is48 ? w.demb2.p : w.demb.p;
     if (smallm) {
         ProfScope ps(m, "grouped_linear");
-        DecInMArgs da{w.g256c.p, glfrag(m->ed_lin_out), d.is48 ? glfrag(m->ed_erb_fc) : nofrag, w.demb.p, w.demb2.p, d.F3 * 64, BT};
-        hipLaunchKernelGGL(dec_in_mfma_kernel, dim3((BT + 63) / 64, 16), dim3(256), 0, st, da);
+        DecInMArgs da{w.g256c.p, glfrag(m->ed_lin_out), d.is48 ? glfrag(m->ed_erb_fc) : nofrag, w.demb.p, w.demb2.p, d.F3 * 64, BT,
+                      glfrag(m->df_out), w.g256f.p, w.skipb.p, x.pconv.p, w.coefs.p, Tc};
+        hipLaunchKernelGGL(dec_in_mfma_kernel, dim3((BT + 63) / 64, dfout_in_decin ? 32 : 16), dim3(256), 0, st, da);
     } else {
         ProfScope ps(m, "grouped_linear");
         run_gl_auto(m, m->ed_lin_out, w.g256c.p, 256, w.demb.p, 512, BT, ACT_RELU);
@@ -1910,6 +1915,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "dfout_in_decin") m->dfout_in_decin = value != 0;
     else if (n == "hop_pconv") m->hop_pconv = value != 0;
     else if (n == "dual_step") m->dual_step = value != 0;
     else if (n == "hop_dec_fork") m->hop_dec_fork = value != 0;

@@ -153,6 +153,10 @@ __global__ __launch_bounds__(256) void emb_out_mfma_kernel(EmbOutMArgs a) {
 struct DecInMArgs {
     const float* h; GlFrag lin_out, erb_fc;     // 16 x (16 -> 32); 48 kHz: 32 x (16 -> 80), NT = 5.  erb_fc.frag == null: demb is the output
     float* demb; float* demb2; int n2; int M;
+    // grid.y rows 16 .. 31 (optional; the decoders in series on one stream): the DF decoder's df_out for group y - 16 --
+    // coefs[b, 2 + t, 60 g + n] = tanh(W (gc + skip) + bias) + p[row, 60 g + n] (gemm_rows.h: SumA producer + DfOutEpi, same operand
+    // order) -- it only shares the launch, not data, with the ERB decoder's linears: one dependent launch less per hop
+    GlFrag df_out; const float* gc; const float* skipb; const float* p; float* coefs; int Tc;
 };
 // grid (ceil(M / 64), 16): block g owns linear_out group g (demb columns [32 g, 32 g + 32)) and erb_fc_emb groups 2g, 2g + 1
 __global__ __launch_bounds__(256) void dec_in_mfma_kernel(DecInMArgs a) {
@@ -161,6 +165,38 @@ __global__ __launch_bounds__(256) void dec_in_mfma_kernel(DecInMArgs a) {
     const int g = blockIdx.y;
     const int row0 = blockIdx.x * 64 + 16 * w;
     int row = row0 + cl; if (row >= a.M) row = a.M - 1;
+    if (g >= 16) {
+        const int gd = g - 16;
+        const float* wf = a.df_out.frag + (size_t)gd * 4 * 256 + lane;
+        float wv[4][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) wv[nt][kb] = wf[(size_t)(nt * 4 + kb) * 64];
+        const float4 x4 = *(const float4*)(a.gc + (size_t)row * 256 + 16 * gd + 4 * q), y4 = *(const float4*)(a.skipb + (size_t)row * 256 + 16 * gd + 4 * q);
+        const float av[4] = {x4.x + y4.x, x4.y + y4.y, x4.z + y4.z, x4.w + y4.w};
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[nt] = mfma16(av[kb], wv[nt][kb], acc[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = nt * 16 + cl;
+            if (col >= 60) continue;
+            const float bv = a.df_out.bias[gd * 60 + col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = row0 + 4 * q + i;
+                if (r >= a.M) continue;
+                const int b = r / a.Tc, t = r - b * a.Tc;
+                a.coefs[((size_t)b * (a.Tc + 2) + 2 + t) * 960 + gd * 60 + col] = tanh_f(acc[nt][i] + bv) + a.p[(size_t)r * 960 + gd * 60 + col];
+            }
+        }
+        return;
+    }
     {
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         gl_tile<2, 1, false>(a.lin_out, g, a.h + (size_t)row * 256 + 16 * g + 4 * q, acc, lane);
