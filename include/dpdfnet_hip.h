@@ -158,7 +158,18 @@ int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
  * decoder stack as one wavefront launch, gru_stack.h), "tail_frames" (default 32: >= 96 streams, automatic chunking: a last
  * chunk of >= 96 frames gives up a tail chunk of this many frames; 0 off), "fcln_gi" / "hop_glue" / "gru256_step" (small-batch
  * and single-hop launch fusions, fcln_gi.h, gru_stack.h; default 1), "stft_ksplit" (bit 0: STFT of a few 48 kHz frames split
- * over K, bit 1: streaming iSTFT split over K; default 3).  Unknown name -> DPDF_E_INVALID.  (Removed after measurement, see
+ * over K, bit 1: streaming iSTFT split over K; default 3).  Small-launch forms (<= 512 frame rows; default 1, 0 = the plain
+ * per-layer launches): "fuse_small" (mask + deep filter in one launch, grouped linears chained per tile), "fuse_gl", "fuse_enc"
+ * (enc_seg.h: each encoder front end as one LDS-pyramid launch, bit-identical to the plain kernels), "fuse_dec" (dec_pyr.h: the
+ * ERB decoder's three stages + mask tap sums), "enc_seg_rows" / "dec_pyr_rows" (their row thresholds, default 512),
+ * "interleave" (the two encoder branches' DPRNN blocks enqueued alternately).  One-chunk calls (a streaming hop, a clip of <=
+ * 256 frames; default 1): "single_chunk_inline" (stage 2 on the main stream: no cross-stream handoff on the chain),
+ * "hop_prologue" (> 4 streams: staging + FIFO import + state copy as one launch in front of the STFT), "late_export" (the hop's
+ * FIFO export behind the overlap-add, the host waits for the output event), "dual_step" (the two decoders' GRU-256 steps
+ * pairwise in one launch), "hop_pconv" (the DF pathway conv inside the front-end launch), "dfout_in_decin" (df_out as extra
+ * workgroups of the ERB decoder's input-linear launch), "hop_dec_fork" (default 0; 1: the DF decoder on its own stream also in
+ * one-chunk calls), "snapshot" (default 1; 0 disables the streaming calls' pre-call state copy and with it the automatic
+ * recovery -- timing only).  Unknown name -> DPDF_E_INVALID.  (Removed after measurement, see
  * DESIGN.md section 7 and tools/experimental/: "gru64_bf16x3", "gru256_pair", "gru256_chain", "pipe_chunk".) */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);
 
