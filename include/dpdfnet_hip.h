@@ -94,7 +94,10 @@ int dpdf_enhance_batch_ragged(dpdf_model* m, const float* wav, int B, int n_max,
  *   pcm_in  [S, n_hops*hop]  new samples per stream (host or device per flags)
  *   pcm_out [S, n_hops*hop]  committed output hops
  * The very first call of a stream needs win samples before the first frame: call with the
- * stream's first hop through dpdf_streams_prime (buffers it, emits nothing). */
+ * stream's first hop through dpdf_streams_prime (buffers it, emits nothing).
+ * Host-pointer calls return as soon as pcm_out is complete; a single hop's last state-FIFO export may still be running on the
+ * model's stream at that point.  Nothing observable depends on it: every entry point that reads or writes stream state
+ * (process, get_state / set_state / get_tails, reset, destroy) is ordered behind it on that stream or synchronises it first. */
 int dpdf_streams_create(dpdf_model* m, int n_streams, dpdf_streams** out);
 void dpdf_streams_destroy(dpdf_streams* s);
 int dpdf_streams_reset(dpdf_streams* s, int stream /* -1 = all */);
