@@ -18,3 +18,15 @@ def test_random_shapes_default_pipeline_equals_plain_form():
     rec = mod.run(budget=10.0, seed=20260417)
     assert not rec.get("FAIL"), rec
     assert rec["cases"] >= 20 and rec["worst_rel_err"] < 5e-5, rec
+
+
+def test_random_streaming_call_sequences_hop_forms_equal_plain_chain():
+    """tools/stream_soak.py: the same random sequence of streaming calls (single hops, multi-hop calls, masked calls, resets,
+    state save / restore through the host; 1..70 streams, four models) through an engine with every hop-only form on and one
+    with all of them off: every output and the final states must agree."""
+    spec = importlib.util.spec_from_file_location("dpdf_stream_soak", Path(__file__).resolve().parents[1] / "tools" / "stream_soak.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rec = mod.run(8.0, 20260929)
+    assert not rec.get("FAIL"), rec
+    assert rec["cases"] >= 10 and rec["worst_rms"] < 2e-6, rec
