@@ -332,6 +332,7 @@ struct dpdf_model {
     int glue8 = 1;                     // single-hop DPRNN glue on eight waves per tile (0: four; A/B)
     int fuse_small = 1;                // launches of <= 512 rows: small dependent kernels merged (mask + deep filter, the embedding fan-in / fan-out linears; 0: A/B)
     int fuse_enc = 1;                  // ... and the ERB encoder's four convolutions (erb_enc_seg_kernel; 0: A/B)
+    int seg10 = 1;                     // 48 kHz pyramid kernels: 10-position segments when 8-position ones would exceed one workgroup per CU (0: A/B)
     int dfout_in_decin = 1;            // decoders in series: df_out shares the ERB decoder's dec_in launch (0: A/B)
     int hop_pconv = 1;                 // streaming hops: the DF decoder's pathway conv inside df_enc_seg_kernel (0: its own launch in stage 2; A/B)
     int dual_step = 1;                 // streaming hops with the decoders in series: the two decoders' GRU-256 steps pairwise in one launch (0: A/B)
@@ -1236,6 +1237,9 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         ProfScope ps(m, "enc_convs_erb");
         if (erb_geo) {      // latency regime: four dependent launches -> one (enc_seg.h)
             if (erb_geo == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(erb_enc_seg_kernel<2, 2, 1, 8>), dim3(d.F3 / 8, BT), dim3(256), 0, sC, era);
+            // 48 kHz: segments of 10 positions once segments of 8 would be more workgroups than CUs (64 streams: 256 instead of 320 --
+            // two workgroups sharing a CU's matrix pipes take twice as long, the launch ends with the slowest)
+            else if (m->seg10 && d.F3 % 10 == 0 && (long)BT * (d.F3 / 8) > 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(erb_enc_seg_kernel<3, 2, 2, 10>), dim3(d.F3 / 10, BT), dim3(256), 0, sC, era);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(erb_enc_seg_kernel<3, 2, 2, 8>), dim3(d.F3 / 8, BT), dim3(256), 0, sC, era);
             werb.intra_gi_ready = erb_gi;
         } else {
@@ -1298,6 +1302,7 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
                       m->C(m->conv1p.ps), m->C(m->conv1p.pb), m->C(m->convt1.dw), m->C(m->convt1.pwfrag), m->C(m->convt1.bias),
                       m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), m->c0out_bias, BT, d.F3, d.F2, d.F1, d.Ec, d.E};
         if (pyr == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_pyr_kernel<2, 2, 1, 8, true>), dim3(1, BT), dim3(256), 0, st, pa);
+        else if (m->seg10 && d.F3 % 10 == 0 && (long)BT * (d.F3 / 8) > 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_pyr_kernel<3, 2, 2, 10, false>), dim3(d.F3 / 10, BT), dim3(256), 0, st, pa);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_pyr_kernel<3, 2, 2, 8, false>), dim3(d.F3 / 8, BT), dim3(256), 0, st, pa);
         m->ln->mask_from_sums = pyr == 48 && BT <= SMALL_M_ROWS;      // (the tap sums are finished inside mask_df_kernel)
         if (pyr == 48 && !m->ln->mask_from_sums) {
@@ -1915,6 +1920,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "fuse_gl") m->fuse_gl = value != 0;
     else if (n == "fuse_small") m->fuse_small = value != 0;
     else if (n == "fuse_enc") m->fuse_enc = value != 0;
+    else if (n == "seg10") m->seg10 = value != 0;
     else if (n == "dfout_in_decin") m->dfout_in_decin = value != 0;
     else if (n == "hop_pconv") m->hop_pconv = value != 0;
     else if (n == "dual_step") m->dual_step = value != 0;

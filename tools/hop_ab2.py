@@ -16,7 +16,7 @@ for sr, nb, S in ((48000, 8, 64), (16000, 2, 1), (16000, 4, 8)):
     pcm = (0.05 * rng.standard_normal((S, m.hop))).astype(np.float32)
     res = [[] for _ in sets]
     base = {'hop_feat': 1, 'fuse_small': 1, 'dec_seg': 1, 'df_ring': 2, 'scan4_max_wgs': 512, 'stft_ksplit': 7, 'hop_glue': 1, 'fcln_gi': 1,
-            'gru256_step': 1, 'fuse_mask': 1, 'hoist_gi': 1, 'glue8': 1, 'fuse_gl': 1, 'interleave': 1, 'fuse_enc': 1, 'fuse_dec': 1, 'overlap': 27, 'single_chunk_inline': 1, 'snapshot': 1, 'late_export': 1, 'hop_prologue': 1, 'hop_dec_fork': 0, 'dual_step': 1, 'hop_pconv': 1, 'dfout_in_decin': 1}
+            'gru256_step': 1, 'fuse_mask': 1, 'hoist_gi': 1, 'glue8': 1, 'fuse_gl': 1, 'interleave': 1, 'fuse_enc': 1, 'fuse_dec': 1, 'overlap': 27, 'single_chunk_inline': 1, 'snapshot': 1, 'late_export': 1, 'hop_prologue': 1, 'hop_dec_fork': 0, 'dual_step': 1, 'hop_pconv': 1, 'dfout_in_decin': 1, 'seg10': 1}
     for rep in range(6):
         for i, opts in enumerate(sets):
             for k in keys:
