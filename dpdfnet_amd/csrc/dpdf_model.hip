@@ -1210,24 +1210,25 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         ProfScope ps(m, "enc_convs_df");
         // df_conv1 (+ the DF decoder's pathway conv, + df_conv0 itself): one time-walking pass when clips x 3 workgroups
         // fill the chip, else the time-parallel gemm_rows forms (df_ring.h)
-        const bool conv0_in_ring = x.have_pconv && m->df_ring >= 2;
-        if (df_seg) {       // latency regime: df_conv0 + df_conv1 + the first block's input projection as one launch (enc_seg.h)
+        if (df_seg) {       // latency regime: df_conv0 + df_conv1 + the first block's input projection (+ pathway conv) as one launch (enc_seg.h)
             hipLaunchKernelGGL(df_enc_seg_kernel, dim3(d.Fd / 16, BT), dim3(256), 0, sA, dfa);
             wdf.intra_gi_ready = df_gi;
-        } else if (!conv0_in_ring) {
-            RowMap rm = RowMap::make(Tc, d.D);
-            Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm};
-            BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
-            launch_gemm_rows<4, 32, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 32, 1);
-        }
-        if (df_seg) {
-        } else if (x.have_pconv) {
-            DfRingArgs ra{x.c0.p, x.c1.p, x.pconv.p, m->C(m->df_conv1.dw), m->C(m->df_conv1.pwfrag), m->C(m->df_conv1.bias),
-                          m->C(m->convp_frag), m->C(m->convp_bias), B, Tc, w.feat_spec.p, m->C(m->dfc0_pwfrag), m->C(m->dfc0_bias)};
-            if (conv0_in_ring) hipLaunchKernelGGL(HIP_KERNEL_NAME(df_ring_kernel<true>), dim3(B * 3), dim3(256), 0, sA, ra);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(df_ring_kernel<false>), dim3(B * 3), dim3(256), 0, sA, ra);
         } else {
-            run_dwconv_s(m, m->df_conv1, c0v, c1v, B, Tc, 2);
+            const bool conv0_in_ring = x.have_pconv && m->df_ring >= 2;
+            if (!conv0_in_ring) {
+                RowMap rm = RowMap::make(Tc, d.D);
+                Conv0DfA ap{w.feat_spec.p, Tc + 2, d.D, rm};
+                BiasReluToView ep{c0v, rm, m->C(m->dfc0_bias)};
+                launch_gemm_rows<4, 32, true>(sA, ap, m->C(m->dfc0_pwfrag), ep, BT * d.D, 32, 1);
+            }
+            if (x.have_pconv) {
+                DfRingArgs ra{x.c0.p, x.c1.p, x.pconv.p, m->C(m->df_conv1.dw), m->C(m->df_conv1.pwfrag), m->C(m->df_conv1.bias),
+                              m->C(m->convp_frag), m->C(m->convp_bias), B, Tc, w.feat_spec.p, m->C(m->dfc0_pwfrag), m->C(m->dfc0_bias)};
+                if (conv0_in_ring) hipLaunchKernelGGL(HIP_KERNEL_NAME(df_ring_kernel<true>), dim3(B * 3), dim3(256), 0, sA, ra);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(df_ring_kernel<false>), dim3(B * 3), dim3(256), 0, sA, ra);
+            } else {
+                run_dwconv_s(m, m->df_conv1, c0v, c1v, B, Tc, 2);
+            }
         }
     }
     // ---- encoder, ERB branch (reference onnx_model/dpdfnet.py:206-219) on its own stream ----
