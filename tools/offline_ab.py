@@ -9,7 +9,7 @@ from dpdfnet_amd.weights import synth_blob
 sr, nb, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 sets = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if "=" in kv) for a in sys.argv[4:]] or [{}]
 keys = sorted({k for s_ in sets for k in s_})
-base = {'inter_fuse_rows': 1024, 'scan4_max_wgs': 512, 'enc_seg_rows': 512, 'dec_pyr_rows': 512, 'fuse_enc': 1, 'fuse_dec': 1, 'dec_seg': 1}
+base = {'gru256_c8_tiles': 4, 'gru256_c16_tiles': 2, 'inter_fuse_rows': 1024, 'scan4_max_wgs': 512, 'enc_seg_rows': 512, 'dec_pyr_rows': 512, 'fuse_enc': 1, 'fuse_dec': 1, 'dec_seg': 1}
 m = be.HipModel(sr, nb, synth_blob(be.manifest(sr, nb), 20260417), 0)
 N = 10 * sr
 wav = torch.from_numpy((0.05 * np.random.default_rng(1).standard_normal((B, N))).astype(np.float32)).cuda()
