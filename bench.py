@@ -606,6 +606,7 @@ def main() -> None:
                 line["cpu_baseline"]["reference_runtime"] = {"kind": "ort", "available": False,
                                                               "why": f"{type(exc).__name__}: {exc}"[:200]}
         if world == 1 and not args.no_other_configs and not args.no_isolated:
+            model.close()       # the side configurations get the device to themselves (the headline engine's 33 GB workspace and four streams go first)
             try:
                 line["other_configs"] = other_configs()
             except Exception as exc:  # never lose the headline line over the side measurements
