@@ -2508,3 +2508,7 @@ extern "C" long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, l
     }
     return n;
 }
+
+#ifdef DPDF_PHASE_TRACE
+extern "C" int dpdf_debug_trace(unsigned long long* out32) { return hipMemcpyFromSymbol(out32, HIP_SYMBOL(dpdf_trace_buf), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; }
+#endif

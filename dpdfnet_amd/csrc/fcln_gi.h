@@ -307,6 +307,12 @@ __global__ __launch_bounds__(256) void dprnn_hop_glue_kernel(HopGlueArgs g) {
 //   the h part's three accumulators handed over through LDS;   fc_inter: K half wk (8 MFMAs);   next gi: three of the 24
 //   (direction x gate, column tile) pairs (48 MFMAs) -- 120 MFMAs and 120 weight registers per wave.
 // Same operands, same packings; sums are taken in a different order than the four-wave form (equal to rounding).
+#ifdef DPDF_PHASE_TRACE
+__device__ unsigned long long dpdf_trace_buf[32];
+#define DPDF_STAMP(i) do { if (NEXT && blockIdx.x == 0 && threadIdx.x == 0) dpdf_trace_buf[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DPDF_STAMP(i) do {} while (0)
+#endif
 template <bool NEXT>
 __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
     __shared__ __attribute__((aligned(16))) float As[16][132];
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
     const int wc = w & 3, wk = w >> 2;
     const int cl = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * 16;
+    DPDF_STAMP(0);
     {
         const int r = tid >> 5, c4 = tid & 31;
         int row = row0 + r; if (row >= g.M) row = g.M - 1;
@@ -358,6 +365,7 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
     }
     const float bfi = g.fci_b[16 * wc + cl], bfe = g.fce_b[16 * wc + cl];
     __syncthreads();
+    DPDF_STAMP(1);
     auto layer_norm_res = [&](const float4 v, const float4 res, const float* gam, const float* bet) {
         const float mean = row16_allreduce_sum(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
         const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
@@ -387,6 +395,7 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
         for (int i = 0; i < 4; ++i) Fs[wk][4 * q + i][16 * wc + cl] = acc0[i] + acc1[i] + bv;
     }
     __syncthreads();
+    DPDF_STAMP(2);
     float4 y1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ln_role) {
         const float4 u = *(const float4*)&Fs[0][rr][rc4], v2 = *(const float4*)&Fs[1][rr][rc4];
@@ -394,6 +403,7 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
         *(float4*)&Ys[rr][rc4] = y1;
     }
     __syncthreads();
+    DPDF_STAMP(3);
     // ---- inter-band GRUCell step: wk = 0 the x part, wk = 1 the h part
     float hn[4];
     {
@@ -417,18 +427,21 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
             for (int i = 0; i < 4; ++i) { Gs[wc][0][i][lane] = a0[i]; Gs[wc][1][i][lane] = a1[i]; Gs[wc][2][i][lane] = a2[i]; }
         }
         __syncthreads();
+        DPDF_STAMP(4);
         if (wk == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 hn[i] = gru64_cell(a0[i] + Gs[wc][0][i][lane], a1[i] + Gs[wc][1][i][lane], a2[i], Gs[wc][2][i][lane], Hs[4 * q + i][16 * wc + cl]);
         }
         __syncthreads();                      // every wave has read h
+        DPDF_STAMP(5);
         if (wk == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) Hs[4 * q + i][16 * wc + cl] = hn[i];
         }
     }
     __syncthreads();
+    DPDF_STAMP(6);
     if (ln_role && rok) {      // h' back into the carried state (row-contiguous pieces)
         float* hp = g.hstate + (long)(grow / g.rdiv) * g.h_hi + (long)(grow % g.rdiv) * g.h_lo + rc4;
         *(float4*)hp = *(const float4*)&Hs[rr][rc4];
@@ -448,6 +461,7 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
         for (int i = 0; i < 4; ++i) Fs[wk][4 * q + i][16 * wc + cl] = acc0[i] + acc1[i] + bv;
     }
     __syncthreads();
+    DPDF_STAMP(7);
     if (ln_role) {
         const float4 u = *(const float4*)&Fs[0][rr][rc4], v2 = *(const float4*)&Fs[1][rr][rc4];
         const float4 y2 = layer_norm_res(make_float4(u.x + v2.x, u.y + v2.y, u.z + v2.z, u.w + v2.w), y1, g.lne_g, g.lne_b);
@@ -456,6 +470,7 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
     }
     if (NEXT) {
         __syncthreads();
+        DPDF_STAMP(8);
         float4 y4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) y4[c] = *(const float4*)&Ys[cl][16 * c + 4 * q];
@@ -481,4 +496,5 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
             }
         }
     }
+    DPDF_STAMP(9);
 }
