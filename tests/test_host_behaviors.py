@@ -479,3 +479,30 @@ def test_progress_callback_reports_in_order_with_a_polling_session(monkeypatch):
     T = 1 + (64 + 8) // 4
     assert seen[0] == (0, T) and seen[1:] == [(i + 1, T) for i in range(T)]
     assert threads == {threading.get_ident()} and out.shape == (64,)
+
+
+def test_stoi_stand_in_behaves_like_an_intelligibility_measure():
+    """evalkit.stoi_np (STOI restated from its paper for boxes without pystoi; not pinned against pystoi): 1 for identical signals,
+    falls monotonically with the SNR of added noise, the same to 3 decimals for two signals 1e-7 apart (the use it is put to:
+    ours vs the reference output), insensitive to the sample rate of the pair, and `waveform_report` falls back to it."""
+    from dpdfnet_amd.evalkit import stoi_np, waveform_report
+    rng = np.random.default_rng(0)
+    sr = 16000
+    t = np.arange(3 * sr) / sr
+    x = sum(np.sin(2 * np.pi * f0 * t + rng.uniform(0, 6)) * (0.5 + 0.5 * np.sin(2 * np.pi * (3 + i) * t))
+            for i, f0 in enumerate((180, 360, 540, 900, 1500, 2400, 3100)))
+    x = 0.5 * x / np.abs(x).max()
+    assert abs(stoi_np(x, x, sr) - 1.0) < 1e-6
+    vals = []
+    for snr in (20, 10, 0, -10):
+        nz = rng.standard_normal(len(x))
+        nz *= np.sqrt(np.mean(x ** 2)) / np.sqrt(np.mean(nz ** 2)) * 10 ** (-snr / 20)
+        vals.append(stoi_np(x, x + nz, sr))
+    assert all(a > b for a, b in zip(vals, vals[1:])) and vals[-1] < 0.6 < vals[0] < 1.0
+    nz = 0.2 * rng.standard_normal(len(x))
+    a, b = stoi_np(x, x + nz, sr), stoi_np(x, x + nz + 1e-7 * rng.standard_normal(len(x)), sr)
+    assert round(a, 3) == round(b, 3)
+    rep = waveform_report(x + 1e-7, x, sr)
+    assert rep["stoi"] is not None and abs(rep["stoi"] - 1.0) < 1e-6
+    with pytest.raises(ValueError):
+        stoi_np(x[:2000], x[:2000], sr)
