@@ -250,6 +250,95 @@ def other_configs() -> dict:
     return out
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` invoked PLAINLY (no launcher, no WORLD_SIZE in the environment): start the N ranks
+    ourselves -- the same `torch.distributed.run` command line the driver uses, one process per GPU on this node,
+    rendezvous on 127.0.0.1 -- and pass the ranks' stdout / stderr through, so that either launch style gives the one
+    JSON line from rank 0.  (The reference's counterpart is one host thread per file, cli.py:249-259, 308-311.)"""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DPDF_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on these hosts (RCCL p2p needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    print(f"[bench.py] --gpus {n} without a launcher: starting {n} ranks with torch.distributed.run", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dist_selftest_worker() -> None:
+    """`bench.py --dist-selftest-only`: one rank, backend nccl (= RCCL on ROCm): communicator init bound to the device, the
+    collectives the N > 1 path of this file uses (all_reduce MAX on a device tensor = the max-over-ranks clock, barrier,
+    all_gather_object, a grouped isend/irecv = gather_to_root's launch shape) -- so that RCCL has executed this code's
+    calls on the box even where only one GPU is leased.  Prints one JSON object."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    res = {"backend": "nccl (RCCL)", "world_size": 1}
+    t0 = time.perf_counter()
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(_free_port())
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
+                                timeout=datetime.timedelta(seconds=60))
+        res["init_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
+        t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+        t1 = time.perf_counter()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); torch.cuda.synchronize()
+        res["first_all_reduce_ms"] = round(1e3 * (time.perf_counter() - t1), 1)
+        res["all_reduce_ok"] = bool(float(t.item()) == 1.25)
+        dist.barrier(); torch.cuda.synchronize()
+        res["barrier_ok"] = True
+        objs = [None]
+        dist.all_gather_object(objs, {"rank": 0})
+        res["all_gather_object_ok"] = objs == [{"rank": 0}]
+        try:
+            ver = torch.cuda.nccl.version()
+            res["rccl_version"] = ".".join(str(v) for v in ver) if isinstance(ver, tuple) else str(ver)
+        except Exception:
+            pass
+        try:        # gather_to_root's launch shape (one grouped isend + irecv), rank 0 to itself
+            a = torch.arange(1 << 20, dtype=torch.float32, device="cuda"); b = torch.zeros_like(a)
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, 0), dist.P2POp(dist.isend, a, 0)]):
+                q.wait()
+            torch.cuda.synchronize()
+            res["grouped_p2p_self_ok"] = bool(torch.equal(a, b))
+        except Exception as exc:
+            res["grouped_p2p_self_ok"] = False
+            res["grouped_p2p_self_error"] = f"{type(exc).__name__}: {exc}"[:200]
+        dist.destroy_process_group()
+        res["rccl_init_ok"] = bool(res["all_reduce_ok"] and res["barrier_ok"] and res["all_gather_object_ok"])
+    except Exception as exc:
+        res["rccl_init_ok"] = False
+        res["error"] = f"{type(exc).__name__}: {exc}"[:300]
+    print("DIST_SELFTEST " + json.dumps(res), flush=True)
+
+
+def dist_selftest(timeout_s: float = 180.0) -> dict:
+    """Run `dist_selftest_worker` in its OWN process under a timeout: a broken or hanging RCCL install is reported on the
+    line (`rccl_init_ok: false`) and can never take the headline measurement with it."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--dist-selftest-only"], capture_output=True, text=True,
+                           timeout=timeout_s, env=dict(os.environ))
+        for l in r.stdout.splitlines():
+            if l.startswith("DIST_SELFTEST "):
+                return json.loads(l[len("DIST_SELFTEST "):])
+        return {"rccl_init_ok": False, "error": f"no result line (rc {r.returncode}): {r.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"rccl_init_ok": False, "error": f"timed out after {timeout_s:g} s"}
+    except Exception as exc:
+        return {"rccl_init_ok": False, "error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,7 +360,19 @@ def main() -> None:
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT", help="engine A/B switch (dpdf_set_option), repeatable")
     ap.add_argument("--cpu-clip-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-clips-per-thread", type=int, default=5)
+    ap.add_argument("--dist-selftest", dest="dist_selftest", action="store_true", default=None,
+                    help="N=1: also bring up a one-rank RCCL process group in a child process and run this file's collectives "
+                         "on it (`rccl_selftest` / `rccl_init_ok` on the line); default on at N=1")
+    ap.add_argument("--no-dist-selftest", dest="dist_selftest", action="store_false")
+    ap.add_argument("--dist-selftest-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.dist_selftest_only:
+        dist_selftest_worker()
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (under torch.distributed.run WORLD_SIZE is set and we fall through)
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -605,6 +706,10 @@ def main() -> None:
             except Exception as exc:
                 line["cpu_baseline"]["reference_runtime"] = {"kind": "ort", "available": False,
                                                               "why": f"{type(exc).__name__}: {exc}"[:200]}
+        if world == 1 and args.dist_selftest is not False:
+            # RCCL executed on this box (one rank): communicator init on the device + the collectives the N > 1 path uses
+            line["rccl_selftest"] = dist_selftest()
+            line["rccl_init_ok"] = bool(line["rccl_selftest"].get("rccl_init_ok"))
         if world == 1 and not args.no_other_configs and not args.no_isolated:
             model.close()       # the side configurations get the device to themselves (the headline engine's 33 GB workspace and four streams go first)
             try:

@@ -49,6 +49,10 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["value_hbm_resident"] == d["value"]
     # the H2D/D2H-inclusive figure rides on the same line and can only be slower than the HBM-resident one
     assert 0 < d["value_incl_pcie"] <= d["value"] * 1.05 and d["pcie"]["finite_output"] is True
+    # RCCL has executed on this box: one-rank process group (backend nccl) in a child process, the collectives of the N > 1 path
+    st = d["rccl_selftest"]
+    assert d["rccl_init_ok"] is True, st
+    assert st["all_reduce_ok"] and st["barrier_ok"] and st["all_gather_object_ok"], st
 
 
 def test_two_ranks_control_flow_over_gloo():
@@ -69,3 +73,19 @@ def test_two_ranks_control_flow_over_gloo():
     assert mg["collective_ok"] is True and mg["collective_error"] is None and mg["gathered_matches_rank_outputs"] is True
     assert mg["gathered_shape"][:2] == [2, 8]
     assert max(r["ms_per_step"] for r in mg["per_rank"]) <= d["ms_per_step"] * 1.001
+
+
+def test_plain_invocation_with_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE in the environment (the shape of the driver's N=1 command
+    with another N): the file starts its ranks itself and rank 0 prints the one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--clips", "8",
+                        "--no-other-configs"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["finite_output"] is True
+    mg = d["multi_gpu"]
+    assert [q["rank"] for q in mg["rccl_ranks"]] == [0, 1] and mg["collective_ok"] is True and mg["gathered_matches_rank_outputs"] is True
+    assert "starting 2 ranks" in r.stderr
