@@ -106,3 +106,40 @@ class StftConfig:
 def make_stft_config(win_len: int) -> StftConfig:
     """hop = win/2, vorbis window (reference audio.py:98-101)."""
     return StftConfig(win_len=int(win_len), hop_size=int(win_len) // 2, window=vorbis_window(int(win_len)))
+
+
+def preprocess_waveform(waveform: np.ndarray, cfg: StftConfig) -> np.ndarray:
+    """Host form of the analysis STFT for callers of the reference's helper (reference audio.py:104-117: librosa.stft,
+    centre / reflect padding, unnormalised): waveform [n] -> spectrum [1, T, F, 2] with T = n // hop + 1.  NOT on the product
+    path -- `enhance()` runs the same transform on the device inside `dpdf_enhance_batch` (csrc/gemm_rows.h `StftA`); this is
+    the numpy statement of it for code that works on spectra (the ORT-shaped session of `ort_shim.py`, tests)."""
+    x = np.asarray(waveform, dtype=np.float32).reshape(-1)
+    win, hop = int(cfg.win_len), int(cfg.hop_size)
+    if x.shape[0] <= win // 2:
+        raise ValueError(f"waveform of {x.shape[0]} samples is too short for reflect padding of {win // 2}")
+    xp = np.pad(x, (win // 2, win // 2), mode="reflect")
+    n_frames = 1 + (xp.shape[0] - win) // hop
+    idx = hop * np.arange(n_frames)[:, None] + np.arange(win)[None, :]
+    spec = np.fft.rfft(xp[idx] * np.asarray(cfg.window, dtype=np.float32)[None, :], axis=-1).astype(np.complex64)
+    return np.stack([spec.real, spec.imag], axis=-1).astype(np.float32)[None, ...]
+
+
+def postprocess_spec(spec_e: np.ndarray, cfg: StftConfig) -> np.ndarray:
+    """Host form of the synthesis (reference audio.py:120-136: librosa.istft centre mode, then drop the first 2 win samples
+    -- the model's two-frame lookahead + the analysis centre -- and pad as many zeros behind).  spec_e [1, T, F, 2] ->
+    waveform [hop (T - 1)].  The vorbis window is power-complementary at 50 % overlap, so librosa's window-sum-square
+    normalisation is 1 over the kept range and is applied for exactness only where it differs from 1."""
+    s = np.asarray(spec_e[0], dtype=np.float32)
+    win, hop = int(cfg.win_len), int(cfg.hop_size)
+    w = np.asarray(cfg.window, dtype=np.float32)
+    frames = np.fft.irfft(s[..., 0] + 1j * s[..., 1], n=win, axis=-1).astype(np.float32) * w[None, :]
+    T = frames.shape[0]
+    y = np.zeros(hop * (T - 1) + win, dtype=np.float32)
+    wss = np.zeros_like(y)
+    for t in range(T):
+        y[t * hop:t * hop + win] += frames[t]
+        wss[t * hop:t * hop + win] += w * w
+    ok = wss > np.finfo(np.float32).tiny
+    y[ok] /= wss[ok]
+    y = y[win // 2:win // 2 + hop * (T - 1)]
+    return np.concatenate([y[win * 2:], np.zeros(win * 2, dtype=np.float32)], axis=0)

@@ -506,3 +506,23 @@ def test_stoi_stand_in_behaves_like_an_intelligibility_measure():
     assert rep["stoi"] is not None and abs(rep["stoi"] - 1.0) < 1e-6
     with pytest.raises(ValueError):
         stoi_np(x[:2000], x[:2000], sr)
+
+
+@pytest.mark.parametrize("tag,win", [("16k_nb0", 320), ("48k_nb1", 960)])
+def test_host_stft_helpers_match_reference_goldens(tag, win):
+    """`audio.preprocess_waveform` / `postprocess_spec` (reference package/src/dpdfnet/audio.py:104-136) against the spectra and
+    waveforms the reference itself produced for the model fixtures (tests/golden/make_golden.py: torch.stft / istft of the
+    reference's own modules, the librosa semantics).  Both fixtures are short enough that `spec_e_head` is the whole spectrum."""
+    from dpdfnet_amd import audio
+    d = np.load(GOLDEN / f"model_{tag}.npz")
+    cfg = audio.make_stft_config(win)
+    wav = d["wav"]
+    spec = audio.preprocess_waveform(np.pad(wav, (0, win)), cfg)
+    assert spec.dtype == np.float32 and spec.shape == (1, (wav.shape[0] + win) // (win // 2) + 1, win // 2 + 1, 2)
+    scale = float(np.abs(d["spec_head"]).max())
+    assert np.abs(spec[0, :8] - d["spec_head"]).max() < 1e-6 * scale and np.abs(spec[0, -4:] - d["spec_tail"]).max() < 1e-6 * scale
+    assert d["spec_e_head"].shape[0] == spec.shape[1]
+    y = audio.fit_length(audio.postprocess_spec(d["spec_e_head"][None], cfg), wav.shape[0])
+    assert y.dtype == np.float32 and np.abs(y - d["enhanced"]).max() < 1e-6
+    with pytest.raises(ValueError):
+        audio.preprocess_waveform(np.zeros(win // 2, np.float32), cfg)
