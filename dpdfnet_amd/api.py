@@ -103,12 +103,21 @@ def _enhance_with_runtime(
         th = threading.Thread(target=_call, name="dpdfnet-enhance")
         th.start()
         reported = 0
-        while th.is_alive():
-            th.join(0.002)
-            done = min(int(runtime.session.progress()), total_frames)
-            while reported < done:
-                reported += 1
-                progress_callback(reported, total_frames)
+        try:
+            import inspect
+            owned = "owner" in inspect.signature(runtime.session.progress).parameters
+        except (TypeError, ValueError):
+            owned = False
+        try:
+            while th.is_alive():
+                th.join(0.002)
+                # only the frames of OUR worker's call: 0 until it is inside the engine (and again once it has left)
+                done = min(int(runtime.session.progress(owner=th.ident) if owned else runtime.session.progress()), total_frames)
+                while reported < done:
+                    reported += 1
+                    progress_callback(reported, total_frames)
+        finally:
+            th.join()           # a callback that raises must not leave the engine call running unobserved
         if "err" in box:
             raise box["err"]
         while reported < total_frames:

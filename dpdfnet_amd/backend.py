@@ -8,6 +8,7 @@ if the shared library or a GPU is missing, loading/creating fails loudly.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import math
 import os
@@ -193,6 +194,8 @@ class HipModel:
         h = ctypes.c_void_p()
         _check(self._L.dpdf_create(ctypes.byref(self.cfg), _fp(blob), blob.size, int(device), ctypes.byref(h)))
         self._h = h
+        self._call_lock = threading.Lock()      # one offline host call at a time per handle (the C side serialises them anyway) ...
+        self._call_owner: Optional[int] = None  # ... so that `progress(owner=...)` can tell WHOSE call the counter belongs to
         self.device = int(device)
         self.sample_rate = int(sample_rate)
         self.nb = int(nb)
@@ -246,6 +249,15 @@ class HipModel:
             return out[0], st[0]
         return out, st
 
+    @contextlib.contextmanager
+    def _offline_call(self):
+        with self._call_lock:
+            self._call_owner = threading.get_ident()
+            try:
+                yield
+            finally:
+                self._call_owner = None
+
     def enhance_batch(self, wav: np.ndarray, attn_limit_db: Optional[float] = None) -> np.ndarray:
         """wav [B,N] float32 at the model rate -> enhanced [B,N]."""
         wav = np.ascontiguousarray(wav, dtype=np.float32)
@@ -253,7 +265,8 @@ class HipModel:
             raise ValueError(f"wav must be [B,N], got {wav.shape}")
         out = np.empty_like(wav)
         db = float("nan") if attn_limit_db is None else float(attn_limit_db)
-        _check(self._L.dpdf_enhance_batch(self._h, wav.ctypes.data, wav.shape[0], wav.shape[1], db, out.ctypes.data, DPDF_HOST_PTRS))
+        with self._offline_call():
+            _check(self._L.dpdf_enhance_batch(self._h, wav.ctypes.data, wav.shape[0], wav.shape[1], db, out.ctypes.data, DPDF_HOST_PTRS))
         return out
 
     def enhance_batch_ragged(self, clips, attn_limit_db: Optional[float] = None) -> List[np.ndarray]:
@@ -270,8 +283,9 @@ class HipModel:
         out = np.empty_like(wav)
         db = float("nan") if attn_limit_db is None else float(attn_limit_db)
         if n_max:
-            _check(self._L.dpdf_enhance_batch_ragged(self._h, wav.ctypes.data, len(clips), n_max,
-                                                     lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), db, out.ctypes.data, DPDF_HOST_PTRS))
+            with self._offline_call():
+                _check(self._L.dpdf_enhance_batch_ragged(self._h, wav.ctypes.data, len(clips), n_max,
+                                                         lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), db, out.ctypes.data, DPDF_HOST_PTRS))
         return [out[i, : int(lens[i])].copy() for i in range(len(clips))]
 
     def enhance_batch_device(self, wav_ptr: int, B: int, N: int, out_ptr: int, attn_limit_db: Optional[float] = None) -> None:
@@ -285,8 +299,12 @@ class HipModel:
     def sync(self) -> None:
         _check(self._L.dpdf_sync(self._h))
 
-    def progress(self) -> int:
-        """Frames of the offline call in flight whose output is complete (lock-free; poll from another thread)."""
+    def progress(self, owner: Optional[int] = None) -> int:
+        """Frames of the offline call in flight whose output is complete (lock-free; poll from another thread).
+        `owner` = ident of the thread that makes the call being watched: 0 is returned until THAT thread is inside its
+        engine call (another thread's call on a shared handle, or the previous call's count, is never reported)."""
+        if owner is not None and self._call_owner != owner:
+            return 0
         return int(self._L.dpdf_progress(self._h))
 
     @property

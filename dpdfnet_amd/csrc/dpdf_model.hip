@@ -1592,6 +1592,7 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     }
     int rc;
     m->ln = &m->lanes[0];
+    m->lanes[0].export_pending = false;      // (never armed across calls: join_export launches it, error exits disarm it)
     if ((rc = init_lane(m->lanes[0]))) return rc;
     if ((rc = ensure_ws(m, B, chunk))) return rc;
     // (Measured and dropped: ending on a quarter-size chunk to shorten the pipeline drain -- 115.0 vs 114.6 ms/step; splitting
@@ -2066,6 +2067,12 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
     if (N == 0) return DPDF_OK;
     std::lock_guard<std::mutex> lk(m->mu);
     HIP_TRY(hipSetDevice(m->device));
+    // dpdf_progress counts THIS call's frames from here on (a poller must never see the previous call's final count while
+    // this one is still allocating / uploading), and reads 0 again once the call has returned
+    struct ProgressEpoch { dpdf_model* m; bool sync_call;
+                           ProgressEpoch(dpdf_model* m_, bool s_) : m(m_), sync_call(s_) { if (m->pin_progress) *m->pin_progress = 0; }
+                           ~ProgressEpoch() { m->progress_on = false; if (sync_call && m->pin_progress) *m->pin_progress = 0; }
+    } progress_epoch(m, !(flags & DPDF_DEVICE_PTRS));
     return with_recovery(m, [&]() -> int {
     const dpdf_dims& d = m->d;
     const int T = 1 + (N + d.win) / d.hop;
@@ -2217,7 +2224,22 @@ extern "C" int dpdf_streams_prime(dpdf_streams* s, const float* pcm_in, int flag
 // snap_in / snap_ola (null: none): where the staging and overlap-add kernels leave the pre-call tails; ev_state (null: none):
 // event behind the pre-call copy of the state, awaited before the frame function starts to update the state in place
 struct StreamView { int S; float* state; float* in_tail; float* ola_tail; float* snap_in = nullptr; float* snap_ola = nullptr; hipEvent_t ev_state = nullptr; };
+static int streams_enqueue_body(dpdf_streams* s, const StreamView& v, const float* src, int T, float* dst, int* host_err);
+// run_stage2 arms Lane.export_pending (+ pending_sio, which holds THIS stream set's state / workspace pointers) for the late FIFO
+// export of a hop; an error exit between there and join_export must not leave it armed for the next call on the model
+// (possibly an offline batch, or after this dpdf_streams is gone).
 static int streams_enqueue(dpdf_streams* s, const StreamView& v, const float* src, int T, float* dst, int* host_err) {
+    dpdf_model* m = s->m;
+    const int rc = streams_enqueue_body(s, v, src, T, dst, host_err);
+    if (rc) {
+        Lane& L = m->lanes[0];
+        L.export_pending = false;
+        m->hx = dpdf_model::HopExtras{};
+        m->snap_dst = nullptr;
+    }
+    return rc;
+}
+static int streams_enqueue_body(dpdf_streams* s, const StreamView& v, const float* src, int T, float* dst, int* host_err) {
     dpdf_model* m = s->m;
     const dpdf_dims& d = m->d;
     const int S = v.S;
@@ -2414,6 +2436,9 @@ extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in,
     else HIP_TRY(hipStreamSynchronize(m->stream));
     if (*s->pin_err) {
         *s->pin_err = 0;
+        // recovery restores the PRE-CALL copy of state and tails: with the copy switched off (option "snapshot" = 0) there is
+        // nothing valid to go back to -- report the device error, the streams need reset / set_state (as for device pointers)
+        if (!m->snapshot) return check_device_err(m);
         if ((rc = streams_recover_and_rerun(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx))) return rc;
     }
     if (n_act == S) memcpy(pcm_out, s->pin_out, npcm * sizeof(float));

@@ -246,18 +246,23 @@ class StreamPool:
                     pcm[r.slot] = r.pcm[o: o + n * hop]
                     active[r.slot] = True
                 res = self._streams.process_masked(pcm, active)
-                self.device_calls += 1
+                with self._lock:
+                    self.device_calls += 1
                 for r in live:
                     o = done[id(r)] * hop
                     outs[id(r)][o: o + n * hop] = res[r.slot]
                     done[id(r)] += n
             for r in reqs:
                 r.out = outs[id(r)]
-        except BaseException as exc:          # every waiter must wake up
+        except Exception as exc:              # the waiters get the engine's error ...
             for r in reqs:
                 r.err = exc
-        finally:
+        except BaseException:                 # ... but never this thread's KeyboardInterrupt / SystemExit: they get a plain failure
             for r in reqs:
+                r.err = RuntimeError("the pool's device call was interrupted in another thread")
+            raise
+        finally:
+            for r in reqs:                    # every waiter must wake up
                 r.done.set()
 
     def _run(self, slot: int, pcm: np.ndarray, k: int) -> np.ndarray:
@@ -269,12 +274,20 @@ class StreamPool:
             if lead:
                 self._leader_active = True
         if lead:
-            if self._window > 0:
-                req.done.wait(self._window)          # nobody sets it yet: a plain bounded wait for followers to queue up
+            interrupted: Optional[BaseException] = None
+            try:
+                if self._window > 0:
+                    req.done.wait(self._window)      # nobody sets it yet: a plain bounded wait for followers to queue up
+            except BaseException as exc:             # (KeyboardInterrupt in the wait ...)
+                interrupted = exc
+            # whatever happened to this thread in the wait, the round is closed and RUN: the next caller leads again, and the
+            # followers queued so far -- whose hops are already out of their buffers -- get their results, nobody blocks forever
             with self._lock:
                 batch, self._queue = self._queue, []
                 self._leader_active = False
-            self._execute(batch)
+            self._execute(batch)                     # (wakes every request of the batch, also when it raises)
+            if interrupted is not None:
+                raise interrupted
         req.done.wait()
         if req.err is not None:
             raise req.err
@@ -286,9 +299,13 @@ class StreamPool:
         (chunks may have different sizes; each result is exactly what `enhancer.process(chunk)` returns)."""
         items = list(items)
         reqs: List[Optional[_Request]] = []
+        # validate EVERY item before any member's buffer is touched: a bad later item must not leave earlier members with hops
+        # taken out of their buffers and never sent to the device
         for enh, chunk in items:
             if enh._pool is not self:
                 raise ValueError("enhancer belongs to another pool")
+            enh._check_rate(chunk, sample_rate)
+        for enh, chunk in items:
             got = enh._stage(chunk, sample_rate)
             reqs.append(None if got is None else _Request(enh._slot, got[0], got[1]))
         live = [r for r in reqs if r is not None]
@@ -321,6 +338,31 @@ class PooledStreamEnhancer:
         if not self._closed:
             self._closed = True
             self._pool._release(self._slot)
+
+    def __enter__(self) -> "PooledStreamEnhancer":
+        return self
+
+    def __exit__(self, *_exc) -> None:
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()                  # a dropped member gives its slot back (close() is idempotent)
+        except Exception:
+            pass
+
+    def _check_rate(self, chunk: np.ndarray, sample_rate: Optional[int]) -> None:
+        """The checks of `_stage` that can fail, without consuming anything."""
+        if self._closed:
+            raise RuntimeError("this pool member was closed")
+        if np.asarray(chunk).size == 0:
+            return
+        sr_in = sample_rate if sample_rate is not None else self._pool._model_sr
+        if self._input_sr is not None and self._input_sr != sr_in:
+            raise ValueError(
+                f"Sample rate changed from {self._input_sr} to {sr_in} between "
+                "process() calls.  Call reset() before processing a new stream."
+            )
 
     def reset(self) -> None:
         self._pool._streams.reset(self._slot)

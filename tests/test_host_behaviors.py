@@ -526,3 +526,129 @@ def test_host_stft_helpers_match_reference_goldens(tag, win):
     assert y.dtype == np.float32 and np.abs(y - d["enhanced"]).max() < 1e-6
     with pytest.raises(ValueError):
         audio.preprocess_waveform(np.zeros(win // 2, np.float32), cfg)
+
+
+def test_process_many_validates_every_item_before_consuming_any(monkeypatch):
+    """A bad later item (sample-rate change, member of another pool) must not leave earlier members with hops taken out of their
+    buffers and never run; a dropped / `with`-scoped member gives its slot back."""
+    WIN, HOP = 320, 160
+    pool = _pool(monkeypatch, 3, win=WIN)
+    other = _pool(monkeypatch, 1, win=WIN)
+    a, b = pool.enhancer(), pool.enhancer()
+    foreign = other.enhancer()
+    x = (np.random.default_rng(1).standard_normal(WIN + 2 * HOP) * 0.3).astype(np.float32)
+    pool.process_many([(a, x[:WIN]), (b, x[:WIN])], sample_rate=16000)
+    with pytest.raises(ValueError, match="Sample rate changed"):
+        pool.process_many([(a, x[WIN:]), (b, x[WIN:])], sample_rate=8000)
+    with pytest.raises(ValueError, match="another pool"):
+        pool.process_many([(a, x[WIN:]), (foreign, x[WIN:])], sample_rate=16000)
+    assert a._pending.shape[0] == 0 and b._pending.shape[0] == 0           # nothing was consumed by the failed calls
+    twin = _pool(monkeypatch, 1, win=WIN).enhancer()
+    twin.process(x[:WIN], sample_rate=16000)
+    np.testing.assert_array_equal(pool.process_many([(a, x[WIN:])], sample_rate=16000)[0], twin.process(x[WIN:], sample_rate=16000))
+    # slots come back without an explicit close()
+    with pool.enhancer() as c:
+        assert c._slot not in pool._free
+    assert len(pool._free) == 1
+    d = pool.enhancer(); slot = d._slot
+    del d
+    import gc; gc.collect()
+    assert slot in pool._free
+
+
+def test_pool_leader_interrupted_in_its_window_does_not_strand_the_round(monkeypatch):
+    """The leader of a round is interrupted in its coalescing wait (KeyboardInterrupt): the round is closed and run all the same
+    -- the follower queued behind it gets its result, the leader sees its interrupt, and the next caller leads a new round."""
+    import threading
+    from dpdfnet_amd import stream as stream_mod
+    WIN, HOP = 320, 160
+    pool = _pool(monkeypatch, 2, win=WIN, window_s=0.0)
+    a, b = pool.enhancer(), pool.enhancer()
+    x = (np.random.default_rng(2).standard_normal(WIN + HOP) * 0.3).astype(np.float32)
+    a.process(x[:WIN], sample_rate=16000); b.process(x[:WIN], sample_rate=16000)
+    pool._window = 0.5
+    box = {"go": threading.Event(), "queued": threading.Event()}
+
+    class LeaderRequest(stream_mod._Request):
+        """The leader's request: its bounded wait lets the follower queue up, then is interrupted."""
+        def __init__(self, slot, pcm, k):
+            super().__init__(slot, pcm, k)
+            ev = self.done
+
+            class Done:
+                def wait(self, timeout=None):
+                    if timeout is None:
+                        return ev.wait(5.0)
+                    box["go"].set(); box["queued"].wait(2.0)
+                    raise KeyboardInterrupt()
+                def set(self): ev.set()
+            self.done = Done()
+
+    def leader():
+        got = a._stage(x[WIN:], 16000)
+        monkeypatch.setattr(stream_mod, "_Request", LeaderRequest)
+        try:
+            pool._run(a._slot, got[0], got[1])
+        except KeyboardInterrupt:
+            box["leader_interrupted"] = True
+
+    def follower():
+        got = b._stage(x[WIN:], 16000)
+        req = stream_mod._Request.__mro__[1](b._slot, got[0], got[1]) if stream_mod._Request is LeaderRequest else None
+        assert req is not None
+        with pool._lock:                                   # queue behind the live leader, exactly as _run does for a follower
+            assert pool._leader_active
+            pool._queue.append(req)
+        box["queued"].set()
+        box["follower_ok"] = req.done.wait(5.0)
+        box["follower_out"] = req.out
+
+    tl = threading.Thread(target=leader); tl.start()
+    assert box["go"].wait(2.0)
+    tf = threading.Thread(target=follower); tf.start()
+    tl.join(10.0); tf.join(10.0)
+    assert not tl.is_alive() and not tf.is_alive()
+    assert box.get("leader_interrupted") is True
+    assert box["follower_ok"] is True and box["follower_out"] is not None and box["follower_out"].shape == (HOP,)
+    assert pool._leader_active is False
+    monkeypatch.setattr(stream_mod, "_Request", LeaderRequest.__mro__[1])
+    pool._window = 0.0
+    assert a.process(np.zeros(HOP, np.float32), sample_rate=16000).shape == (HOP,)    # a new round can be led
+
+
+def test_progress_counts_only_the_watched_threads_call(monkeypatch):
+    """backend.HipModel.progress(owner=...) is 0 unless THAT thread is inside its engine call: a poller never reports another
+    thread's call on a shared runtime or the previous call's final count (the C side also zeroes the counter per call)."""
+    import threading
+    from dpdfnet_amd import backend
+
+    class FakeL:
+        def dpdf_progress(self, h): return 77
+    m = backend.HipModel.__new__(backend.HipModel)
+    m._L, m._h = FakeL(), None
+    m._call_lock, m._call_owner = threading.Lock(), None
+    me = threading.get_ident()
+    assert m.progress() == 77 and m.progress(owner=me) == 0
+    with m._offline_call():
+        assert m.progress(owner=me) == 77 and m.progress(owner=me + 1) == 0
+    assert m.progress(owner=me) == 0
+    # a callback that raises: the worker is joined before the exception leaves enhance()
+    sess = _patch(monkeypatch, win=8)
+    sess.progress = lambda: 0
+    import dpdfnet_amd, time
+    started = {}
+    real = sess.enhance_batch
+
+    def slow(wav, attn=None, **kw):
+        started["t"] = threading.current_thread(); time.sleep(0.05)
+        return real(wav, attn, **kw)
+    sess.enhance_batch = slow
+
+    def cb(d, t):
+        if d == 0:
+            return
+        raise RuntimeError("callback failed")
+    sess.progress = lambda: 1
+    with pytest.raises(RuntimeError, match="callback failed"):
+        dpdfnet_amd.enhance(np.zeros(64, np.float32), 16000, progress_callback=cb)
+    assert not started["t"].is_alive()
