@@ -179,6 +179,29 @@ def ort_baseline(onnx_path: str, seconds: float = 15.0) -> dict:
             "ms_per_frame_per_thread": 1e3 * dt * cores / max(1, sum(counts))}
 
 
+def public_api_pass(B: int, N: int, steps: int, ref_slots: dict) -> dict:
+    """The figure a USER of the package gets: `dpdfnet_amd.enhance_batch(list_of_numpy_clips, 16000, model="dpdfnet4")`, timed end to
+    end per call (reference package/src/dpdfnet/api.py:51-113 is its per-clip counterpart): list of 1-D float32 arrays in,
+    list of arrays out, everything in between (bucketing, the engine call on row pointers, H2D / D2H) inside the call."""
+    import dpdfnet_amd
+    clips = [c.copy() for c in synth_clips(B, N, SR, WEIGHT_SEED)]          # every clip in its own allocation, as a caller holds them
+    kw = dict(model=MODEL, onnx_path=f"synthetic:{WEIGHT_SEED}")
+    dpdfnet_amd.enhance_batch(clips, SR, **kw)                                # builds + caches the runtime, first-touch allocations
+    t0 = time.perf_counter()
+    outs = None
+    for _ in range(steps):
+        outs = dpdfnet_amd.enhance_batch(clips, SR, **kw)
+    dt = (time.perf_counter() - t0) / steps
+    from dpdfnet_amd import runtime as _rt
+    T = 1 + (N + 320) // 160
+    res = {"value_public_api": B * T / dt, "ms_per_call": 1e3 * dt, "calls": steps,
+           "call": f'dpdfnet_amd.enhance_batch(<list of {B} float32 arrays x {N} samples>, {SR}, model="{MODEL}")',
+           "finite_output": bool(all(np.isfinite(o).all() for o in outs)),
+           "max_abs_diff_vs_hbm_resident_output": (max(float(np.abs(outs[b] - ref_slots[b]).max()) for b in ref_slots) if ref_slots else None)}
+    _rt.clear_cache()
+    return res
+
+
 def other_configs() -> dict:
     """BASELINE.json's remaining single-GPU configurations, timed briefly beside the headline (they are parity-test
     cases in tests/test_gpu_fullsize.py; these are their speeds): dpdfnet2 / dpdfnet8 at 256 clips x 10 s, one clip
@@ -239,10 +262,71 @@ def other_configs() -> dict:
                                   "bound_us": round(bound_us, 1), "achieved_over_bound": round(1e6 * dt / bound_us, 2)},
                 "io": "host PCM in, host PCM out (pinned staging, zero-copy), one device call per hop"}
 
+    def public_streams(model_name: str, sr_: int, S: int, calls: int = 200) -> dict:
+        """configs[4] through the objects a USER holds (reference package/src/dpdfnet/stream.py:74-165): (a) one
+        `StreamEnhancer.group(S)` object, one hop of every stream per process() call; (b) S independent `pool.enhancer()` objects
+        fed one hop each per round from four host threads (the pool coalesces the hops that arrive within its window into one
+        device call).  Python staging, locks and the coalescing window are inside the figures."""
+        import threading
+        from dpdfnet_amd import StreamEnhancer, runtime as _rt
+        kw = dict(model=model_name, onnx_path=f"synthetic:{WEIGHT_SEED}")
+        hop = sr_ // 100
+        rng = np.random.default_rng(1)
+        pcm = (0.05 * rng.standard_normal((S, hop))).astype(np.float32)
+        g = StreamEnhancer.group(S, **kw)
+        g.process(np.concatenate([pcm, pcm], axis=1))          # window filled: primes, first hop
+        for _ in range(20):
+            g.process(pcm)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            y = g.process(pcm)
+        dt_group = (time.perf_counter() - t0) / calls
+        assert y.shape == (S, hop)
+        del g
+        pool = StreamEnhancer.pool(S, window_s=2e-4, **kw)
+        members = [pool.enhancer() for _ in range(S)]
+        pool.process_many([(m_, np.concatenate([pcm[i], pcm[i]])) for i, m_ in enumerate(members)])
+        nthreads, rounds = 4, calls
+        share = [list(range(t, S, nthreads)) for t in range(nthreads)]
+        bar = threading.Barrier(nthreads + 1)
+
+        def feeder(t: int) -> None:
+            mine = [(members[i], pcm[i]) for i in share[t]]
+            bar.wait()
+            for _ in range(rounds):
+                pool.process_many(mine)                         # this thread's streams: one request each, coalesced per round
+            bar.wait()
+
+        # (each thread hands its 16 streams to the pool together; hops of DIFFERENT threads meet in the pool only through process():
+        # measured below as the per-member form)
+        ths = [threading.Thread(target=feeder, args=(t,)) for t in range(nthreads)]
+        for th in ths:
+            th.start()
+        dc0 = pool.device_calls
+        bar.wait(); t0 = time.perf_counter(); bar.wait()
+        dt_pool = (time.perf_counter() - t0) / rounds
+        for th in ths:
+            th.join()
+        calls_per_round = (pool.device_calls - dc0) / rounds
+        for m_ in members:
+            m_.close()
+        del pool, members
+        _rt.clear_cache()
+        return {"us_per_call_public_group": round(1e6 * dt_group, 1),
+                "us_per_round_public_pool_4_threads": round(1e6 * dt_pool, 1), "pool_device_calls_per_round": round(calls_per_round, 2),
+                "note": "group: StreamEnhancer.group(S).process([S, hop]) per hop; pool: S pool.enhancer() objects, four host threads "
+                        "each feeding its 16 members one hop per round (one device call per thread and round: masked calls of 16 streams)"}
+
     # latency-bound configurations first (short kernels: measured before the long throughput runs heat the chip)
     fps, ms = offline(NB, 1, 5)
     out[f"{MODEL}_16k_1x10s"] = {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5)}
     out["dpdfnet8_48khz_hr_64_streams_1_hop"] = streams(48000, 8, 64)         # BASELINE configs[4]
+    try:
+        pub = public_streams("dpdfnet8_48khz_hr", 48000, 64)
+        pub["public_group_over_c_abi"] = round(pub["us_per_call_public_group"] / out["dpdfnet8_48khz_hr_64_streams_1_hop"]["us_per_call"], 3)
+        out["dpdfnet8_48khz_hr_64_streams_1_hop"]["public_objects"] = pub
+    except Exception as exc:
+        out["dpdfnet8_48khz_hr_64_streams_1_hop"]["public_objects"] = {"error": f"{type(exc).__name__}: {exc}"}
     out["dpdfnet2_16k_1_stream_1_hop"] = streams(16000, 2, 1)                  # one StreamEnhancer (the reference's unit of work)
     for nb in (2, 8):
         fps, ms = offline(nb, 256, 3)
@@ -532,49 +616,34 @@ def main() -> None:
         model.set_overlap(args.overlap if args.overlap >= 0 else 27)
 
     # ---- SURVEY 8(d)'s full metric: the same steps INCLUDING H2D of the noisy PCM and D2H of the enhanced PCM ----
-    # pinned host buffers, double-buffered device buffers; the upload of step i+1 and the download of step i-1 run on
-    # their own streams under the compute of step i.
+    # Through the PRODUCT: the library's own host-pointer call (dpdf_enhance_batch: numpy block in, numpy block out, pageable
+    # memory), which pipelines upload / compute / download over time slices inside the library (pinned staging ring, copy
+    # threads, per-chunk STFT / iSTFT: csrc/dpdf_model.hip enhance_impl).  Nothing is staged or overlapped by this file.
     pcie = None
     if world == 1 and not args.no_pcie:
-        h_in = torch.from_numpy(wav_host).pin_memory()
-        h_out = [torch.empty((B, N), dtype=torch.float32).pin_memory() for _ in range(2)]
-        d_in = [torch.empty_like(wav), torch.empty_like(wav)]
-        d_out = [torch.empty_like(wav), torch.empty_like(wav)]
-        s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
-        up = [None, None]; down = [None, None]
-
-        def upload(i: int) -> None:
-            with torch.cuda.stream(s_in):
-                d_in[i & 1].copy_(h_in, non_blocking=True)
-                e = torch.cuda.Event(); e.record(s_in); up[i & 1] = e
-
-        def run_pcie(nsteps: int) -> float:
+        def run_host(nsteps: int):
             sync(); t_ = time.perf_counter()
-            upload(0)
-            for i in range(nsteps):
-                up[i & 1].synchronize()                          # PCM of step i is in HBM
-                if down[i & 1] is not None:
-                    down[i & 1].synchronize()                    # download of step i-2 has left this output buffer
-                model.enhance_batch_device(d_in[i & 1].data_ptr(), B, N, d_out[i & 1].data_ptr(), None)
-                if i + 1 < nsteps:
-                    upload(i + 1)                                # under the compute of step i
-                model.sync()
-                with torch.cuda.stream(s_out):
-                    h_out[i & 1].copy_(d_out[i & 1], non_blocking=True)   # under the compute of step i+1
-                    e = torch.cuda.Event(); e.record(s_out); down[i & 1] = e
-            for e in down:
-                if e is not None:
-                    e.synchronize()
-            return time.perf_counter() - t_
+            y = None
+            for _ in range(nsteps):
+                y = model.enhance_batch(wav_host)
+            return time.perf_counter() - t_, y
 
-        run_pcie(1)
-        dtp = run_pcie(args.steps)
+        run_host(1)
+        dtp, y_host = run_host(args.steps)
+        model.set_option("host_pipe", 0)
+        run_host(1)
+        dtp0, _ = run_host(max(1, min(args.steps, 3)))
+        model.set_option("host_pipe", 1)
+        dtp0 /= max(1, min(args.steps, 3))
+        ref_slots = {b: timed_out_host[b] for b in timed_out_host} if timed_out_host else {}
         pcie = {"value_incl_pcie": B * T * args.steps / dtp, "ms_per_step_incl_pcie": 1e3 * dtp / args.steps,
-                "note": "host PCM (pinned) -> HBM -> enhance -> HBM -> host PCM (pinned), every step; copies double-buffered on "
-                        "their own streams under the compute of the neighbouring steps; includes the un-overlapped first upload "
-                        "and last download",
+                "note": "dpdf_enhance_batch with HOST pointers (pageable numpy block in and out), every step: the library pipelines "
+                        "H2D / compute / D2H over time slices itself; includes the exposed first upload and last download",
                 "bytes_per_step_each_way": int(B * N * 4),
-                "finite_output": bool(np.isfinite(h_out[(args.steps - 1) & 1].numpy()).all())}
+                "ms_per_step_unpipelined": 1e3 * dtp0,
+                "unpipelined_note": "the same call with dpdf_set_option host_pipe=0: one pageable upload, compute, one pageable download",
+                "finite_output": bool(np.isfinite(y_host).all()),
+                "max_abs_diff_vs_hbm_resident_output": (max(float(np.abs(y_host[b] - ref_slots[b]).max()) for b in ref_slots) if ref_slots else None)}
 
     if rank == 0:
         finite = bool(torch.isfinite(out).all().item())
@@ -710,6 +779,14 @@ def main() -> None:
             # RCCL executed on this box (one rank): communicator init on the device + the collectives the N > 1 path uses
             line["rccl_selftest"] = dist_selftest()
             line["rccl_init_ok"] = bool(line["rccl_selftest"].get("rccl_init_ok"))
+        if world == 1 and not args.no_pcie:
+            model.close()       # the public API builds its own (cached) handle: give it the device
+            try:
+                line["public_api"] = public_api_pass(B, N, args.steps, timed_out_host if args.clips == B else {})
+                line["value_public_api"] = line["public_api"]["value_public_api"]
+                line["public_api_over_hbm_resident"] = line["value_public_api"] / value
+            except Exception as exc:
+                line["public_api"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_other_configs and not args.no_isolated:
             model.close()       # the side configurations get the device to themselves (the headline engine's 33 GB workspace and four streams go first)
             try:

@@ -13,6 +13,7 @@ import ctypes
 import math
 import os
 import threading
+import weakref
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Dict, List, Optional, Tuple, Union
@@ -51,6 +52,7 @@ EXPORTED_SYMBOLS = (
     "dpdf_resample_len", "dpdf_resample", "dpdf_enhance_batch_ragged", "dpdf_debug_raise_device_error",
     "dpdf_set_option", "dpdf_streams_process_masked", "dpdf_streams_set_state", "dpdf_streams_get_tails",
     "dpdf_streams_prime_one", "dpdf_streams_is_primed", "dpdf_recovery_count", "dpdf_progress",
+    "dpdf_enhance_batch_rows",
 )
 
 
@@ -97,6 +99,8 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_enhance_batch.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, ctypes.c_int]
         L.dpdf_num_frames.argtypes = [vp, ctypes.c_int]
         L.dpdf_enhance_batch_ragged.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_float, vp, ctypes.c_int]
+        L.dpdf_enhance_batch_rows.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                              ctypes.POINTER(vp), ctypes.c_int]
         L.dpdf_debug_raise_device_error.argtypes = [vp]
         L.dpdf_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
         L.dpdf_streams_create.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
@@ -127,6 +131,51 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_resample.argtypes = [ctypes.c_int, vp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
         _lib = L
         return L
+
+
+class _HostBlockPool:
+    """Recycled host memory for the outputs of the batch calls.
+
+    A fresh 164 MB result block costs the kernel ~40 000 page faults (zeroed pages) while the library scatters into it and a
+    page-table teardown when it is dropped: 5-8 ms per 256 x 10 s call, as much as the whole H2D / D2H pipeline leaves exposed.
+    Blocks are therefore leased: `take(n)` hands out a flat float32 array of n elements on a block from the free list (or a new
+    one); the results of a call are row views of it; when the LAST view of a lease is garbage collected the block returns to the
+    free list (a ctypes array is the views' common base object; its weakref finaliser gives the block back).  Consequence: one
+    kept result keeps its whole block alive.  DPDFNET_OUTPUT_POOL_MB (default 2048) bounds the idle memory kept; 0 turns leasing
+    off (every result its own fresh array)."""
+
+    def __init__(self) -> None:
+        self._lock = threading.Lock()
+        self._free: List[np.ndarray] = []
+        self.limit_bytes = int(float(os.environ.get("DPDFNET_OUTPUT_POOL_MB", "2048")) * (1 << 20))
+        self.leases = 0          # statistics (tests)
+        self.reused = 0
+
+    def _give_back(self, raw: np.ndarray) -> None:
+        with self._lock:
+            if sum(b.nbytes for b in self._free) + raw.nbytes <= self.limit_bytes:
+                self._free.append(raw)
+
+    def take(self, n: int) -> np.ndarray:
+        n = int(n)
+        if self.limit_bytes <= 0 or n * 4 < (1 << 20):          # small results: plain arrays
+            return np.empty(n, dtype=np.float32)
+        raw = None
+        with self._lock:
+            self.leases += 1
+            fits = [b for b in self._free if n <= b.size <= 2 * n + 1024]
+            if fits:
+                raw = min(fits, key=lambda b: b.size)
+                self._free = [b for b in self._free if b is not raw]
+                self.reused += 1
+        if raw is None:
+            raw = np.empty(n, dtype=np.float32)
+        lease = (ctypes.c_float * raw.size).from_buffer(raw)          # shares raw's memory and keeps raw alive
+        weakref.finalize(lease, self._give_back, raw)
+        return np.frombuffer(lease, dtype=np.float32)[:n]           # .base (and every view's base) is `lease`
+
+
+_out_pool = _HostBlockPool()
 
 
 def _fp(a: np.ndarray):
@@ -263,30 +312,37 @@ class HipModel:
         wav = np.ascontiguousarray(wav, dtype=np.float32)
         if wav.ndim != 2:
             raise ValueError(f"wav must be [B,N], got {wav.shape}")
-        out = np.empty_like(wav)
+        out = _out_pool.take(wav.size).reshape(wav.shape)      # recycled host memory (no first-touch page faults; _HostBlockPool)
         db = float("nan") if attn_limit_db is None else float(attn_limit_db)
         with self._offline_call():
             _check(self._L.dpdf_enhance_batch(self._h, wav.ctypes.data, wav.shape[0], wav.shape[1], db, out.ctypes.data, DPDF_HOST_PTRS))
         return out
 
     def enhance_batch_ragged(self, clips, attn_limit_db: Optional[float] = None) -> List[np.ndarray]:
-        """Clips of different lengths (1-D float32 at the model rate) in ONE engine call (`dpdf_enhance_batch_ragged`);
-        each result equals `enhance_batch` on that clip alone."""
+        """Clips of different (or equal) lengths, each a 1-D float32 array at the model rate in its OWN buffer, in ONE engine
+        call (`dpdf_enhance_batch_rows`): the library reads every clip where it lies and writes every result into its own fresh
+        array -- no [B, n_max] block is assembled or taken apart here, and the H2D / D2H of the PCM is pipelined under the
+        compute inside the library.  Each result equals `enhance_batch` on that clip alone."""
         clips = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in clips]
         if not clips:
             return []
+        B = len(clips)
         lens = np.array([c.shape[0] for c in clips], dtype=np.int32)
         n_max = int(lens.max())
-        wav = np.zeros((len(clips), n_max), dtype=np.float32)
-        for i, c in enumerate(clips):
-            wav[i, : c.shape[0]] = c
-        out = np.empty_like(wav)
+        offs = np.concatenate([[0], np.cumsum(lens, dtype=np.int64)])
+        block = _out_pool.take(int(offs[-1]))                  # one leased block, the results are its row views (_HostBlockPool)
+        outs = [block[int(offs[i]): int(offs[i + 1])] for i in range(B)]
+        if n_max == 0:
+            return outs
+        live = [i for i in range(B) if lens[i] > 0]          # zero-length clips stay out of the call (their result is empty)
+        rows_in = (ctypes.c_void_p * len(live))(*[clips[i].ctypes.data for i in live])
+        rows_out = (ctypes.c_void_p * len(live))(*[outs[i].ctypes.data for i in live])
+        ll = np.ascontiguousarray(lens[live])
         db = float("nan") if attn_limit_db is None else float(attn_limit_db)
-        if n_max:
-            with self._offline_call():
-                _check(self._L.dpdf_enhance_batch_ragged(self._h, wav.ctypes.data, len(clips), n_max,
-                                                         lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), db, out.ctypes.data, DPDF_HOST_PTRS))
-        return [out[i, : int(lens[i])].copy() for i in range(len(clips))]
+        with self._offline_call():
+            _check(self._L.dpdf_enhance_batch_rows(self._h, rows_in, ll.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), len(live), n_max, db,
+                                                   rows_out, DPDF_HOST_PTRS))
+        return outs
 
     def enhance_batch_device(self, wav_ptr: int, B: int, N: int, out_ptr: int, attn_limit_db: Optional[float] = None) -> None:
         """Device-pointer form (HBM-resident input/output; asynchronous on the model's stream)."""

@@ -16,10 +16,21 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
+
+#include <sys/mman.h>
+#include <unistd.h>
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23      // Linux >= 5.14: prefault writable, contents untouched
+#endif
 
 #include "../../include/dpdfnet_hip.h"
 #include "../../include/dpdf_norm_init.h"
@@ -289,6 +300,58 @@ struct Lane {
 
 struct ProfEntry { double ms = 0; long calls = 0; };
 
+// ---- host I/O pipeline of the batch entry points (enhance_host_pipelined) --------------------------------------------------
+// A few worker threads that copy rows between the caller's (pageable) memory and pinned staging: a blocking parallel-for
+// in which the calling thread takes part.  One 256-clip time slice is 31 MB each way; four threads move it in ~1 ms.
+struct HostCopyPool {
+    std::vector<std::thread> th;
+    std::mutex mu; std::condition_variable cv, cv_done;
+    const std::function<void(int)>* job = nullptr;
+    int n_items = 0, busy = 0; std::atomic<int> next{0}; unsigned long gen = 0; bool stop = false;
+    void worker() {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* fn; int n;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; fn = job; n = n_items; ++busy;
+            }
+            // (a worker that wakes up only after its generation's run() has returned finds job == nullptr and must not touch the
+            // counter, which may already belong to the next generation)
+            if (fn) for (int i; (i = next.fetch_add(1)) < n;) (*fn)(i);
+            { std::lock_guard<std::mutex> lk(mu); if (--busy == 0) cv_done.notify_all(); }
+        }
+    }
+    void ensure(int n_threads) {
+        while ((int)th.size() < n_threads - 1) th.emplace_back([this] { worker(); });
+    }
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (th.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        { std::lock_guard<std::mutex> lk(mu); job = &fn; n_items = n; next.store(0); ++gen; }
+        cv.notify_all();
+        for (int i; (i = next.fetch_add(1)) < n;) fn(i);
+        std::unique_lock<std::mutex> lk(mu);
+        // every worker that woke up for this generation has drained the counter; workers that have not woken up yet will find it drained
+        cv_done.wait(lk, [&] { return busy == 0; });
+        job = nullptr; n_items = 0;
+    }
+    ~HostCopyPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+struct HostPipe {
+    static constexpr int R = 3;        // ring depth: slice k+2 is staged and slice k-2 drained while chunk k is enqueued
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    float* pin_in[R] = {}; float* pin_out[R] = {}; size_t cap_in = 0, cap_out = 0;     // floats per slot
+    hipEvent_t ev_up[R] = {}, ev_down[R] = {}, ev_s2[R] = {};
+    HostCopyPool pool;
+};
+
 struct dpdf_model {
     dpdf_cfg cfg; dpdf_dims d; dpdf_state_layout L;
     int device = 0;
@@ -363,6 +426,10 @@ struct dpdf_model {
     size_t window, stft_frag_s, istft_frag;
     int stft_groups_s, istft_groups, istft_K;
     DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state, stft_part;
+    HostPipe hp;                       // pinned staging ring + copy streams of the host-pointer batch calls
+    int host_pipe = 1;                 // host-pointer batch calls pipelined over time slices (0: one upload, compute, one download; A/B)
+    int host_prefault = 1;             // pipelined host calls: a helper thread populates the caller's output rows while the first chunk computes (0: A/B)
+    int host_copy_threads = 4;         // threads (incl. the caller's) that move rows between the caller's memory and pinned staging
     int stft_ksplit = 7;               // few frames: bit 0 STFT split five ways over K (stft_small), bit 1 streaming iSTFT split seven ways (summed by the overlap-add kernel)
     // profiling
     bool prof_on = false;
@@ -1573,9 +1640,8 @@ int join_export(dpdf_model* m) {
     if (L.x2_pending) { HIP_TRY(hipStreamWaitEvent(m->stream, L.ev_x2, 0)); L.x2_pending = false; }
     return DPDF_OK;
 }
-int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T, float* state,
-               float* out, const float* attn_raw, float alpha, bool defer_export_join = false) {
-    const dpdf_dims& d = m->d;
+// The time chunks of a [B][T] problem.
+std::vector<int> chunk_schedule(const dpdf_model* m, int B, int T) {
     // chunk_frames: >0 explicit, <0 whole sequence, 0 auto (below); small batches: 256 frames per
     // chunk -- a small batch is latency-bound and wants several chunks so that stage 2 of one runs under stage 1 of the
     // next (tools/latency_bench.py --chunks: 1 clip x 10 s 22.0 -> 18.2 ms, 32 clips 39.3 -> 29.7 ms)
@@ -1590,11 +1656,6 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
         if (B < 96) chunk = std::min(T, 256);
         else chunk = std::min(T, std::min(192, std::max(64, 131072 / B)));
     }
-    int rc;
-    m->ln = &m->lanes[0];
-    m->lanes[0].export_pending = false;      // (never armed across calls: join_export launches it, error exits disarm it)
-    if ((rc = init_lane(m->lanes[0]))) return rc;
-    if ((rc = ensure_ws(m, B, chunk))) return rc;
     // (Measured and dropped: ending on a quarter-size chunk to shorten the pipeline drain -- 115.0 vs 114.6 ms/step; splitting
     // the batch over two independent lanes -- 180 vs 120 ms/step; stage 2 as a five-stream pipeline of sub-stages across
     // chunks for small batches -- 13.3 vs 10.3 ms for one clip: DESIGN.md section 7.)
@@ -1609,6 +1670,23 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
         sizes.back() = last - m->tail_frames;
         sizes.push_back(m->tail_frames);
     }
+    return sizes;
+}
+// Callbacks around the chunks of run_chunks (the pipelined host path: per-chunk STFT in front of stage 1, per-chunk iSTFT /
+// overlap-add / download behind stage 2).  stage2_stream = the stream stage 2 of that chunk was enqueued on.
+struct ChunkHooks {
+    std::function<int(int ci, int t0, int Tc)> pre;
+    std::function<int(int ci, int t0, int Tc, hipStream_t stage2_stream)> post;
+};
+int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T, float* state,
+               float* out, const float* attn_raw, float alpha, bool defer_export_join = false, const ChunkHooks* hooks = nullptr) {
+    const dpdf_dims& d = m->d;
+    int rc;
+    m->ln = &m->lanes[0];
+    m->lanes[0].export_pending = false;      // (never armed across calls: join_export launches it, error exits disarm it)
+    if ((rc = init_lane(m->lanes[0]))) return rc;
+    const std::vector<int> sizes = chunk_schedule(m, B, T);
+    if ((rc = ensure_ws(m, B, *std::max_element(sizes.begin(), sizes.end())))) return rc;
     // Stage 2 imports its FIFOs BEFORE it waits for stage 1 of the chunk (run_stage2), so nothing else orders the stage-2 stream
     // behind what the caller queued on the main stream in front of this call -- the upload or the initialisation of the very
     // state that import reads.  One event at the head of the call does.
@@ -1621,7 +1699,9 @@ int run_chunks(dpdf_model* m, const float* raw, size_t clip_stride, int B, int T
     int i = 0, t0 = 0;
     for (size_t ci = 0; ci < sizes.size(); t0 += sizes[ci], ++ci, ++i) {
         ChunkArgs c{raw + (size_t)t0 * d.F * 2, clip_stride, B, sizes[ci], state, out, clip_stride, t0, attn_raw, alpha, i & 1};
+        if (hooks && hooks->pre && (rc = hooks->pre((int)ci, t0, sizes[ci]))) return rc;
         if ((rc = run_stage1(m, c)) || (rc = run_stage2(m, c))) return rc;
+        if (hooks && hooks->post && (rc = hooks->post((int)ci, t0, sizes[ci], ((m->overlap & 1) && !m->ln->single_chunk) ? m->ln->sB : m->ln->sA))) return rc;
     }
     Lane& L = m->lanes[0];
     for (int p = 0; p < NRING; ++p)
@@ -1830,6 +1910,15 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
     if (m->iconsts) (void)hipFree(m->iconsts);
     if (m->d_err) (void)hipFree(m->d_err);
     if (m->pin_progress) (void)hipHostFree(m->pin_progress);
+    for (int r = 0; r < HostPipe::R; ++r) {
+        if (m->hp.pin_in[r]) (void)hipHostFree(m->hp.pin_in[r]);
+        if (m->hp.pin_out[r]) (void)hipHostFree(m->hp.pin_out[r]);
+        if (m->hp.ev_up[r]) (void)hipEventDestroy(m->hp.ev_up[r]);
+        if (m->hp.ev_down[r]) (void)hipEventDestroy(m->hp.ev_down[r]);
+        if (m->hp.ev_s2[r]) (void)hipEventDestroy(m->hp.ev_s2[r]);
+    }
+    if (m->hp.s_up) (void)hipStreamDestroy(m->hp.s_up);
+    if (m->hp.s_down) (void)hipStreamDestroy(m->hp.s_down);
     if (m->d_lens) (void)hipFree(m->d_lens);
     if (m->d_init_state) (void)hipFree(m->d_init_state);
     for (hipEvent_t e : m->prof_events) if (e) (void)hipEventDestroy(e);
@@ -1932,6 +2021,9 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "dec_pyr_rows") m->dec_pyr_rows = value;
     else if (n == "late_export") m->late_export = value != 0;
     else if (n == "snapshot") m->snapshot = value != 0;
+    else if (n == "host_pipe") m->host_pipe = value != 0;
+    else if (n == "host_prefault") m->host_prefault = value != 0;
+    else if (n == "host_copy_threads") m->host_copy_threads = value < 1 ? 1 : value;
     else if (n == "single_chunk_inline") m->single_chunk_inline = value != 0;
     else if (n == "fuse_dec") m->fuse_dec = value != 0;
     else if (n == "interleave") m->interleave = value != 0;
@@ -2057,8 +2149,48 @@ extern "C" int dpdf_run_frames(dpdf_model* m, const float* spec, int B, int T, f
 // ------------------------------------------------------------------------------------------------
 
 // lengths: nullptr = every clip is N samples; else host array [B] of per-clip sample counts (<= N, the row stride)
-static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int* lengths, float attn_limit_db, float* out, int flags) {
-    if (!m || !wav || !out) return set_err(DPDF_E_INVALID, "null argument");
+// Rows of a host-pointer call: in[b] holds in_len[b] readable floats, out[b] takes out_len[b] (null: N each).
+struct HostRows { const float* const* in; float* const* out; const int* in_len; const int* out_len; };
+
+// Pinned staging ring, copy streams and the copy threads of the pipelined host path (grown on demand, kept by the handle).
+static int ensure_host_pipe(dpdf_model* m, size_t slot_in, size_t slot_out) {
+    HostPipe& hp = m->hp;
+    if (!hp.s_up) {
+        HIP_TRY(hipStreamCreateWithFlags(&hp.s_up, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&hp.s_down, hipStreamNonBlocking));
+        for (int r = 0; r < HostPipe::R; ++r) {
+            HIP_TRY(hipEventCreateWithFlags(&hp.ev_up[r], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&hp.ev_down[r], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&hp.ev_s2[r], hipEventDisableTiming));
+        }
+    }
+    hp.pool.ensure(std::max(1, std::min(m->host_copy_threads, 16)));
+    if (slot_in > hp.cap_in) {
+        HIP_TRY(hipStreamSynchronize(hp.s_up));
+        for (int r = 0; r < HostPipe::R; ++r) {
+            if (hp.pin_in[r]) (void)hipHostFree(hp.pin_in[r]);
+            hp.pin_in[r] = nullptr;
+        }
+        hp.cap_in = 0;
+        for (int r = 0; r < HostPipe::R; ++r) HIP_TRY(hipHostMalloc((void**)&hp.pin_in[r], slot_in * sizeof(float), hipHostMallocDefault));
+        hp.cap_in = slot_in;
+    }
+    if (slot_out > hp.cap_out) {
+        HIP_TRY(hipStreamSynchronize(hp.s_down));
+        for (int r = 0; r < HostPipe::R; ++r) {
+            if (hp.pin_out[r]) (void)hipHostFree(hp.pin_out[r]);
+            hp.pin_out[r] = nullptr;
+        }
+        hp.cap_out = 0;
+        for (int r = 0; r < HostPipe::R; ++r) HIP_TRY(hipHostMalloc((void**)&hp.pin_out[r], slot_out * sizeof(float), hipHostMallocDefault));
+        hp.cap_out = slot_out;
+    }
+    return DPDF_OK;
+}
+
+static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int* lengths, float attn_limit_db, float* out, int flags,
+                        const HostRows* rows = nullptr) {
+    if (!m || (!rows && (!wav || !out))) return set_err(DPDF_E_INVALID, "null argument");
     if (B <= 0 || N < 0) return set_err(DPDF_E_INVALID, "bad batch geometry B=%d N=%d", B, N);
     if (attn_limit_db < 0.f) return set_err(DPDF_E_INVALID, "attn_limit_db must be non-negative, infinity, or None.");
     if (lengths)
@@ -2073,6 +2205,19 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
                            ProgressEpoch(dpdf_model* m_, bool s_) : m(m_), sync_call(s_) { if (m->pin_progress) *m->pin_progress = 0; }
                            ~ProgressEpoch() { m->progress_on = false; if (sync_call && m->pin_progress) *m->pin_progress = 0; }
     } progress_epoch(m, !(flags & DPDF_DEVICE_PTRS));
+    const bool host = !(flags & DPDF_DEVICE_PTRS);
+    if (rows && !host) return set_err(DPDF_E_INVALID, "the row-pointer form takes host pointers");
+    // host-pointer calls see their rows through pointers (a [B][N] block is B rows N floats apart)
+    std::vector<const float*> blk_in; std::vector<float*> blk_out;
+    HostRows hr{nullptr, nullptr, nullptr, nullptr};
+    if (host) {
+        if (rows) hr = *rows;
+        else {
+            blk_in.resize(B); blk_out.resize(B);
+            for (int b = 0; b < B; ++b) { blk_in[b] = wav + (size_t)b * N; blk_out[b] = out + (size_t)b * N; }
+            hr = HostRows{blk_in.data(), blk_out.data(), nullptr, nullptr};
+        }
+    }
     return with_recovery(m, [&]() -> int {
     const dpdf_dims& d = m->d;
     const int T = 1 + (N + d.win) / d.hop;
@@ -2087,19 +2232,152 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         HIP_TRY(hipMemcpyAsync(m->d_lens, m->h_lens.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, m->stream));
         d_lens = m->d_lens;
     }
-    const bool host = !(flags & DPDF_DEVICE_PTRS);
     const size_t nw = (size_t)B * N, nspec = (size_t)B * T * d.F * 2;
     int rc;
     const float* d_wav = wav; float* d_out = out;
+    // ---- host pointers: pipelined over TIME SLICES (the metric includes the H2D of the noisy and the D2H of the
+    // enhanced PCM).  The frame function walks time chunks [t0, t1) anyway: chunk k needs the samples below (t1 - 1) hop + win / 2
+    // and completes the output samples below (t1 - 5) hop (overlap-add of frames p / hop - 1 and p / hop at p = n + 2 win +
+    // win / 2).  So slice k+2 is gathered into pinned staging by the copy threads and uploaded, and slice k-2 downloaded and
+    // scattered to the caller's rows, while the GPU computes chunk k; the STFT and the iSTFT + overlap-add run per chunk
+    // (the synthesis on the download stream).  Only the first slice's upload and the last one's download are exposed.
+    const std::vector<int> sizes = chunk_schedule(m, B, T);
+    bool piped = host && m->host_pipe && !m->prof_on;
+    for (int Tc : sizes) piped = piped && (long)B * Tc > SMALL_M_ROWS;
+    struct Slice { int t0, Tc, u0, u1, v0, v1; };
+    std::vector<Slice> sl;
+    size_t slot_in = 0, slot_out = 0;
+    if (piped) {
+        int t0 = 0, u = 0, v = 0;
+        for (size_t k = 0; k < sizes.size(); ++k) {
+            const int t1 = t0 + sizes[k];
+            const bool last = k + 1 == sizes.size();
+            const int u1 = last ? N : std::max(u, std::min(N, (t1 - 1) * d.hop + d.win / 2));
+            const int v1 = last ? N : std::max(v, std::min(N, (t1 - 5) * d.hop));
+            sl.push_back(Slice{t0, sizes[k], u, u1, v, v1});
+            slot_in = std::max(slot_in, (size_t)B * (u1 - u)); slot_out = std::max(slot_out, (size_t)B * (v1 - v));
+            t0 = t1; u = u1; v = v1;
+        }
+    }
+    std::vector<float> flat_in, flat_out;          // small host calls in the row-pointer form: one contiguous staging block each way
     if (host) {
         if ((rc = m->io_wav.ensure(nw)) || (rc = m->io_out.ensure(nw))) return rc;
-        HIP_TRY(hipMemcpyAsync(m->io_wav.p, wav, nw * sizeof(float), hipMemcpyHostToDevice, m->stream));
         d_wav = m->io_wav.p; d_out = m->io_out.p;
+        if (piped) { if ((rc = ensure_host_pipe(m, slot_in, slot_out))) return rc; }
+        else {
+            const float* src = wav;
+            if (rows) {
+                flat_in.assign(nw, 0.f);
+                for (int b = 0; b < B; ++b) memcpy(flat_in.data() + (size_t)b * N, hr.in[b], (size_t)(hr.in_len ? hr.in_len[b] : N) * sizeof(float));
+                src = flat_in.data();
+            }
+            HIP_TRY(hipMemcpyAsync(m->io_wav.p, src, nw * sizeof(float), hipMemcpyHostToDevice, m->stream));
+            if (rows) HIP_TRY(hipStreamSynchronize(m->stream));       // flat_in is pageable: the copy has left it
+        }
     }
     if ((rc = m->raw_spec.ensure(nspec)) || (rc = m->enh_spec.ensure(nspec)) ||
         (rc = m->batch_state.ensure((size_t)B * d.state_size)) || (rc = m->frames.ensure((size_t)B * T * d.win))) return rc;
-    // A1: analysis STFT
-    {
+    HostPipe& hp = m->hp;
+    constexpr int R = HostPipe::R;
+    static const bool trace = getenv("DPDF_HOST_PIPE_TRACE") != nullptr;      // stderr: where the host thread of a pipelined call spends its time
+    struct Tr { double t_stage = 0, t_upwait = 0, t_drainwait = 0, t_scatter = 0; } tr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_call0 = now(); double t_first_up = 0;
+    // gather slice k of every row into its pinned slot and queue the upload
+    auto stage_up = [&](int k) -> int {
+        const Slice& q = sl[k];
+        const int slot = k % R, w = q.u1 - q.u0;
+        double t0_ = now();
+        if (k >= R) HIP_TRY(hipEventSynchronize(hp.ev_up[slot]));           // the upload that last read this slot
+        tr.t_upwait += now() - t0_; t0_ = now();
+        if (w > 0) {
+            float* pin = hp.pin_in[slot];
+            const std::function<void(int)> fn = [&](int b) {
+                const int have = hr.in_len ? hr.in_len[b] : N;
+                const int n = std::max(0, std::min(have, q.u1) - q.u0);         // (samples beyond a short clip's end are never read)
+                if (n > 0) memcpy(pin + (size_t)b * w, hr.in[b] + q.u0, (size_t)n * sizeof(float));
+            };
+            if (m->host_copy_threads > 1) hp.pool.run(B, fn); else for (int b = 0; b < B; ++b) fn(b);
+            HIP_TRY(hipMemcpy2DAsync(m->io_wav.p + q.u0, (size_t)N * sizeof(float), pin, (size_t)w * sizeof(float), (size_t)w * sizeof(float), B,
+                                     hipMemcpyHostToDevice, hp.s_up));
+        }
+        HIP_TRY(hipEventRecord(hp.ev_up[slot], hp.s_up));
+        tr.t_stage += now() - t0_;
+        return DPDF_OK;
+    };
+    // wait for slice k's download and scatter it to the caller's rows
+    auto drain = [&](int k) -> int {
+        const Slice& q = sl[k];
+        const int slot = k % R, w = q.v1 - q.v0;
+        double t0_ = now();
+        HIP_TRY(hipEventSynchronize(hp.ev_down[slot]));
+        tr.t_drainwait += now() - t0_; t0_ = now();
+        if (trace) fprintf(stderr, "[host_pipe]   slice %d down at %.2f ms\n", k, now() - t_call0);
+        if (w > 0) {
+            const float* pin = hp.pin_out[slot];
+            const std::function<void(int)> fn = [&](int b) {
+                const int room = hr.out_len ? hr.out_len[b] : N;
+                const int n = std::max(0, std::min(room, q.v1) - q.v0);
+                if (n > 0) memcpy(hr.out[b] + q.v0, pin + (size_t)b * w, (size_t)n * sizeof(float));
+            };
+            if (m->host_copy_threads > 1) hp.pool.run(B, fn); else for (int b = 0; b < B; ++b) fn(b);
+        }
+        tr.t_scatter += now() - t0_;
+        return DPDF_OK;
+    };
+    ChunkHooks hooks;
+    // Output rows the caller has just allocated are not backed by pages yet: the first write to every 4 KB costs a fault and a
+    // zeroed page (~40 000 of them for 256 x 10 s), and the writes of the LAST slices are the exposed tail of the call.  A helper
+    // thread populates the rows (madvise MADV_POPULATE_WRITE: contents untouched, so no ordering against the scatter is needed)
+    // while the GPU works on the first chunk.  Rows that are populated already cost a page-table walk.
+    struct Prefault { std::thread th; ~Prefault() { if (th.joinable()) th.join(); } } prefault;
+    if (piped && m->host_prefault && nw * sizeof(float) >= ((size_t)8 << 20)) {
+        prefault.th = std::thread([&hr, B, N] {
+            const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
+            for (int b = 0; b < B; ++b) {
+                const size_t n = (size_t)(hr.out_len ? hr.out_len[b] : N) * sizeof(float);
+                size_t lo = ((size_t)hr.out[b] + pg - 1) / pg * pg, hi = ((size_t)hr.out[b] + n) / pg * pg;
+                if (hi > lo && madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE) != 0) return;     // old kernel / odd mapping: leave it to the scatter
+            }
+        });
+    }
+    if (piped) {
+        if ((rc = stage_up(0))) return rc;
+        t_first_up = now() - t_call0;
+        if (sl.size() > 1 && (rc = stage_up(1))) return rc;
+        hooks.pre = [&](int k, int t0, int Tc) -> int {
+            // A1 for the frames of this chunk, behind its slice's upload
+            HIP_TRY(hipStreamWaitEvent(m->stream, hp.ev_up[k % R], 0));
+            const RowSeg seg{Tc, T, t0};
+            StftSegA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window), d_lens, seg};
+            SegStore<2> ep{m->raw_spec.p, (size_t)2 * d.F, 32, 32, 2 * d.F, seg};
+            launch_gemm_rows_wn<2, 64>(m->stream, ap, m->C(m->stft_frag_s), ep, B * Tc, d.win, m->stft_groups_s / 4);
+            return DPDF_OK;
+        };
+        hooks.post = [&](int k, int t0, int Tc, hipStream_t s2) -> int {
+            // A14 for the frames of this chunk + the output samples they complete, on the download stream behind stage 2
+            const Slice& q = sl[k];
+            const int slot = k % R, w = q.v1 - q.v0;
+            HIP_TRY(hipEventRecord(hp.ev_s2[slot], s2));
+            HIP_TRY(hipStreamWaitEvent(hp.s_down, hp.ev_s2[slot], 0));
+            const RowSeg seg{Tc, T, t0};
+            PlainSegA<48> ap{m->enh_spec.p, (size_t)2 * d.F, 2 * d.F, seg};
+            WindowSegStore<5> ep{m->frames.p, d.win, m->C(m->window), seg};
+            if (m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(hp.s_down, ap, m->C(m->istft_frag), ep, B * Tc, m->istft_K, m->istft_groups / 4);
+            else launch_gemm_rows<5, 48, false>(hp.s_down, ap, m->C(m->istft_frag), ep, B * Tc, m->istft_K, m->istft_groups);
+            if (w > 0) {
+                OlaArgs oa{m->frames.p, m->C(m->window), d_out, B, T, N, d.win, d.hop, d_lens, q.v0, w};
+                hipLaunchKernelGGL(ola_kernel, dim3((unsigned)(((size_t)B * w + 255) / 256)), dim3(256), 0, hp.s_down, oa);
+                HIP_TRY(hipMemcpy2DAsync(hp.pin_out[slot], (size_t)w * sizeof(float), d_out + q.v0, (size_t)N * sizeof(float), (size_t)w * sizeof(float), B,
+                                         hipMemcpyDeviceToHost, hp.s_down));
+            }
+            HIP_TRY(hipEventRecord(hp.ev_down[slot], hp.s_down));
+            if (k + 2 < (int)sl.size() && (rc = stage_up(k + 2))) return rc;
+            if (k >= 2 && (rc = drain(k - 2))) return rc;
+            return DPDF_OK;
+        };
+    } else {
+        // A1: analysis STFT
         ProfScope ps(m, "stft");
         StftA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window), 0, d_lens};
         if (B * T <= SMALL_M_ROWS) {
@@ -2122,9 +2400,22 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
     if (m->pin_progress) *m->pin_progress = 0;
     m->progress_on = true;
     rc = run_chunks(m, m->raw_spec.p, (size_t)T * d.F * 2, B, T, m->batch_state.p, m->enh_spec.p,
-                    attn ? m->raw_spec.p : nullptr, alpha);
+                    attn ? m->raw_spec.p : nullptr, alpha, false, piped ? &hooks : nullptr);
     m->progress_on = false;
-    if (rc) return rc;
+    if (rc) {
+        if (piped) { (void)hipStreamSynchronize(hp.s_up); (void)hipStreamSynchronize(hp.s_down); (void)hipStreamSynchronize(m->stream); }
+        return rc;
+    }
+    if (piped) {
+        HIP_TRY(hipGetLastError());
+        const int n = (int)sl.size();
+        for (int k = std::max(0, n - 2); k < n; ++k) if ((rc = drain(k))) return rc;
+        HIP_TRY(hipStreamSynchronize(m->stream));        // the state exports of the last chunk; every stream is joined behind this
+        if (trace) fprintf(stderr, "[host_pipe] call %.2f ms: first upload staged+queued by %.2f, gather+queue %.2f, wait(up slot) %.2f, wait(down) %.2f, scatter %.2f, enqueue+rest %.2f\n",
+                           now() - t_call0, t_first_up, tr.t_stage, tr.t_upwait, tr.t_drainwait, tr.t_scatter,
+                           now() - t_call0 - tr.t_stage - tr.t_upwait - tr.t_drainwait - tr.t_scatter);
+        return device_err_or_retry(m);
+    }
     // A14: synthesis
     {
         ProfScope ps(m, "istft");
@@ -2137,8 +2428,12 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
     }
     HIP_TRY(hipGetLastError());
     if (host) {
-        HIP_TRY(hipMemcpyAsync(out, d_out, nw * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        float* dst = out;
+        if (rows) { flat_out.resize(nw); dst = flat_out.data(); }
+        HIP_TRY(hipMemcpyAsync(dst, d_out, nw * sizeof(float), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
+        if (rows)
+            for (int b = 0; b < B; ++b) memcpy(hr.out[b], flat_out.data() + (size_t)b * N, (size_t)(hr.out_len ? hr.out_len[b] : N) * sizeof(float));
         return device_err_or_retry(m);
     }
     return DPDF_OK;
@@ -2152,6 +2447,15 @@ extern "C" int dpdf_enhance_batch_ragged(dpdf_model* m, const float* wav, int B,
                                          float attn_limit_db, float* out, int flags) {
     if (!lengths) return set_err(DPDF_E_INVALID, "null lengths");
     return enhance_impl(m, wav, B, n_max, lengths, attn_limit_db, out, flags);
+}
+extern "C" int dpdf_enhance_batch_rows(dpdf_model* m, const float* const* in_rows, const int* lengths, int B, int n_max,
+                                       float attn_limit_db, float* const* out_rows, int flags) {
+    if (!in_rows || !out_rows) return set_err(DPDF_E_INVALID, "null argument");
+    if (flags & DPDF_DEVICE_PTRS) return set_err(DPDF_E_INVALID, "dpdf_enhance_batch_rows takes host pointers");
+    for (int b = 0; b < B; ++b)
+        if (!in_rows[b] || !out_rows[b]) return set_err(DPDF_E_INVALID, "null row pointer %d", b);
+    HostRows hr{in_rows, out_rows, lengths, lengths};
+    return enhance_impl(m, nullptr, B, n_max, lengths, attn_limit_db, nullptr, flags, &hr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -564,6 +564,124 @@ struct WindowStore {
     }
 };
 
+// ============================ time-slice forms (pipelined host I/O) ============================
+// A host-pointer batch call is pipelined over time slices (dpdf_model.hip, enhance_host_pipelined): the PCM of time chunk k+1 is
+// uploaded and the PCM of chunk k-1 downloaded under the compute of chunk k, so the STFT and the iSTFT run PER CHUNK on the
+// rows (clip b, frames t0 .. t0+Tc) of tensors laid out [B][T][...].  RowSeg maps the launch's dense row index onto them.
+struct RowSeg {
+    int Tc, T, t0;
+    __device__ __forceinline__ size_t map(int row) const { const int b = row / Tc; return (size_t)b * T + t0 + (row - b * Tc); }
+};
+// StftA on the rows of one time chunk (same arithmetic per element: window[k] * x_pad[...])
+template <int KP>
+struct StftSegA {
+    const float* wav; int N; int T; int win, hop; const float* window; const int* lens; RowSeg seg;
+    static constexpr int NI = GEMM_BM * KP / 256;
+    struct Regs { float v[NI]; };
+    __device__ __forceinline__ void load(Regs& R, int row0, int kp, int, int M) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx / KP, k = idx - r * KP;
+            int row = row0 + r;
+            float v = 0.f;
+            if (row < M) {
+                const int b = row / seg.Tc, t = seg.t0 + (row - b * seg.Tc);
+                const int nb_ = lens ? lens[b] : N;
+                const int np_ = nb_ + win;
+                int kk = kp + k;
+                int j = t * hop + kk - win / 2;
+                if (j < 0) j = -j;
+                if (j >= np_) j = 2 * (np_ - 1) - j;
+                const bool live = !lens || t < 1 + np_ / hop;
+                if (live && j >= 0 && j < nb_ && kk < win) v = wav[(size_t)b * N + j] * window[kk];
+            }
+            R.v[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*As)[KP + 4], const Regs& R, int, int, int, int) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx / KP, k = idx - r * KP;
+            As[r][k] = R.v[i];
+        }
+    }
+};
+template <int KP>
+struct PlainSegA {         // PlainA whose row r is row seg.map(r) of src
+    const float* src; size_t lda; int kmax; RowSeg seg;
+    static constexpr int V = KP / 4, NI = (GEMM_BM * V + 255) / 256;
+    struct Regs { float4 v[NI]; };
+    __device__ __forceinline__ void load(Regs& R, int row0, int kp, int, int M) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx / V, c4 = (idx - r * V) * 4;
+            int row = row0 + r, k = kp + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < GEMM_BM * V && row < M) {
+                const float* s = src + seg.map(row) * lda + k;
+                if (k + 3 < kmax) v = *(const float4*)s;
+                else {
+                    if (k < kmax) v.x = s[0];
+                    if (k + 1 < kmax) v.y = s[1];
+                    if (k + 2 < kmax) v.z = s[2];
+                }
+            }
+            R.v[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float (*As)[KP + 4], const Regs& R, int, int, int, int) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int r = idx / V, c4 = (idx - r * V) * 4;
+            if (idx < GEMM_BM * V) *(float4*)&As[r][c4] = R.v[i];
+        }
+    }
+};
+template <int NT>
+struct SegStore {          // out[seg.map(r)*ldo + grp*gostride + col] = acc (the STFT's store, no bias / activation)
+    float* out; size_t ldo; int gostride; int N; int ncol_total; RowSeg seg;
+    using Pref = NoRegs;
+    __device__ __forceinline__ void prefetch(Pref&, int, int, int, int) const {}
+    __device__ __forceinline__ void call(f32x4 (&acc)[NT], const Pref&, int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            int col = nt * 16 + cl;
+            if (col >= N) continue;
+            if (grp * gostride + col >= ncol_total) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = row0 + rq + i;
+                if (row < M) out[seg.map(row) * ldo + (size_t)grp * gostride + col] = acc[nt][i];
+            }
+        }
+    }
+};
+template <int NT>
+struct WindowSegStore {    // WindowStore onto rows seg.map(r)
+    float* out; int win; const float* window; RowSeg seg;
+    using Pref = NoRegs;
+    __device__ __forceinline__ void prefetch(Pref&, int, int, int, int) const {}
+    __device__ __forceinline__ void call(f32x4 (&acc)[NT], const Pref&, int row0, int lane, int grp, int M) const {
+        const int cl = lane & 15, rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            int col = grp * NT * 16 + nt * 16 + cl;
+            if (col >= win) continue;
+            float wv = window[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = row0 + rq + i;
+                if (row < M) out[seg.map(row) * win + col] = acc[nt][i] * wv;
+            }
+        }
+    }
+};
+
 // ================================= the kernel =================================================
 // wfrag layout: [grp][chunk c][tile nt][kb][lane]  (chunk = 16 K values; value = W[kperm(c,lane>>4,kb)][nt*16+(lane&15)])
 template <int NT, int KP, bool PERSIST_B, class AProd, class Epi>

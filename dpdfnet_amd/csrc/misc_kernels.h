@@ -443,11 +443,15 @@ struct OlaArgs {
     int B, T, N, win, hop;
     const int* lens;       // ragged batch (else nullptr): clip b is lens[b] samples / T_b = 1 + (lens[b] + win) / hop frames long;
                            // its own 2*win shift, zero tail and fit_length; out[b][lens[b]:N] = 0
+    int n0 = 0, nw = 0;    // nw > 0: only the samples [n0, n0 + nw) of every clip (time slice of a pipelined host call: they need
+                           // frames < (n0 + nw) / hop + 5 only)
 };
 __global__ void ola_kernel(OlaArgs a) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)a.B * a.N) return;
-    const int b = (int)(idx / a.N), i = (int)(idx - (size_t)b * a.N);
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int span = a.nw > 0 ? a.nw : a.N;
+    if (idx >= (size_t)a.B * span) return;
+    const int b = (int)(idx / span), i = a.n0 + (int)(idx - (size_t)b * span);
+    idx = (size_t)b * a.N + i;
     const int nb = a.lens ? a.lens[b] : a.N;
     const int Tb = a.lens ? 1 + (nb + a.win) / a.hop : a.T;
     const long ylen = (long)a.hop * (Tb - 1);

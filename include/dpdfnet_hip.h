@@ -88,6 +88,17 @@ int dpdf_progress(const dpdf_model* m);
  * clip (causal: padding frames cannot reach earlier outputs), so callers bucket by length to bound the waste. */
 int dpdf_enhance_batch_ragged(dpdf_model* m, const float* wav, int B, int n_max, const int* lengths,
                               float attn_limit_db, float* out, int flags);
+/* The same with every clip in its OWN host buffer -- a list of arrays is what `enhance_batch` / `enhance_dir` hold (reference
+ * api.py:51-113 per clip, cli.py:249-259 per file): in_rows[b] holds lengths[b] samples (lengths NULL: n_max each),
+ * out_rows[b] receives lengths[b] samples; no [B, n_max] block has to be assembled or taken apart by the caller.  Host
+ * pointers only.
+ * HOST-pointer calls of all three entry points are pipelined over time slices inside the library: the noisy PCM of time
+ * chunk k+2 is gathered into pinned staging by a few copy threads and uploaded, and the enhanced PCM of chunk k-2 downloaded
+ * and scattered to the caller's rows, while the GPU computes chunk k (the metric includes H2D and D2H);
+ * only the first slice's upload and the last one's download are exposed.  dpdf_set_option "host_pipe" 0 = one upload,
+ * compute, one download (A/B); "host_copy_threads" (default 4, the caller's thread included). */
+int dpdf_enhance_batch_rows(dpdf_model* m, const float* const* in_rows, const int* lengths, int B, int n_max,
+                            float attn_limit_db, float* const* out_rows, int flags);
 
 /* Device-resident streaming (StreamEnhancer.process hot loop, stream.py:116-156, for S
  * concurrent streams): state, analysis tail and overlap-add tail live in HBM.

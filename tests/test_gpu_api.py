@@ -397,3 +397,48 @@ def test_enhance_progress_is_real_and_ordered(be):
     sess = next(iter(runtime._cache.values())).session
     assert sess.progress() == T
     runtime.clear_cache()
+
+
+# ----- host-pointer batch calls: pipelined over time slices inside the library ---------------------------------------
+@pytest.mark.parametrize("tag", ["16k_nb2", "48k_nb1"])
+def test_host_calls_pipelined_over_time_slices_equal_the_plain_path(tag, be):
+    """the metric includes the H2D / D2H of the PCM -- the library pipelines them under the compute per time slice
+    (per-chunk STFT, per-chunk iSTFT + overlap-add on the download stream, pinned staging ring, copy threads).  Block form,
+    ragged block form and the row-pointer form against (a) the same call with the pipeline off, bit for bit, (b) the oracle -- for several chunk schedules incl. chunks shorter than the 5-frame output lag."""
+    import ctypes
+    g, meta = load_golden(tag)
+    sr, nb = meta["sample_rate"], meta["nb"]
+    hop = 160 if sr == 16000 else 480
+    blob = golden_blob(meta)
+    o = make_oracle(meta, blob)
+    B = 72
+    n = 37 * hop + 17
+    rng = np.random.default_rng(5)
+    wav = np.stack([synth_clip(n, sr, 900 + i) for i in range(B)])
+    lens = np.array([n] + [int(rng.integers(1, n + 1)) for _ in range(B - 3)] + [hop // 2, n], dtype=np.int32)
+    for chunk, attn in ((16, None), (8, 12.0), (11, None)):
+        m = be.HipModel(sr, nb, blob, 0)
+        m.set_chunk_frames(chunk)                                  # 72 x chunk rows > 512: every chunk takes the pipelined form
+        piped = m.enhance_batch(wav, attn)
+        rag = np.zeros_like(wav)
+        db = float("nan") if attn is None else attn
+        be._check(m._L.dpdf_enhance_batch_ragged(m._h, wav.ctypes.data, B, n, lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), db, rag.ctypes.data, 0))
+        rows = m.enhance_batch_ragged([wav[b, : lens[b]].copy() for b in range(B)], attn)
+        m.set_option("host_pipe", 0)
+        plain = m.enhance_batch(wav, attn)
+        rag0 = np.zeros_like(wav)
+        be._check(m._L.dpdf_enhance_batch_ragged(m._h, wav.ctypes.data, B, n, lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), db, rag0.ctypes.data, 0))
+        m.set_option("host_pipe", 1)
+        np.testing.assert_array_equal(piped, plain)            # (= the device-pointer path: bench.py asserts that on its line)
+        np.testing.assert_array_equal(rag, rag0)
+        for b in range(B):
+            np.testing.assert_array_equal(rows[b], rag[b, : lens[b]])
+            assert np.all(rag[b, lens[b]:] == 0.0)
+        for b in (0, 1, B - 2, B - 1):
+            assert rms(piped[b] - o.enhance(wav[b], attn)) < WAVE_TOL
+            assert rms(rows[b] - o.enhance(wav[b, : lens[b]], attn)) < WAVE_TOL
+        again = m.enhance_batch(wav, attn)                         # the staging ring is reused: same answer
+        np.testing.assert_array_equal(again, piped)
+        m.set_option("host_copy_threads", 1)
+        np.testing.assert_array_equal(m.enhance_batch(wav, attn), piped)
+        m.close()

@@ -49,6 +49,11 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["value_hbm_resident"] == d["value"]
     # the H2D/D2H-inclusive figure rides on the same line and can only be slower than the HBM-resident one
     assert 0 < d["value_incl_pcie"] <= d["value"] * 1.05 and d["pcie"]["finite_output"] is True
+    # ... measured through the library's own pipelined host-pointer call, bit-identical to the HBM-resident output; and the figure of
+    # the public Python API (list of numpy clips in, list out) rides on the same line
+    assert d["pcie"]["max_abs_diff_vs_hbm_resident_output"] == 0.0 and d["pcie"]["ms_per_step_unpipelined"] > 0
+    assert d["value_public_api"] > 0 and d["public_api"]["finite_output"] is True
+    assert d["public_api"]["max_abs_diff_vs_hbm_resident_output"] == 0.0
     # RCCL has executed on this box: one-rank process group (backend nccl) in a child process, the collectives of the N > 1 path
     st = d["rccl_selftest"]
     assert d["rccl_init_ok"] is True, st

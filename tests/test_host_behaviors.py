@@ -78,10 +78,10 @@ def test_enhance_stereo_and_batch(monkeypatch):
     with pytest.raises(ValueError, match="mono/stereo"):
         api.enhance(np.zeros((2, 3, 4), np.float32), 16000)
     clips = [np.zeros(800, np.float32), np.zeros(1600, np.float32), np.zeros(800, np.float32), np.zeros(0, np.float32)]
-    sess.calls.clear()
+    sess.calls.clear(); sess.ragged_calls.clear()
     outs = api.enhance_batch(clips, 16000)
     assert [o.shape[0] for o in outs] == [800, 1600, 800, 0]
-    assert sorted(c[0] for c in sess.calls) == [(1, 1600), (2, 800)]     # grouped by length
+    assert sorted(sess.ragged_calls) == [[800, 800], [1600]] and sess.calls == []     # grouped by length, one row-pointer call per group
 
 
 def _stream(monkeypatch, win=8, zero=True):
@@ -270,7 +270,7 @@ def test_enhance_dir_batches_files_by_rate_and_length(tmp_path, monkeypatch):
     outs = api.enhance_dir(src, dst, file_callback=lambda i, o: seen.append(i.name))
     assert [o.name for o in outs] == ["a_enhanced.wav", "b_enhanced.wav", "c_enhanced.wav", "d_enhanced.wav"]
     assert sorted(seen) == ["a.wav", "b.wav", "c.wav", "d.wav"]
-    assert sorted(shape for shape, _ in sess.calls) == [(1, 1600), (2, 3200)]       # a+c share one call
+    assert sorted(sess.ragged_calls) == [[1600], [3200, 3200]]                      # a+c share one call
     for k, n in lens.items():
         y, sr = api._read_audio(dst / f"{k}_enhanced.wav")
         assert sr == 16000 and y.shape == (n,)
@@ -311,8 +311,8 @@ def test_length_buckets_and_ragged_directory(tmp_path, monkeypatch):
     sess.ragged_calls.clear(); sess.calls.clear()
     got = api.enhance_batch([np.zeros(n, np.float32) + 0.01 * k for k, n in enumerate(lens)], 16000, devices=[0, 0])
     assert [len(g) for g in got] == lens
-    assert sorted(len(c) for c in sess.ragged_calls) == [2, 3]          # [4000, 3777, 3501] and [1700, 1601]
-    assert sorted(shape for shape, _ in sess.calls) == [(1, 1500), (2, 3200)]   # the equal-length shards of the two buckets
+    assert sorted(sorted(c) for c in sess.ragged_calls) == [[1500], [1601, 1700], [3200, 3200], [3501, 3777, 4000]]   # two shards per bucket
+    assert sess.calls == []
 
 
 def test_evalkit_si_snr_and_alignment():
@@ -652,3 +652,38 @@ def test_progress_counts_only_the_watched_threads_call(monkeypatch):
     with pytest.raises(RuntimeError, match="callback failed"):
         dpdfnet_amd.enhance(np.zeros(64, np.float32), 16000, progress_callback=cb)
     assert not started["t"].is_alive()
+
+
+def test_output_blocks_are_leased_and_recycled(monkeypatch):
+    """backend._HostBlockPool: the results of a batch call are views of one leased block; the block returns to the free list when
+    the LAST view dies (also when only one result was kept), and the next call of that size reuses it without touching the OS."""
+    import gc
+    from dpdfnet_amd import backend
+    pool = backend._HostBlockPool()
+    n = 1 << 19                                        # 2 MB: above the small-result cut
+    a = pool.take(n)
+    assert a.dtype == np.float32 and a.shape == (n,) and a.flags.writeable and a.flags.c_contiguous
+    addr = a.ctypes.data
+    rows = [a[i * 1000:(i + 1) * 1000] for i in range(4)]
+    rows[2][:] = 7.0
+    del a
+    gc.collect()
+    assert pool._free == []                            # views alive: still leased
+    keep = rows[2]
+    del rows
+    gc.collect()
+    assert pool._free == [] and float(keep.sum()) == 7000.0
+    del keep
+    gc.collect()
+    assert len(pool._free) == 1                        # the last view is gone: the block is back
+    b = pool.take(n - 100)                             # a slightly smaller request takes the same block
+    assert b.ctypes.data == addr and pool.reused == 1 and b.shape == (n - 100,)
+    c = pool.take(n)                                   # the first block is out: a new one
+    assert c.ctypes.data != addr
+    small = pool.take(1000)
+    assert small.base is None                          # small results are plain arrays
+    pool.limit_bytes = 0
+    assert pool.take(n).base is None                   # leasing off: plain arrays
+    del b, c
+    gc.collect()
+    assert pool._free == []                            # (limit 0: the returned blocks are dropped, nothing is kept)
