@@ -19,6 +19,7 @@ that share one device-resident stream set; hops that arrive within a short windo
 from __future__ import annotations
 
 import threading
+import time
 from pathlib import Path
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
@@ -205,6 +206,7 @@ class StreamPool:
         self._free: List[int] = list(range(self._n - 1, -1, -1))
         self._window = float(window_s)
         self._lock = threading.Lock()
+        self._arrived = threading.Condition(self._lock)      # followers tell the waiting leader that the queue has grown
         self._queue: List[_Request] = []
         self._leader_active = False
         self.device_calls = 0              # masked device calls issued so far (what the coalescing saves)
@@ -265,19 +267,29 @@ class StreamPool:
             for r in reqs:                    # every waiter must wake up
                 r.done.set()
 
-    def _run(self, slot: int, pcm: np.ndarray, k: int) -> np.ndarray:
-        """Called by a member from its own thread: queue k hops; the first caller of a round leads it."""
-        req = _Request(slot, pcm, k)
+    def _run_group(self, reqs: List[_Request]) -> None:
+        """Queue this thread's requests; the first caller of a round leads it: it waits -- at most the pool's window, and only
+        until every stream in use has a request queued -- for other threads' hops, then issues the device call(s) for everyone
+        queued.  Returns when all of `reqs` are done (their .out / .err set)."""
         with self._lock:
-            self._queue.append(req)
+            self._queue.extend(reqs)
             lead = not self._leader_active
             if lead:
                 self._leader_active = True
+            else:
+                self._arrived.notify()
         if lead:
             interrupted: Optional[BaseException] = None
             try:
                 if self._window > 0:
-                    req.done.wait(self._window)      # nobody sets it yet: a plain bounded wait for followers to queue up
+                    deadline = time.monotonic() + self._window
+                    with self._lock:
+                        # (a stream has at most one request per round: once as many are queued as slots are in use, nobody else can come)
+                        while len(self._queue) < self._n - len(self._free):
+                            left = deadline - time.monotonic()
+                            if left <= 0:
+                                break
+                            self._arrived.wait(left)
             except BaseException as exc:             # (KeyboardInterrupt in the wait ...)
                 interrupted = exc
             # whatever happened to this thread in the wait, the round is closed and RUN: the next caller leads again, and the
@@ -288,7 +300,13 @@ class StreamPool:
             self._execute(batch)                     # (wakes every request of the batch, also when it raises)
             if interrupted is not None:
                 raise interrupted
-        req.done.wait()
+        for r in reqs:
+            r.done.wait()
+
+    def _run(self, slot: int, pcm: np.ndarray, k: int) -> np.ndarray:
+        """Called by a member from its own thread: queue k hops; the first caller of a round leads it."""
+        req = _Request(slot, pcm, k)
+        self._run_group([req])
         if req.err is not None:
             raise req.err
         return req.out
@@ -310,7 +328,7 @@ class StreamPool:
             reqs.append(None if got is None else _Request(enh._slot, got[0], got[1]))
         live = [r for r in reqs if r is not None]
         if live:
-            self._execute(live)
+            self._run_group(live)        # coalesces with the process() / process_many() calls of other threads in the same window
         outs = []
         for (enh, _), r in zip(items, reqs):
             if r is None:

@@ -560,48 +560,33 @@ def test_pool_leader_interrupted_in_its_window_does_not_strand_the_round(monkeyp
     """The leader of a round is interrupted in its coalescing wait (KeyboardInterrupt): the round is closed and run all the same
     -- the follower queued behind it gets its result, the leader sees its interrupt, and the next caller leads a new round."""
     import threading
-    from dpdfnet_amd import stream as stream_mod
     WIN, HOP = 320, 160
-    pool = _pool(monkeypatch, 2, win=WIN, window_s=0.0)
-    a, b = pool.enhancer(), pool.enhancer()
+    pool = _pool(monkeypatch, 3, win=WIN, window_s=0.0)
+    a, b, c = pool.enhancer(), pool.enhancer(), pool.enhancer()          # three slots in use: two requests do not fire the round early
     x = (np.random.default_rng(2).standard_normal(WIN + HOP) * 0.3).astype(np.float32)
     a.process(x[:WIN], sample_rate=16000); b.process(x[:WIN], sample_rate=16000)
-    pool._window = 0.5
-    box = {"go": threading.Event(), "queued": threading.Event()}
+    pool._window = 5.0
+    box = {"go": threading.Event()}
+    real = pool._arrived
 
-    class LeaderRequest(stream_mod._Request):
-        """The leader's request: its bounded wait lets the follower queue up, then is interrupted."""
-        def __init__(self, slot, pcm, k):
-            super().__init__(slot, pcm, k)
-            ev = self.done
-
-            class Done:
-                def wait(self, timeout=None):
-                    if timeout is None:
-                        return ev.wait(5.0)
-                    box["go"].set(); box["queued"].wait(2.0)
-                    raise KeyboardInterrupt()
-                def set(self): ev.set()
-            self.done = Done()
+    class Cond:
+        """The leader's wait: lets the follower queue up (and notify), then is interrupted."""
+        def wait(self, timeout=None):
+            box["go"].set()
+            real.wait(2.0)
+            raise KeyboardInterrupt()
+        def notify(self):
+            real.notify()
+    pool._arrived = Cond()
 
     def leader():
-        got = a._stage(x[WIN:], 16000)
-        monkeypatch.setattr(stream_mod, "_Request", LeaderRequest)
         try:
-            pool._run(a._slot, got[0], got[1])
+            a.process(x[WIN:], sample_rate=16000)
         except KeyboardInterrupt:
             box["leader_interrupted"] = True
 
     def follower():
-        got = b._stage(x[WIN:], 16000)
-        req = stream_mod._Request.__mro__[1](b._slot, got[0], got[1]) if stream_mod._Request is LeaderRequest else None
-        assert req is not None
-        with pool._lock:                                   # queue behind the live leader, exactly as _run does for a follower
-            assert pool._leader_active
-            pool._queue.append(req)
-        box["queued"].set()
-        box["follower_ok"] = req.done.wait(5.0)
-        box["follower_out"] = req.out
+        box["follower_out"] = b.process(x[WIN:], sample_rate=16000)
 
     tl = threading.Thread(target=leader); tl.start()
     assert box["go"].wait(2.0)
@@ -609,11 +594,39 @@ def test_pool_leader_interrupted_in_its_window_does_not_strand_the_round(monkeyp
     tl.join(10.0); tf.join(10.0)
     assert not tl.is_alive() and not tf.is_alive()
     assert box.get("leader_interrupted") is True
-    assert box["follower_ok"] is True and box["follower_out"] is not None and box["follower_out"].shape == (HOP,)
-    assert pool._leader_active is False
-    monkeypatch.setattr(stream_mod, "_Request", LeaderRequest.__mro__[1])
+    assert box["follower_out"].shape == (HOP,)
+    assert pool._leader_active is False and pool._queue == []
+    pool._arrived = real
     pool._window = 0.0
     assert a.process(np.zeros(HOP, np.float32), sample_rate=16000).shape == (HOP,)    # a new round can be led
+
+
+def test_pool_round_fires_as_soon_as_every_stream_in_use_has_queued(monkeypatch):
+    """process_many() calls of several threads meet in one round (one device call), and the leader does not sit out its window
+    once every stream in use has a request queued."""
+    import threading, time
+    WIN, HOP = 320, 160
+    pool = _pool(monkeypatch, 8, win=WIN, window_s=0.0)
+    ms = [pool.enhancer() for _ in range(8)]
+    x = (np.random.default_rng(4).standard_normal((8, WIN + HOP)) * 0.3).astype(np.float32)
+    pool.process_many([(m, x[i, :WIN]) for i, m in enumerate(ms)], sample_rate=16000)
+    pool._window = 5.0                                   # a round that waited for its window would take 5 s
+    base = pool.device_calls
+    outs = {}
+    bar = threading.Barrier(4)
+
+    def feeder(t):
+        mine = [(ms[i], x[i, WIN:]) for i in range(t, 8, 4)]
+        bar.wait()
+        outs[t] = pool.process_many(mine, sample_rate=16000)
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=feeder, args=(t,)) for t in range(4)]
+    for th in ths: th.start()
+    for th in ths: th.join(20.0)
+    assert time.perf_counter() - t0 < 2.0                # fired on the eighth request, not on the window
+    assert pool.device_calls - base == 1                 # four threads, one device call
+    assert all(len(outs[t]) == 2 and outs[t][0].shape == (HOP,) for t in range(4))
 
 
 def test_progress_counts_only_the_watched_threads_call(monkeypatch):
