@@ -47,6 +47,7 @@
 #include "small_fused_mfma.h"
 #include "enc_seg.h"
 #include "dec_pyr.h"
+#include "dft960.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -426,6 +427,10 @@ struct dpdf_model {
     size_t window, stft_frag_s, istft_frag;
     int stft_groups_s, istft_groups, istft_K;
     DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state, stft_part;
+    size_t dft_f1 = 0, dft_f2 = 0, dft_iA = 0, dft_iB = 0;    // 48 kHz: operands of the two-stage 960-point DFT (dft960.h)
+    DevBuf dft_mid_f, dft_mid_i;       // its intermediates [frames][30][64] (analysis / synthesis: they may run on different streams)
+    long dbg_nspec = 0, dbg_nframes = 0;
+    int dft2 = 1;                      // 48 kHz big launches: STFT / iSTFT as two small matrix stages (0: one [960 x 962] GEMM; A/B)
     HostPipe hp;                       // pinned staging ring + copy streams of the host-pointer batch calls
     int host_pipe = 1;                 // host-pointer batch calls pipelined over time slices (0: one upload, compute, one download; A/B)
     int host_prefault = 1;             // pipelined host calls: a helper thread populates the caller's output rows while the first chunk computes (0: A/B)
@@ -1851,6 +1856,42 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
         m->istft_frag = A.add(frag);
     }
 
+    if (d.win == 960) {
+        // ---- two-stage 960-point DFT (dft960.h): 960 = 32 x 30, n = 30 n1 + n2, k = k1 + 32 k2 ----
+        auto ang = [](long num, int den) { return 2.0 * M_PI * (double)(num % den) / den; };
+        m->dft_f1 = A.add(pack_frag(32, 64, 4, [&](int n1, int n) -> float {
+            const int k1 = n >> 1; const double a = ang((long)n1 * k1, 32);
+            return (n & 1) ? (float)(-std::sin(a)) : (float)std::cos(a);
+        }));
+        std::vector<float> f2, fa;
+        for (int k1 = 0; k1 < 32; ++k1) {
+            auto f = pack_frag(64, 32, 2, [&](int kk, int n) -> float {
+                if (kk >= 60) return 0.f;
+                const int n2 = kk >> 1, cc = kk & 1, k2 = n >> 1, cp = n & 1;
+                const double th = ang((long)n2 * (k1 + 32 * k2), 960);
+                if (cc == cp) return (float)std::cos(th);
+                return cc ? (float)std::sin(th) : (float)(-std::sin(th));
+            });
+            f2.insert(f2.end(), f.begin(), f.end());
+            auto g = pack_frag(64, 64, 4, [&](int kk, int n) -> float {
+                if (kk >= 60 || n >= 60) return 0.f;
+                const int k2 = kk >> 1, cc = kk & 1, n2 = n >> 1, cp = n & 1;
+                const int k = k1 + 32 * k2; const bool mir = k > 480; const int ks = mir ? 960 - k : k;
+                if (cc == 1 && (ks == 0 || ks == 480)) return 0.f;          // irfft ignores Im of DC / Nyquist
+                const double sg = mir ? -1.0 : 1.0, th = ang((long)n2 * k, 960);
+                if (cc == 0) return cp == 0 ? (float)std::cos(th) : (float)std::sin(th);
+                return cp == 0 ? (float)(-sg * std::sin(th)) : (float)(sg * std::cos(th));
+            });
+            fa.insert(fa.end(), g.begin(), g.end());
+        }
+        m->dft_f2 = A.add(f2);
+        m->dft_iA = A.add(fa);
+        m->dft_iB = A.add(pack_frag(64, 32, 2, [&](int kk, int n1) -> float {
+            const int k1 = kk >> 1; const double a = ang((long)n1 * k1, 32);
+            return (float)(((kk & 1) ? -std::sin(a) : std::cos(a)) / 960.0);
+        }));
+    }
+
     // ---- streams: lane 0 now; the second lane and the sub-stage pipeline's streams only when first used (init_lane):
     // HIP multiplexes streams onto a handful of hardware queues, and streams that merely exist still take part in that
     // mapping -- with 14 streams per handle the four active ones of a second handle ended up sharing queues (one
@@ -1904,7 +1945,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
         for (int k = 0; k < 2; ++k) if (L.gru_sbuf[k]) (void)hipFree(L.gru_sbuf[k]);
         for (int k = 0; k < 5; ++k) if (L.arrive[k]) (void)hipFree(L.arrive[k]);
     }
-    DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state, &m->stft_part};
+    DevBuf* bufs[] = {&m->io_spec, &m->io_spec_e, &m->io_state, &m->io_wav, &m->io_out, &m->frames, &m->raw_spec, &m->enh_spec, &m->batch_state, &m->stft_part, &m->dft_mid_f, &m->dft_mid_i};
     for (DevBuf* b : bufs) b->release();
     if (m->consts) (void)hipFree(m->consts);
     if (m->iconsts) (void)hipFree(m->iconsts);
@@ -2023,6 +2064,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "snapshot") m->snapshot = value != 0;
     else if (n == "host_pipe") m->host_pipe = value != 0;
     else if (n == "host_prefault") m->host_prefault = value != 0;
+    else if (n == "dft2") m->dft2 = value != 0;
     else if (n == "host_copy_threads") m->host_copy_threads = value < 1 ? 1 : value;
     else if (n == "single_chunk_inline") m->single_chunk_inline = value != 0;
     else if (n == "fuse_dec") m->fuse_dec = value != 0;
@@ -2277,6 +2319,13 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
     }
     if ((rc = m->raw_spec.ensure(nspec)) || (rc = m->enh_spec.ensure(nspec)) ||
         (rc = m->batch_state.ensure((size_t)B * d.state_size)) || (rc = m->frames.ensure((size_t)B * T * d.win))) return rc;
+    // 48 kHz, big launches: the 960-point DFT as two small matrix stages (dft960.h)
+    m->dbg_nspec = (long)nspec; m->dbg_nframes = (long)B * T * d.win;
+    const bool dft2 = d.win == 960 && m->dft2 && (long)B * T > SMALL_M_ROWS;
+    if (dft2) {
+        const size_t rows = piped ? (size_t)B * *std::max_element(sizes.begin(), sizes.end()) : (size_t)B * T;
+        if ((rc = m->dft_mid_f.ensure(rows * 1920)) || (rc = m->dft_mid_i.ensure(rows * 1920))) return rc;
+    }
     HostPipe& hp = m->hp;
     constexpr int R = HostPipe::R;
     static const bool trace = getenv("DPDF_HOST_PIPE_TRACE") != nullptr;      // stderr: where the host thread of a pipelined call spends its time
@@ -2349,6 +2398,11 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
             // A1 for the frames of this chunk, behind its slice's upload
             HIP_TRY(hipStreamWaitEvent(m->stream, hp.ev_up[k % R], 0));
             const RowSeg seg{Tc, T, t0};
+            if (dft2) {
+                Dft960Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, nullptr, m->raw_spec.p, m->dft_mid_f.p, m->C(m->dft_f1), m->C(m->dft_f2), seg, B * Tc};
+                launch_dft960_forward(m->stream, da);
+                return DPDF_OK;
+            }
             StftSegA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window), d_lens, seg};
             SegStore<2> ep{m->raw_spec.p, (size_t)2 * d.F, 32, 32, 2 * d.F, seg};
             launch_gemm_rows_wn<2, 64>(m->stream, ap, m->C(m->stft_frag_s), ep, B * Tc, d.win, m->stft_groups_s / 4);
@@ -2361,10 +2415,15 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
             HIP_TRY(hipEventRecord(hp.ev_s2[slot], s2));
             HIP_TRY(hipStreamWaitEvent(hp.s_down, hp.ev_s2[slot], 0));
             const RowSeg seg{Tc, T, t0};
+            if (dft2) {
+                Dft960Args da{nullptr, N, T, d.hop, m->C(m->window), nullptr, m->frames.p, m->enh_spec.p, m->dft_mid_i.p, m->C(m->dft_iB), m->C(m->dft_iA), seg, B * Tc};
+                launch_dft960_inverse(hp.s_down, da);
+            } else {
             PlainSegA<48> ap{m->enh_spec.p, (size_t)2 * d.F, 2 * d.F, seg};
             WindowSegStore<5> ep{m->frames.p, d.win, m->C(m->window), seg};
             if (m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(hp.s_down, ap, m->C(m->istft_frag), ep, B * Tc, m->istft_K, m->istft_groups / 4);
             else launch_gemm_rows<5, 48, false>(hp.s_down, ap, m->C(m->istft_frag), ep, B * Tc, m->istft_K, m->istft_groups);
+            }
             if (w > 0) {
                 OlaArgs oa{m->frames.p, m->C(m->window), d_out, B, T, N, d.win, d.hop, d_lens, q.v0, w};
                 hipLaunchKernelGGL(ola_kernel, dim3((unsigned)(((size_t)B * w + 255) / 256)), dim3(256), 0, hp.s_down, oa);
@@ -2382,6 +2441,9 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         StftA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window), 0, d_lens};
         if (B * T <= SMALL_M_ROWS) {
             if ((rc = stft_small(m, ap, m->raw_spec.p, B * T))) return rc;
+        } else if (dft2) {
+            Dft960Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, nullptr, m->raw_spec.p, m->dft_mid_f.p, m->C(m->dft_f1), m->C(m->dft_f2), RowSeg{T, T, 0}, B * T};
+            launch_dft960_forward(m->stream, da);
         } else {
             BiasActStore<2> ep{m->raw_spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
             ep.ncol_total = 2 * d.F;
@@ -2421,6 +2483,10 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         ProfScope ps(m, "istft");
         PlainA<48> ap{m->enh_spec.p, (size_t)2 * d.F, 0, 2 * d.F};
         WindowStore<5> ep{m->frames.p, d.win, m->C(m->window)};
+        if (dft2) {
+            Dft960Args da{nullptr, N, T, d.hop, m->C(m->window), nullptr, m->frames.p, m->enh_spec.p, m->dft_mid_i.p, m->C(m->dft_iB), m->C(m->dft_iA), RowSeg{T, T, 0}, B * T};
+            launch_dft960_inverse(m->stream, da);
+        } else
         if (B * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups / 4);
         else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups);
         OlaArgs oa{m->frames.p, m->C(m->window), d_out, B, T, N, d.win, d.hop, d_lens};
@@ -2830,6 +2896,8 @@ extern "C" long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, l
     else if (s == "m") { src = w.m.p; n = BT * d.E; }
     else if (s == "coefs") { src = w.coefs.p; n = B * (Tc + 2) * d.D * 10; }
     else if (s == "xm") { src = w.xm.p; n = B * (Tc + 4) * d.F * 2; }
+    else if (s == "raw_spec") { src = m->raw_spec.p; n = m->dbg_nspec; }        // the last offline call's analysis spectra [B][T][F][2]
+    else if (s == "frames") { src = m->frames.p; n = m->dbg_nframes; }          // ... and windowed synthesis frames [B][T][win]
     if (!src) return -1;
     if (host && cap >= n) {
         if (hipStreamSynchronize(m->stream) != hipSuccess) return -1;

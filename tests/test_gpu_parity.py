@@ -492,3 +492,54 @@ def test_every_gru256_scan_form_agrees(be):
     r0, s0 = o.run_frames(spec[7])
     assert np.abs(ref[7] - r0).max() < STAGE_REL_TOL * scale and np.abs(st_ref[7] - s0).max() < 2e-4
     m.close()
+
+
+def test_48k_two_stage_dft_equals_the_one_gemm_form_and_the_reference(be):
+    """dft960.h: the 960-point analysis / synthesis transforms of big 48 kHz launches as two small matrix stages (960 = 32 x 30)
+    against the one-GEMM form of the same engine (spectra, synthesis frames, waveforms), the reference's own STFT of the golden
+    clip (`spec_head` / `spec_tail`, torch.stft of the reference modules) and the oracle -- plain and pipelined host paths,
+    ragged lengths, a frame count that is no multiple of the 8- / 16-frame tiles."""
+    import ctypes
+    g, meta = load_golden("48k_nb1")
+    blob = golden_blob(meta)
+    sr, nb = meta["sample_rate"], meta["nb"]
+    n = len(g["wav"])
+    B = 19
+    wav = np.stack([g["wav"]] + [synth_clip(n, sr, 700 + i) for i in range(B - 1)])
+    T = 1 + (n + 960) // 480
+    o = make_oracle(meta, blob)
+    res = {}
+    for dft2 in (1, 0):
+        m = be.HipModel(sr, nb, blob, 0)
+        m.set_option("dft2", dft2)
+        for pipe in (0, 1):
+            m.set_option("host_pipe", pipe)
+            y = m.enhance_batch(wav, None)
+            spec = m.debug_fetch("raw_spec").reshape(B, T, 481, 2)
+            frames = m.debug_fetch("frames").reshape(B, T, 960)
+            res[(dft2, pipe)] = (y, spec, frames)
+        m.close()
+    y_ref, spec_ref, frames_ref = res[(0, 0)]
+    scale = float(np.abs(spec_ref).max())
+    for key in ((1, 0), (1, 1)):
+        y, spec, frames = res[key]
+        assert np.abs(spec - spec_ref).max() < 3e-6 * scale, (key, np.abs(spec - spec_ref).max() / scale)
+        assert np.abs(frames - frames_ref).max() < 3e-6 * max(1.0, float(np.abs(frames_ref).max())), key
+        assert rms(y - y_ref) < 5e-7 and np.abs(y - y_ref).max() < 6e-6, (key, rms(y - y_ref), np.abs(y - y_ref).max())
+        # the reference's own analysis of the golden clip (unnormalised STFT, first 8 and last 4 frames)
+        assert np.abs(spec[0, :8] - g["spec_head"]).max() < 3e-6 * scale and np.abs(spec[0, -4:] - g["spec_tail"]).max() < 3e-6 * scale
+        assert rms(y[0] - g["enhanced"]) < 2e-6
+        for b in (1, B - 1):
+            assert rms(y[b] - o.enhance(wav[b])) < 2e-6
+    np.testing.assert_array_equal(res[(1, 0)][0], res[(1, 1)][0])       # plain and pipelined host paths: bit-identical
+    # ragged: per-clip reflection point / frame count inside the two-stage analysis
+    lens = np.array([n, n - 1, 7 * 480 + 3, 2 * 480, 100, 1] + [n - 13 * i for i in range(B - 6)], dtype=np.int32)
+    m = be.HipModel(sr, nb, blob, 0)
+    rows = m.enhance_batch_ragged([wav[b, : lens[b]].copy() for b in range(B)])
+    m.set_option("dft2", 0)
+    rows0 = m.enhance_batch_ragged([wav[b, : lens[b]].copy() for b in range(B)])
+    m.close()
+    for b in range(B):
+        assert np.abs(rows[b] - rows0[b]).max() < 6e-6, (b, lens[b])
+    for b in (2, 4):
+        assert rms(rows[b] - o.enhance(wav[b, : lens[b]])) < 2e-6
