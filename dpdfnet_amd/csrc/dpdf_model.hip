@@ -47,7 +47,7 @@
 #include "small_fused_mfma.h"
 #include "enc_seg.h"
 #include "dec_pyr.h"
-#include "dft960.h"
+#include "dft2stage.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -427,12 +427,13 @@ struct dpdf_model {
     size_t window, stft_frag_s, istft_frag;
     int stft_groups_s, istft_groups, istft_K;
     DevBuf io_spec, io_spec_e, io_state, io_wav, io_out, frames, raw_spec, enh_spec, batch_state, stft_part;
-    size_t dft_f1 = 0, dft_f2 = 0, dft_iA = 0, dft_iB = 0;    // 48 kHz: operands of the two-stage 960-point DFT (dft960.h)
+    size_t dft_f1 = 0, dft_f2 = 0, dft_iA = 0, dft_iB = 0;    // operands of the two-stage DFT (dft2stage.h)
     DevBuf dft_mid_f, dft_mid_i;       // its intermediates [frames][30][64] (analysis / synthesis: they may run on different streams)
     long dbg_nspec = 0, dbg_nframes = 0;
-    int dft2 = 1;                      // 48 kHz big launches: STFT / iSTFT as two small matrix stages (0: one [960 x 962] GEMM; A/B)
+    int dft2 = 1;                      // big launches: STFT / iSTFT as two small matrix stages (0: one [win x 2F] GEMM; A/B)
     HostPipe hp;                       // pinned staging ring + copy streams of the host-pointer batch calls
     int host_pipe = 1;                 // host-pointer batch calls pipelined over time slices (0: one upload, compute, one download; A/B)
+    int chunk_io = 0;                  // device-pointer batch calls of several chunks: STFT / iSTFT + overlap-add per chunk beside the frame function (0: two whole-batch launches; A/B)
     int host_prefault = 1;             // pipelined host calls: a helper thread populates the caller's output rows while the first chunk computes (0: A/B)
     int host_copy_threads = 4;         // threads (incl. the caller's) that move rows between the caller's memory and pinned staging
     int stft_ksplit = 7;               // few frames: bit 0 STFT split five ways over K (stft_small), bit 1 streaming iSTFT split seven ways (summed by the overlap-add kernel)
@@ -1283,7 +1284,8 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         // df_conv1 (+ the DF decoder's pathway conv, + df_conv0 itself): one time-walking pass when clips x 3 workgroups
         // fill the chip, else the time-parallel gemm_rows forms (df_ring.h)
         if (df_seg) {       // latency regime: df_conv0 + df_conv1 + the first block's input projection (+ pathway conv) as one launch (enc_seg.h)
-            hipLaunchKernelGGL(df_enc_seg_kernel, dim3(d.Fd / 16, BT), dim3(256), 0, sA, dfa);
+            if (dfa.p) hipLaunchKernelGGL(HIP_KERNEL_NAME(df_enc_seg_kernel<true>), dim3(d.Fd / 16, BT), dim3(256), 0, sA, dfa);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(df_enc_seg_kernel<false>), dim3(d.Fd / 16, BT), dim3(256), 0, sA, dfa);
             wdf.intra_gi_ready = df_gi;
         } else {
             const bool conv0_in_ring = x.have_pconv && m->df_ring >= 2;
@@ -1856,8 +1858,10 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
         m->istft_frag = A.add(frag);
     }
 
-    if (d.win == 960) {
-        // ---- two-stage 960-point DFT (dft960.h): 960 = 32 x 30, n = 30 n1 + n2, k = k1 + 32 k2 ----
+    if (d.win == 960 || d.win == 320) {
+        // ---- two-stage DFT (dft2stage.h): N = 32 x N2, n = N2 n1 + n2, k = k1 + 32 k2 ----
+        const int Nw = d.win, N2 = Nw / 32, NK2 = N2 / 2 + 1;
+        const int KC = (2 * N2 + 15) / 16, NT2 = (2 * NK2 + 15) / 16, NTA = (2 * N2 + 15) / 16;
         auto ang = [](long num, int den) { return 2.0 * M_PI * (double)(num % den) / den; };
         m->dft_f1 = A.add(pack_frag(32, 64, 4, [&](int n1, int n) -> float {
             const int k1 = n >> 1; const double a = ang((long)n1 * k1, 32);
@@ -1865,20 +1869,20 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
         }));
         std::vector<float> f2, fa;
         for (int k1 = 0; k1 < 32; ++k1) {
-            auto f = pack_frag(64, 32, 2, [&](int kk, int n) -> float {
-                if (kk >= 60) return 0.f;
+            auto f = pack_frag(16 * KC, 16 * NT2, NT2, [&](int kk, int n) -> float {
+                if (kk >= 2 * N2 || n >= 2 * NK2) return 0.f;
                 const int n2 = kk >> 1, cc = kk & 1, k2 = n >> 1, cp = n & 1;
-                const double th = ang((long)n2 * (k1 + 32 * k2), 960);
+                const double th = ang((long)n2 * (k1 + 32 * k2), Nw);
                 if (cc == cp) return (float)std::cos(th);
                 return cc ? (float)std::sin(th) : (float)(-std::sin(th));
             });
             f2.insert(f2.end(), f.begin(), f.end());
-            auto g = pack_frag(64, 64, 4, [&](int kk, int n) -> float {
-                if (kk >= 60 || n >= 60) return 0.f;
+            auto g = pack_frag(16 * KC, 16 * NTA, NTA, [&](int kk, int n) -> float {
+                if (kk >= 2 * N2 || n >= 2 * N2) return 0.f;
                 const int k2 = kk >> 1, cc = kk & 1, n2 = n >> 1, cp = n & 1;
-                const int k = k1 + 32 * k2; const bool mir = k > 480; const int ks = mir ? 960 - k : k;
-                if (cc == 1 && (ks == 0 || ks == 480)) return 0.f;          // irfft ignores Im of DC / Nyquist
-                const double sg = mir ? -1.0 : 1.0, th = ang((long)n2 * k, 960);
+                const int k = k1 + 32 * k2; const bool mir = k > Nw / 2; const int ks = mir ? Nw - k : k;
+                if (cc == 1 && (ks == 0 || ks == Nw / 2)) return 0.f;       // irfft ignores Im of DC / Nyquist
+                const double sg = mir ? -1.0 : 1.0, th = ang((long)n2 * k, Nw);
                 if (cc == 0) return cp == 0 ? (float)std::cos(th) : (float)std::sin(th);
                 return cp == 0 ? (float)(-sg * std::sin(th)) : (float)(sg * std::cos(th));
             });
@@ -1888,7 +1892,7 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
         m->dft_iA = A.add(fa);
         m->dft_iB = A.add(pack_frag(64, 32, 2, [&](int kk, int n1) -> float {
             const int k1 = kk >> 1; const double a = ang((long)n1 * k1, 32);
-            return (float)(((kk & 1) ? -std::sin(a) : std::cos(a)) / 960.0);
+            return (float)(((kk & 1) ? -std::sin(a) : std::cos(a)) / (double)Nw);
         }));
     }
 
@@ -2065,6 +2069,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "host_pipe") m->host_pipe = value != 0;
     else if (n == "host_prefault") m->host_prefault = value != 0;
     else if (n == "dft2") m->dft2 = value != 0;
+    else if (n == "chunk_io") m->chunk_io = value != 0;
     else if (n == "host_copy_threads") m->host_copy_threads = value < 1 ? 1 : value;
     else if (n == "single_chunk_inline") m->single_chunk_inline = value != 0;
     else if (n == "fuse_dec") m->fuse_dec = value != 0;
@@ -2284,7 +2289,10 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
     // scattered to the caller's rows, while the GPU computes chunk k; the STFT and the iSTFT + overlap-add run per chunk
     // (the synthesis on the download stream).  Only the first slice's upload and the last one's download are exposed.
     const std::vector<int> sizes = chunk_schedule(m, B, T);
-    bool piped = host && m->host_pipe && !m->prof_on;
+    // Device-pointer calls take the same per-chunk form without the copies ("chunk_io"): only the first chunk's STFT precedes the
+    // frame function and only the last chunk's iSTFT + overlap-add follows it; the rest runs beside the chunks (the synthesis on
+    // its own stream behind each chunk's stage 2) instead of as two whole-batch launches on the critical stream.
+    bool piped = (host ? m->host_pipe : (m->chunk_io && sizes.size() > 1)) && !m->prof_on;
     for (int Tc : sizes) piped = piped && (long)B * Tc > SMALL_M_ROWS;
     struct Slice { int t0, Tc, u0, u1, v0, v1; };
     std::vector<Slice> sl;
@@ -2317,14 +2325,18 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
             if (rows) HIP_TRY(hipStreamSynchronize(m->stream));       // flat_in is pageable: the copy has left it
         }
     }
+    if (piped && !host && (rc = ensure_host_pipe(m, 0, 0))) return rc;        // (its download stream and events; no staging)
     if ((rc = m->raw_spec.ensure(nspec)) || (rc = m->enh_spec.ensure(nspec)) ||
         (rc = m->batch_state.ensure((size_t)B * d.state_size)) || (rc = m->frames.ensure((size_t)B * T * d.win))) return rc;
-    // 48 kHz, big launches: the 960-point DFT as two small matrix stages (dft960.h)
+    // big launches: the analysis / synthesis DFT as two small matrix stages (dft2stage.h)
     m->dbg_nspec = (long)nspec; m->dbg_nframes = (long)B * T * d.win;
-    const bool dft2 = d.win == 960 && m->dft2 && (long)B * T > SMALL_M_ROWS;
+    const bool dft2 = (d.win == 960 || d.win == 320) && m->dft2 && (long)B * T > SMALL_M_ROWS;
+    // (the synthesis side only at 960: at 320 its two launches measure 0.96 ms against 0.88 ms for the one GEMM + overlap-add)
+    const bool dft2_inv = dft2 && d.win == 960;
     if (dft2) {
         const size_t rows = piped ? (size_t)B * *std::max_element(sizes.begin(), sizes.end()) : (size_t)B * T;
-        if ((rc = m->dft_mid_f.ensure(rows * 1920)) || (rc = m->dft_mid_i.ensure(rows * 1920))) return rc;
+        const size_t per_frame = (size_t)(d.win / 32) * 64;
+        if ((rc = m->dft_mid_f.ensure(rows * per_frame)) || (rc = m->dft_mid_i.ensure(rows * per_frame))) return rc;
     }
     HostPipe& hp = m->hp;
     constexpr int R = HostPipe::R;
@@ -2380,7 +2392,7 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
     // thread populates the rows (madvise MADV_POPULATE_WRITE: contents untouched, so no ordering against the scatter is needed)
     // while the GPU works on the first chunk.  Rows that are populated already cost a page-table walk.
     struct Prefault { std::thread th; ~Prefault() { if (th.joinable()) th.join(); } } prefault;
-    if (piped && m->host_prefault && nw * sizeof(float) >= ((size_t)8 << 20)) {
+    if (piped && host && m->host_prefault && nw * sizeof(float) >= ((size_t)8 << 20)) {
         prefault.th = std::thread([&hr, B, N] {
             const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
             for (int b = 0; b < B; ++b) {
@@ -2391,16 +2403,22 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         });
     }
     if (piped) {
-        if ((rc = stage_up(0))) return rc;
-        t_first_up = now() - t_call0;
-        if (sl.size() > 1 && (rc = stage_up(1))) return rc;
+        if (host) {
+            if ((rc = stage_up(0))) return rc;
+            t_first_up = now() - t_call0;
+            if (sl.size() > 1 && (rc = stage_up(1))) return rc;
+        } else {
+            // the download stream starts behind whatever the caller queued in front of this call
+            HIP_TRY(hipEventRecord(hp.ev_up[0], m->stream));
+            HIP_TRY(hipStreamWaitEvent(hp.s_down, hp.ev_up[0], 0));
+        }
         hooks.pre = [&](int k, int t0, int Tc) -> int {
             // A1 for the frames of this chunk, behind its slice's upload
-            HIP_TRY(hipStreamWaitEvent(m->stream, hp.ev_up[k % R], 0));
+            if (host) HIP_TRY(hipStreamWaitEvent(m->stream, hp.ev_up[k % R], 0));
             const RowSeg seg{Tc, T, t0};
             if (dft2) {
-                Dft960Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, nullptr, m->raw_spec.p, m->dft_mid_f.p, m->C(m->dft_f1), m->C(m->dft_f2), seg, B * Tc};
-                launch_dft960_forward(m->stream, da);
+                Dft2Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, nullptr, m->raw_spec.p, m->dft_mid_f.p, m->C(m->dft_f1), m->C(m->dft_f2), seg, B * Tc};
+                launch_dft2_forward(m->stream, da, d.win);
                 return DPDF_OK;
             }
             StftSegA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window), d_lens, seg};
@@ -2415,9 +2433,9 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
             HIP_TRY(hipEventRecord(hp.ev_s2[slot], s2));
             HIP_TRY(hipStreamWaitEvent(hp.s_down, hp.ev_s2[slot], 0));
             const RowSeg seg{Tc, T, t0};
-            if (dft2) {
-                Dft960Args da{nullptr, N, T, d.hop, m->C(m->window), nullptr, m->frames.p, m->enh_spec.p, m->dft_mid_i.p, m->C(m->dft_iB), m->C(m->dft_iA), seg, B * Tc};
-                launch_dft960_inverse(hp.s_down, da);
+            if (dft2_inv) {
+                Dft2Args da{nullptr, N, T, d.hop, m->C(m->window), nullptr, m->frames.p, m->enh_spec.p, m->dft_mid_i.p, m->C(m->dft_iB), m->C(m->dft_iA), seg, B * Tc};
+                launch_dft2_inverse(hp.s_down, da, d.win);
             } else {
             PlainSegA<48> ap{m->enh_spec.p, (size_t)2 * d.F, 2 * d.F, seg};
             WindowSegStore<5> ep{m->frames.p, d.win, m->C(m->window), seg};
@@ -2427,10 +2445,11 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
             if (w > 0) {
                 OlaArgs oa{m->frames.p, m->C(m->window), d_out, B, T, N, d.win, d.hop, d_lens, q.v0, w};
                 hipLaunchKernelGGL(ola_kernel, dim3((unsigned)(((size_t)B * w + 255) / 256)), dim3(256), 0, hp.s_down, oa);
-                HIP_TRY(hipMemcpy2DAsync(hp.pin_out[slot], (size_t)w * sizeof(float), d_out + q.v0, (size_t)N * sizeof(float), (size_t)w * sizeof(float), B,
-                                         hipMemcpyDeviceToHost, hp.s_down));
+                if (host) HIP_TRY(hipMemcpy2DAsync(hp.pin_out[slot], (size_t)w * sizeof(float), d_out + q.v0, (size_t)N * sizeof(float), (size_t)w * sizeof(float), B,
+                                                   hipMemcpyDeviceToHost, hp.s_down));
             }
             HIP_TRY(hipEventRecord(hp.ev_down[slot], hp.s_down));
+            if (!host) return DPDF_OK;
             if (k + 2 < (int)sl.size() && (rc = stage_up(k + 2))) return rc;
             if (k >= 2 && (rc = drain(k - 2))) return rc;
             return DPDF_OK;
@@ -2442,8 +2461,8 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         if (B * T <= SMALL_M_ROWS) {
             if ((rc = stft_small(m, ap, m->raw_spec.p, B * T))) return rc;
         } else if (dft2) {
-            Dft960Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, nullptr, m->raw_spec.p, m->dft_mid_f.p, m->C(m->dft_f1), m->C(m->dft_f2), RowSeg{T, T, 0}, B * T};
-            launch_dft960_forward(m->stream, da);
+            Dft2Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, nullptr, m->raw_spec.p, m->dft_mid_f.p, m->C(m->dft_f1), m->C(m->dft_f2), RowSeg{T, T, 0}, B * T};
+            launch_dft2_forward(m->stream, da, d.win);
         } else {
             BiasActStore<2> ep{m->raw_spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};
             ep.ncol_total = 2 * d.F;
@@ -2468,6 +2487,12 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         if (piped) { (void)hipStreamSynchronize(hp.s_up); (void)hipStreamSynchronize(hp.s_down); (void)hipStreamSynchronize(m->stream); }
         return rc;
     }
+    if (piped && !host) {
+        // the output is complete behind the synthesis of the last chunk: order the caller's stream behind it
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamWaitEvent(m->stream, hp.ev_down[((int)sl.size() - 1) % R], 0));
+        return DPDF_OK;
+    }
     if (piped) {
         HIP_TRY(hipGetLastError());
         const int n = (int)sl.size();
@@ -2483,9 +2508,9 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         ProfScope ps(m, "istft");
         PlainA<48> ap{m->enh_spec.p, (size_t)2 * d.F, 0, 2 * d.F};
         WindowStore<5> ep{m->frames.p, d.win, m->C(m->window)};
-        if (dft2) {
-            Dft960Args da{nullptr, N, T, d.hop, m->C(m->window), nullptr, m->frames.p, m->enh_spec.p, m->dft_mid_i.p, m->C(m->dft_iB), m->C(m->dft_iA), RowSeg{T, T, 0}, B * T};
-            launch_dft960_inverse(m->stream, da);
+        if (dft2_inv) {
+            Dft2Args da{nullptr, N, T, d.hop, m->C(m->window), nullptr, m->frames.p, m->enh_spec.p, m->dft_mid_i.p, m->C(m->dft_iB), m->C(m->dft_iA), RowSeg{T, T, 0}, B * T};
+            launch_dft2_inverse(m->stream, da, d.win);
         } else
         if (B * T > SMALL_M_ROWS && m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups / 4);
         else launch_gemm_rows<5, 48, false>(m->stream, ap, m->C(m->istft_frag), ep, B * T, m->istft_K, m->istft_groups);

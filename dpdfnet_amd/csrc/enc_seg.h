@@ -195,6 +195,8 @@ struct DfEncArgs {
     // order, so the same p): one launch less in stage 2, where df_out's epilogue then only ADDS p
     float* p; const float* cpfrag; const float* cpbias;     // p [B*Tc][D][10]; fragments [chunk 20][kb 4][lane]; bias [10]
 };
+// PCONV: the pathway conv is part of the launch (a.p != nullptr).
+template <bool PCONV>
 __global__ __launch_bounds__(256) void df_enc_seg_kernel(DfEncArgs a) {
     constexpr int R1 = 16, N0 = 2 * R1 + 1;
     __shared__ __attribute__((aligned(16))) float C0[N0][68];       // row r = band 2 a1 - 1 + r
@@ -205,8 +207,8 @@ __global__ __launch_bounds__(256) void df_enc_seg_kernel(DfEncArgs a) {
     const int a1 = blockIdx.x * R1, lo0 = 2 * a1 - 1;
     // pathway conv operands, up front: wave (mt = row tile, kh = K half); chunk cg = 4 kt + cc <-> frame t - 4 + kt, channels 16 cc ..
     const int mt = w & 1, kh = w >> 1;
-    float cp[40]; float4 hist[10];
-    if (a.p) {
+    float cp[PCONV ? 40 : 1]; float4 hist[PCONV ? 10 : 1];
+    if (PCONV) {
 #pragma unroll
         for (int i = 0; i < 40; ++i) cp[i] = a.cpfrag[(size_t)(40 * kh + i) * 64 + lane];
         const int band = 2 * a1 + mt * 16 + cl;
@@ -257,12 +259,15 @@ __global__ __launch_bounds__(256) void df_enc_seg_kernel(DfEncArgs a) {
     }
     __syncthreads();
     // ---- pathway conv over frames t - 4 .. t of the owned bands (the newest frame from C0)
-    if (a.p) {
+    if (PCONV) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ci = 0; ci < 10; ++ci) {
             const int cg = 10 * kh + ci, kt = cg >> 2, cc = cg & 3;
-            const float4 a4 = kt < 4 ? hist[ci] : *(const float4*)&C0[1 + mt * 16 + cl][cc * 16 + 4 * q];
+            // (two assignments, not `cond ? hist[ci] : *(lds)`: a conditional between two lvalues selects their ADDRESSES, a private
+            // one and an LDS one, and that kept all of `hist` in scratch memory: 176 bytes per lane)
+            float4 a4 = hist[ci];
+            if (kt >= 4) a4 = *(const float4*)&C0[1 + mt * 16 + cl][cc * 16 + 4 * q];
             acc = mfma16(a4.x, cp[ci * 4 + 0], acc);
             acc = mfma16(a4.y, cp[ci * 4 + 1], acc);
             acc = mfma16(a4.z, cp[ci * 4 + 2], acc);

@@ -494,19 +494,21 @@ def test_every_gru256_scan_form_agrees(be):
     m.close()
 
 
-def test_48k_two_stage_dft_equals_the_one_gemm_form_and_the_reference(be):
-    """dft960.h: the 960-point analysis / synthesis transforms of big 48 kHz launches as two small matrix stages (960 = 32 x 30)
+@pytest.mark.parametrize("tag", ["48k_nb1", "16k_nb2"])
+def test_two_stage_dft_equals_the_one_gemm_form_and_the_reference(tag, be):
+    """dft2stage.h: the analysis / synthesis transforms of big launches as two small matrix stages (960 = 32 x 30, 320 = 32 x 10)
     against the one-GEMM form of the same engine (spectra, synthesis frames, waveforms), the reference's own STFT of the golden
     clip (`spec_head` / `spec_tail`, torch.stft of the reference modules) and the oracle -- plain and pipelined host paths,
-    ragged lengths, a frame count that is no multiple of the 8- / 16-frame tiles."""
-    import ctypes
-    g, meta = load_golden("48k_nb1")
+    ragged lengths, a frame count that is no multiple of the frame tiles."""
+    g, meta = load_golden(tag)
     blob = golden_blob(meta)
     sr, nb = meta["sample_rate"], meta["nb"]
+    win = 960 if sr == 48000 else 320
+    hop, F = win // 2, win // 2 + 1
     n = len(g["wav"])
     B = 19
     wav = np.stack([g["wav"]] + [synth_clip(n, sr, 700 + i) for i in range(B - 1)])
-    T = 1 + (n + 960) // 480
+    T = 1 + (n + win) // hop
     o = make_oracle(meta, blob)
     res = {}
     for dft2 in (1, 0):
@@ -515,8 +517,8 @@ def test_48k_two_stage_dft_equals_the_one_gemm_form_and_the_reference(be):
         for pipe in (0, 1):
             m.set_option("host_pipe", pipe)
             y = m.enhance_batch(wav, None)
-            spec = m.debug_fetch("raw_spec").reshape(B, T, 481, 2)
-            frames = m.debug_fetch("frames").reshape(B, T, 960)
+            spec = m.debug_fetch("raw_spec").reshape(B, T, F, 2)
+            frames = m.debug_fetch("frames").reshape(B, T, win)
             res[(dft2, pipe)] = (y, spec, frames)
         m.close()
     y_ref, spec_ref, frames_ref = res[(0, 0)]
@@ -533,7 +535,7 @@ def test_48k_two_stage_dft_equals_the_one_gemm_form_and_the_reference(be):
             assert rms(y[b] - o.enhance(wav[b])) < 2e-6
     np.testing.assert_array_equal(res[(1, 0)][0], res[(1, 1)][0])       # plain and pipelined host paths: bit-identical
     # ragged: per-clip reflection point / frame count inside the two-stage analysis
-    lens = np.array([n, n - 1, 7 * 480 + 3, 2 * 480, 100, 1] + [n - 13 * i for i in range(B - 6)], dtype=np.int32)
+    lens = np.array([n, n - 1, 7 * hop + 3, 2 * hop, 100, 1] + [n - 13 * i for i in range(B - 6)], dtype=np.int32)
     m = be.HipModel(sr, nb, blob, 0)
     rows = m.enhance_batch_ragged([wav[b, : lens[b]].copy() for b in range(B)])
     m.set_option("dft2", 0)

@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""48 kHz offline, 256 x 10 s: two-stage 960-point DFT (dft960.h) on / off, same process, interleaved; per-class serial times."""
+"""Offline, 256 x 10 s: two-stage DFT (dft2stage.h) on / off, same process, interleaved; per-class serial times.
+usage: python tools/dft2_ab.py [sr]"""
 import sys, time, json
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np, torch
 from dpdfnet_amd import backend as be
 from dpdfnet_amd.weights import synth_blob
-sr, B = 48000, 256
+sr, B = (int(sys.argv[1]) if len(sys.argv) > 1 else 48000), 256
 N = 10 * sr
 wav = torch.from_numpy((0.05 * np.random.default_rng(1).standard_normal((B, N))).astype(np.float32)).cuda()
 out = torch.empty_like(wav)
-for nb in (2, 8):
+for nb in ((2, 8) if sr == 48000 else (4,)):
     m = be.HipModel(sr, nb, synth_blob(be.manifest(sr, nb), 20260417), 0)
     T = m.num_frames(N)
     for rep in range(2):
