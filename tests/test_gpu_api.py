@@ -395,7 +395,7 @@ def test_enhance_progress_is_real_and_ordered(be):
     ref = dpdfnet_amd.enhance(wav, sr, model="dpdfnet2", onnx_path="synthetic:9")
     np.testing.assert_array_equal(out, ref)
     sess = next(iter(runtime._cache.values())).session
-    assert sess.progress() == T
+    assert sess.progress() == 0          # the counter belongs to a call: it reads 0 again once the (synchronous) call has returned
     runtime.clear_cache()
 
 
