@@ -120,3 +120,19 @@ def test_layout():
     for rel in ["bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/dpdfnet_hip.h",
                 "oracle/dpdf_oracle.c", "tests/golden/make_golden.py", "profiles"]:
         assert (ROOT / rel).exists(), rel
+
+
+def test_banked_profiles_are_of_this_build():
+    """profiles/build_manifest.json (written by tools/profile_round.sh on the GPU box next to the traces it collects) lists the
+    sha256 of every source file of the measured build; it must match the tree, so that the evidence under profiles/ is evidence
+    of the build that is committed (kernel sources, C ABI headers, bench.py, the Python host layer)."""
+    import json
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(root / "tools"))
+    import build_manifest
+    banked = json.loads((root / "profiles" / "build_manifest.json").read_text())["files"]
+    now = build_manifest.manifest()
+    changed = sorted(k for k in set(banked) | set(now) if banked.get(k) != now.get(k))
+    assert not changed, f"sources changed since profiles/ was collected (re-run tools/profile_round.sh + tools/bank_profiles.sh): {changed}"

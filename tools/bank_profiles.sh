@@ -8,6 +8,7 @@ cp $P/trace_serial/bench_kernel_stats.csv profiles/${T}_serial_kernel_stats.csv
 cp $P/bench_line_under_trace_pipelined.json profiles/${T}_bench_line_under_trace_pipelined.json
 cp $P/bench_line_under_trace_serial.json profiles/${T}_bench_line_under_trace_serial.json
 cp $P/pmc_summary.json profiles/${T}_pmc_summary.json; cp $P/pmc_summary.json profiles/pmc_summary.json
+cp $P/build_manifest.json profiles/build_manifest.json
 cp gpurun_out/${T}_bench_default.json profiles/${T}_bench_line_default_run.json
 cp $X/hop_48k_nb8_64streams_kernel_stats.csv profiles/${T}_stream_hop_kernel_stats.csv
 cp $X/hop_48k_nb8_64streams_timeline.txt profiles/${T}_stream_hop_timeline.txt

@@ -7,6 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-rX}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
+python $R/tools/build_manifest.py > $OUT/build_manifest.json        # what exactly was measured (checked by tests/test_abi_and_layout.py)
 # Every launch of a traced run has ONE execution shape (no appended serial step, no side configs), so that the CSV's
 # AverageNs of a kernel IS the bench line's roofline.avg_launch_ms of the same run:
 #   trace_pipelined: the default 4-stream pipeline  -> roofline.frac
