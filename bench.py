@@ -221,6 +221,76 @@ def public_api_pass(B: int, steps: int, ref_slots: dict, timeout_s: float = 600.
     raise RuntimeError(f"no result line (rc {r.returncode}): {r.stderr[-300:]}")
 
 
+def public_streams(model_name: str, sr_: int, S: int, calls: int = 200) -> dict:
+    """configs[4] through the objects a USER holds (reference package/src/dpdfnet/stream.py:74-165): (a) one
+    `StreamEnhancer.group(S)` object, one hop of every stream per process() call; (b) S independent `pool.enhancer()` objects
+    fed one hop each per round from four host threads (the pool coalesces the hops that arrive within its window into one
+    device call).  Python staging, locks and the coalescing window are inside the figures."""
+    import threading
+    from dpdfnet_amd import StreamEnhancer, runtime as _rt
+    kw = dict(model=model_name, onnx_path=f"synthetic:{WEIGHT_SEED}")
+    hop = sr_ // 100
+    rng = np.random.default_rng(1)
+    pcm = (0.05 * rng.standard_normal((S, hop))).astype(np.float32)
+    g = StreamEnhancer.group(S, **kw)
+    g.process(np.concatenate([pcm, pcm], axis=1))          # window filled: primes, first hop
+    for _ in range(20):
+        g.process(pcm)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        y = g.process(pcm)
+    dt_group = (time.perf_counter() - t0) / calls
+    assert y.shape == (S, hop)
+    del g
+    pool = StreamEnhancer.pool(S, window_s=2e-4, **kw)
+    members = [pool.enhancer() for _ in range(S)]
+    pool.process_many([(m_, np.concatenate([pcm[i], pcm[i]])) for i, m_ in enumerate(members)])
+    nthreads, rounds = 4, calls
+    share = [list(range(t, S, nthreads)) for t in range(nthreads)]
+    bar = threading.Barrier(nthreads + 1)
+
+    def feeder(t: int) -> None:
+        mine = [(members[i], pcm[i]) for i in share[t]]
+        bar.wait()
+        for _ in range(rounds):
+            pool.process_many(mine)                         # this thread's streams: one request each, coalesced per round
+        bar.wait()
+
+    # (each thread hands its 16 streams to the pool together; the four threads' requests meet in the pool's round: the first
+    # caller leads and fires as soon as every stream in use has queued, or after the window)
+    ths = [threading.Thread(target=feeder, args=(t,)) for t in range(nthreads)]
+    for th in ths:
+        th.start()
+    dc0 = pool.device_calls
+    bar.wait(); t0 = time.perf_counter(); bar.wait()
+    dt_pool = (time.perf_counter() - t0) / rounds
+    for th in ths:
+        th.join()
+    calls_per_round = (pool.device_calls - dc0) / rounds
+    for m_ in members:
+        m_.close()
+    del pool, members
+    _rt.clear_cache()
+    return {"us_per_call_public_group": round(1e6 * dt_group, 1),
+            "us_per_round_public_pool_4_threads": round(1e6 * dt_pool, 1), "pool_device_calls_per_round": round(calls_per_round, 2),
+            "note": "group: StreamEnhancer.group(S).process([S, hop]) per hop; pool: S pool.enhancer() objects, four host threads "
+                    "each feeding its 16 members one hop per round through process_many(); the pool coalesces the four threads' requests into one "
+                    "device call per round (the round fires when all 64 streams in use have queued, or after the 200 us window)"}
+
+
+
+def public_streams_pass(model_name: str, sr_: int, S: int, timeout_s: float = 600.0) -> dict:
+    """`public_streams` in a process of its own (bench.py --public-streams-only): like the public batch API it is what a user's process
+    does, and further engine handles in THIS process would share hardware queues with the ones measured before and after."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--public-streams-only", f"{model_name},{sr_},{S}"],
+                       capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ))
+    for l in r.stdout.splitlines():
+        if l.startswith("PUBLIC_STREAMS "):
+            return json.loads(l[len("PUBLIC_STREAMS "):])
+    raise RuntimeError(f"no result line (rc {r.returncode}): {r.stderr[-300:]}")
+
+
 def other_configs() -> dict:
     """BASELINE.json's remaining single-GPU configurations, timed briefly beside the headline (they are parity-test
     cases in tests/test_gpu_fullsize.py; these are their speeds): dpdfnet2 / dpdfnet8 at 256 clips x 10 s, one clip
@@ -281,68 +351,12 @@ def other_configs() -> dict:
                                   "bound_us": round(bound_us, 1), "achieved_over_bound": round(1e6 * dt / bound_us, 2)},
                 "io": "host PCM in, host PCM out (pinned staging, zero-copy), one device call per hop"}
 
-    def public_streams(model_name: str, sr_: int, S: int, calls: int = 200) -> dict:
-        """configs[4] through the objects a USER holds (reference package/src/dpdfnet/stream.py:74-165): (a) one
-        `StreamEnhancer.group(S)` object, one hop of every stream per process() call; (b) S independent `pool.enhancer()` objects
-        fed one hop each per round from four host threads (the pool coalesces the hops that arrive within its window into one
-        device call).  Python staging, locks and the coalescing window are inside the figures."""
-        import threading
-        from dpdfnet_amd import StreamEnhancer, runtime as _rt
-        kw = dict(model=model_name, onnx_path=f"synthetic:{WEIGHT_SEED}")
-        hop = sr_ // 100
-        rng = np.random.default_rng(1)
-        pcm = (0.05 * rng.standard_normal((S, hop))).astype(np.float32)
-        g = StreamEnhancer.group(S, **kw)
-        g.process(np.concatenate([pcm, pcm], axis=1))          # window filled: primes, first hop
-        for _ in range(20):
-            g.process(pcm)
-        t0 = time.perf_counter()
-        for _ in range(calls):
-            y = g.process(pcm)
-        dt_group = (time.perf_counter() - t0) / calls
-        assert y.shape == (S, hop)
-        del g
-        pool = StreamEnhancer.pool(S, window_s=2e-4, **kw)
-        members = [pool.enhancer() for _ in range(S)]
-        pool.process_many([(m_, np.concatenate([pcm[i], pcm[i]])) for i, m_ in enumerate(members)])
-        nthreads, rounds = 4, calls
-        share = [list(range(t, S, nthreads)) for t in range(nthreads)]
-        bar = threading.Barrier(nthreads + 1)
-
-        def feeder(t: int) -> None:
-            mine = [(members[i], pcm[i]) for i in share[t]]
-            bar.wait()
-            for _ in range(rounds):
-                pool.process_many(mine)                         # this thread's streams: one request each, coalesced per round
-            bar.wait()
-
-        # (each thread hands its 16 streams to the pool together; the four threads' requests meet in the pool's round: the first
-        # caller leads and fires as soon as every stream in use has queued, or after the window)
-        ths = [threading.Thread(target=feeder, args=(t,)) for t in range(nthreads)]
-        for th in ths:
-            th.start()
-        dc0 = pool.device_calls
-        bar.wait(); t0 = time.perf_counter(); bar.wait()
-        dt_pool = (time.perf_counter() - t0) / rounds
-        for th in ths:
-            th.join()
-        calls_per_round = (pool.device_calls - dc0) / rounds
-        for m_ in members:
-            m_.close()
-        del pool, members
-        _rt.clear_cache()
-        return {"us_per_call_public_group": round(1e6 * dt_group, 1),
-                "us_per_round_public_pool_4_threads": round(1e6 * dt_pool, 1), "pool_device_calls_per_round": round(calls_per_round, 2),
-                "note": "group: StreamEnhancer.group(S).process([S, hop]) per hop; pool: S pool.enhancer() objects, four host threads "
-                        "each feeding its 16 members one hop per round through process_many(); the pool coalesces the four threads' requests into one "
-                        "device call per round (the round fires when all 64 streams in use have queued, or after the 200 us window)"}
-
     # latency-bound configurations first (short kernels: measured before the long throughput runs heat the chip)
     fps, ms = offline(NB, 1, 5)
     out[f"{MODEL}_16k_1x10s"] = {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5)}
     out["dpdfnet8_48khz_hr_64_streams_1_hop"] = streams(48000, 8, 64)         # BASELINE configs[4]
     try:
-        pub = public_streams("dpdfnet8_48khz_hr", 48000, 64)
+        pub = public_streams_pass("dpdfnet8_48khz_hr", 48000, 64)
         pub["public_group_over_c_abi"] = round(pub["us_per_call_public_group"] / out["dpdfnet8_48khz_hr_64_streams_1_hop"]["us_per_call"], 3)
         pub["public_pool_over_c_abi"] = round(pub["us_per_round_public_pool_4_threads"] / out["dpdfnet8_48khz_hr_64_streams_1_hop"]["us_per_call"], 3)
         out["dpdfnet8_48khz_hr_64_streams_1_hop"]["public_objects"] = pub
@@ -472,7 +486,13 @@ def main() -> None:
     ap.add_argument("--dist-selftest-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--public-api-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--ref-slots", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--public-streams-only", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.public_streams_only:
+        name, sr_, S_ = args.public_streams_only.split(",")
+        print("PUBLIC_STREAMS " + json.dumps(public_streams(name, int(sr_), int(S_))), flush=True)
+        return
 
     if args.public_api_only:
         public_api_worker(args.clips, max(1, args.steps), args.ref_slots)

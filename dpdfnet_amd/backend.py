@@ -61,6 +61,29 @@ def lib_path() -> Path:
     return Path(override) if override else _PKG_DIR / _LIB_NAME
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own `libamdhip64.so.7` / `libhsa-runtime64.so.1` under
+    torch/lib with the SAME sonames as the system ROCm: whichever copy is loaded first serves both.  With the system copy first
+    (this library loaded before torch) a later `torch.cuda` initialisation finds "No HIP GPUs"; with torch's copy first both
+    work (bench.py's order).  So if torch is installed but not imported yet, its bundled runtime is loaded here -- by path, torch
+    itself is NOT imported -- before the engine library.  DPDFNET_NO_TORCH_HIP_PRELOAD=1 opts out."""
+    import sys
+    if os.environ.get("DPDFNET_NO_TORCH_HIP_PRELOAD", "") not in ("", "0") or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        libdir = Path(spec.origin).parent / "lib"
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            f = libdir / name
+            if f.is_file():
+                ctypes.CDLL(str(f), mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass          # best effort: the engine itself runs on either copy
+
+
 def load_library() -> ctypes.CDLL:
     """Load the HIP extension.  Raises RuntimeError (never falls back) when it is missing."""
     global _lib
@@ -73,6 +96,7 @@ def load_library() -> ctypes.CDLL:
                 f"MI355X HIP extension not built: {p} is missing. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)."
             )
+        _preload_torch_hip_runtime()
         try:
             L = ctypes.CDLL(str(p))
         except OSError as exc:

@@ -429,7 +429,16 @@ def test_host_calls_pipelined_over_time_slices_equal_the_plain_path(tag, be):
         rag0 = np.zeros_like(wav)
         be._check(m._L.dpdf_enhance_batch_ragged(m._h, wav.ctypes.data, B, n, lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), db, rag0.ctypes.data, 0))
         m.set_option("host_pipe", 1)
-        np.testing.assert_array_equal(piped, plain)            # (= the device-pointer path: bench.py asserts that on its line)
+        np.testing.assert_array_equal(piped, plain)
+        # the device-pointer path, whole-batch transforms and the per-chunk form ("chunk_io": an A/B option, off by default)
+        import torch
+        d_in = torch.from_numpy(wav).cuda()
+        for cio in (0, 1):
+            m.set_option("chunk_io", cio)
+            d_out = torch.zeros_like(d_in)
+            m.enhance_batch_device(d_in.data_ptr(), B, n, d_out.data_ptr(), attn); m.sync()
+            np.testing.assert_array_equal(piped, d_out.cpu().numpy())
+        m.set_option("chunk_io", 0)
         np.testing.assert_array_equal(rag, rag0)
         for b in range(B):
             np.testing.assert_array_equal(rows[b], rag[b, : lens[b]])
@@ -442,3 +451,45 @@ def test_host_calls_pipelined_over_time_slices_equal_the_plain_path(tag, be):
         m.set_option("host_copy_threads", 1)
         np.testing.assert_array_equal(m.enhance_batch(wav, attn), piped)
         m.close()
+
+
+def test_torch_cuda_still_works_after_the_engine_was_loaded_first():
+    """PyTorch-ROCm bundles its own HIP runtime under the system's sonames; the engine library loaded first used to make a later
+    torch.cuda initialisation fail ("No HIP GPUs are available").  backend.load_library preloads torch's copy when torch is
+    installed but not yet imported (fresh process: engine first, then torch on the GPU, then the engine again)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    code = (
+        "import numpy as np\n"
+        "from dpdfnet_amd import backend\n"
+        "from dpdfnet_amd.weights import synth_blob\n"
+        "m = backend.HipModel(16000, 0, synth_blob(backend.manifest(16000, 0), 1), 0)\n"
+        "y = m.enhance_batch(np.zeros((1, 4000), np.float32))\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "x = torch.ones(1024, device='cuda')\n"
+        "assert float(x.sum().item()) == 1024.0\n"
+        "y2 = m.enhance_batch(np.zeros((1, 4000), np.float32))\n"
+        "assert np.array_equal(y, y2)\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=Path(__file__).resolve().parents[1], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
+
+
+def test_row_pointer_call_rejects_bad_arguments(be):
+    import ctypes
+    sr, nb, blob = _synthetic(be, "dpdfnet2", 3)
+    m = be.HipModel(sr, nb, blob, 0)
+    x = np.zeros(400, np.float32); y = np.zeros(400, np.float32)
+    rows_in = (ctypes.c_void_p * 1)(x.ctypes.data); rows_out = (ctypes.c_void_p * 1)(y.ctypes.data)
+    null = (ctypes.c_void_p * 1)(None)
+    lens = (ctypes.c_int * 1)(400)
+    nan = float("nan")
+    assert m._L.dpdf_enhance_batch_rows(m._h, rows_in, lens, 1, 400, nan, rows_out, 0) == 0
+    for args in ((null, lens, 1, 400, nan, rows_out, 0), (rows_in, lens, 1, 400, nan, null, 0), (rows_in, lens, 1, 400, nan, rows_out, 1),
+                 (rows_in, (ctypes.c_int * 1)(401), 1, 400, nan, rows_out, 0), (rows_in, lens, 1, 400, -3.0, rows_out, 0)):
+        with pytest.raises(ValueError):
+            be._check(m._L.dpdf_enhance_batch_rows(m._h, *args))
+    assert m.enhance_batch_ragged([]) == [] and m.enhance_batch_ragged([np.zeros(0, np.float32)])[0].shape == (0,)
+    m.close()
