@@ -30,3 +30,14 @@ def test_random_streaming_call_sequences_hop_forms_equal_plain_chain():
     rec = mod.run(8.0, 20260929)
     assert not rec.get("FAIL"), rec
     assert rec["cases"] >= 10 and rec["worst_rms"] < 2e-6, rec
+
+
+def test_random_host_calls_pipelined_equal_plain():
+    """tools/host_pipe_soak.py: random batch shapes / chunk lengths / ragged lengths / attenuation limits through the pipelined
+    host-pointer calls and through the plain ones of the same engine: bit-identical, in the block, ragged and row-pointer forms."""
+    spec = importlib.util.spec_from_file_location("dpdf_host_pipe_soak", Path(__file__).resolve().parents[1] / "tools" / "host_pipe_soak.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rec = mod.run(10.0, 20260929)
+    assert not rec.get("FAIL"), rec
+    assert rec["cases"] >= 8 and rec["cases_with_pipelined_shape"] >= 3, rec
