@@ -59,6 +59,17 @@ def synth_clips(n_clips: int, n: int, sr: int, first_seed: int) -> np.ndarray:
     return out
 
 
+def banked_trace(kind: str) -> str:
+    """profiles/r<N>_<kind>_kernel_stats.csv of the latest round banked under profiles/ (tools/bank_profiles.sh), by name."""
+    import re
+    best, best_n = f"profiles/rN_{kind}_kernel_stats.csv (none banked)", -1
+    for f in (ROOT / "profiles").glob(f"r*_{kind}_kernel_stats.csv"):
+        mt = re.match(r"r(\d+)_", f.name)
+        if mt and int(mt.group(1)) > best_n:
+            best, best_n = f"profiles/{f.name}", int(mt.group(1))
+    return best
+
+
 def usable_cores() -> int:
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU
     box exposes 256 hardware threads but cpu.max limits the container to a few of them)."""
@@ -337,7 +348,7 @@ def other_configs() -> dict:
         d = backend.query_dims(sr_, nb_)
         # Latency model of a hop: the two branches run side by side, each a chain of nb x (F' dependent
         # GRU-64 steps + one glue launch); the DF branch (F' = 48) is the longer one.  Measured minima on this chip
-        # (rocprofv3 trace of single hops, profiles/r3_stream_hop_*): 0.55 us per 4-row scan step (64 x 8.4-cycle
+        # (rocprofv3 trace of single hops, profiles/r*_stream_hop_*): 0.55 us per 4-row scan step (64 x 8.4-cycle
         # v_mfma_f32_4x4x1 + one LDS round trip + the gate chain), ~1.5 us per dependent kernel boundary.
         # Launches on the chain of a one-chunk call (main stream; the decoders one after the other): prologue / import, STFT,
         # features, encoder front end (+ projection at 48 kHz x 64), nb x (scan, glue), emb_in, 5 GRU-256 steps, emb_out, df_out,
@@ -779,7 +790,7 @@ def main() -> None:
                 "timing": f"HIP events on the launching stream around every launch of {psteps} steps run right after the timed "
                           "region in the same execution shape (the timed region itself runs with these events off: "
                           f"{1e3 * dt / args.steps:.2f} ms/step timed vs {prof_ms:.2f} ms/step with events)",
-                "reproduce": ("profiles/r3_serial_kernel_stats.csv" if serial_mode else "profiles/r3_pipelined_kernel_stats.csv")
+                "reproduce": (banked_trace("serial") if serial_mode else banked_trace("pipelined"))
                              + ": rocprofv3 --kernel-trace --stats of `python bench.py --no-isolated --no-other-configs --no-cpu-baseline "
                                "--no-pcie" + (" --overlap 0`" if serial_mode else "`") + " -- every launch of that run has this execution "
                                "shape, so the CSV's AverageNs for the kernel is this avg_launch_ms (profiles/README.md)",
@@ -798,7 +809,7 @@ def main() -> None:
                 roofline["frac_note"] = ("`frac` divides by the launch duration seen INSIDE the 4-stream pipeline, where the kernel "
                                          "shares the CUs with three other streams (faster pipeline => longer individual launches); "
                                          "`frac_isolated` is the same kernel, same launches, run back to back in the extra serial "
-                                         "step (= profiles/r3_serial_kernel_stats.csv, the --overlap 0 run); `whole_path_frac` is "
+                                         f"step (= {banked_trace('serial')}, the --overlap 0 run); `whole_path_frac` is "
                                          "frames/s x FLOP/frame over the fp32 MFMA peak")
                 roofline["roofline_isolated"] = {
                     "note": "one extra step AFTER the timed region with the stream pipeline switched off (kernels back to back)",

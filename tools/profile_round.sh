@@ -12,7 +12,7 @@ python $R/tools/build_manifest.py > $OUT/build_manifest.json        # what exact
 # AverageNs of a kernel IS the bench line's roofline.avg_launch_ms of the same run:
 #   trace_pipelined: the default 4-stream pipeline  -> roofline.frac
 #   trace_serial:    --overlap 0, kernels back to back -> roofline.frac_isolated of the default run
-CMD="timeout 600 python bench.py --steps 3 --warmup 1 --no-isolated --no-other-configs --no-cpu-baseline --no-pcie"
+CMD="timeout 600 python bench.py --steps 3 --warmup 1 --no-isolated --no-other-configs --no-cpu-baseline --no-pcie --no-dist-selftest"
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -o bench -- $CMD > $OUT/bench_trace_pipelined.log 2>&1
 grep '^{"metric"' $OUT/bench_trace_pipelined.log > $OUT/bench_line_under_trace_pipelined.json
