@@ -302,7 +302,7 @@ def public_streams_pass(model_name: str, sr_: int, S: int, timeout_s: float = 60
     raise RuntimeError(f"no result line (rc {r.returncode}): {r.stderr[-300:]}")
 
 
-def other_configs() -> dict:
+def other_configs(only=None) -> dict:
     """BASELINE.json's remaining single-GPU configurations, timed briefly beside the headline (they are parity-test
     cases in tests/test_gpu_fullsize.py; these are their speeds): dpdfnet2 / dpdfnet8 at 256 clips x 10 s, one clip
     through the engine (what a single `enhance()` call costs), and configs[4]: 64 concurrent device-resident
@@ -362,10 +362,35 @@ def other_configs() -> dict:
                                   "bound_us": round(bound_us, 1), "achieved_over_bound": round(1e6 * dt / bound_us, 2)},
                 "io": "host PCM in, host PCM out (pinned staging, zero-copy), one device call per hop"}
 
-    # latency-bound configurations first (short kernels: measured before the long throughput runs heat the chip)
-    fps, ms = offline(NB, 1, 5)
-    out[f"{MODEL}_16k_1x10s"] = {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5)}
-    out["dpdfnet8_48khz_hr_64_streams_1_hop"] = streams(48000, 8, 64)         # BASELINE configs[4]
+    # Every side configuration is measured in a process of its own (`bench.py --side-config <name>`): engine handles created
+    # one after the other in ONE process end up sharing hardware queues (section 3b of DESIGN.md) -- the fifth handle of the bench
+    # process measured dpdfnet8 at 194.7 ms per step, a fresh process 187.0.
+    if only == "one_clip":
+        fps, ms = offline(NB, 1, 5)
+        return {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5)}
+    if only == "streams48":
+        return streams(48000, 8, 64)                                           # BASELINE configs[4]
+    if only == "streams16":
+        return streams(16000, 2, 1)                                            # one StreamEnhancer (the reference's unit of work)
+    if only in ("offline2", "offline8"):
+        nb = int(only[-1])
+        fps, ms = offline(nb, 256, 3)
+        return {"frames_per_s": round(fps), "ms_per_step": round(ms, 2), "whole_path_frac": mfma(fps, SR, nb)}
+    if only is not None:
+        raise SystemExit(f"unknown side configuration {only!r}")
+
+    def child(name: str) -> dict:
+        import subprocess
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--side-config", name], capture_output=True, text=True,
+                           timeout=900, env=dict(os.environ))
+        for l in r.stdout.splitlines():
+            if l.startswith("SIDE "):
+                return json.loads(l[len("SIDE "):])
+        return {"error": f"no result line (rc {r.returncode}): {r.stderr[-300:]}"}
+
+    # latency-bound configurations first
+    out[f"{MODEL}_16k_1x10s"] = child("one_clip")
+    out["dpdfnet8_48khz_hr_64_streams_1_hop"] = child("streams48")
     try:
         pub = public_streams_pass("dpdfnet8_48khz_hr", 48000, 64)
         pub["public_group_over_c_abi"] = round(pub["us_per_call_public_group"] / out["dpdfnet8_48khz_hr_64_streams_1_hop"]["us_per_call"], 3)
@@ -373,10 +398,9 @@ def other_configs() -> dict:
         out["dpdfnet8_48khz_hr_64_streams_1_hop"]["public_objects"] = pub
     except Exception as exc:
         out["dpdfnet8_48khz_hr_64_streams_1_hop"]["public_objects"] = {"error": f"{type(exc).__name__}: {exc}"}
-    out["dpdfnet2_16k_1_stream_1_hop"] = streams(16000, 2, 1)                  # one StreamEnhancer (the reference's unit of work)
+    out["dpdfnet2_16k_1_stream_1_hop"] = child("streams16")
     for nb in (2, 8):
-        fps, ms = offline(nb, 256, 3)
-        out[f"dpdfnet{nb}_16k_256x10s"] = {"frames_per_s": round(fps), "ms_per_step": round(ms, 2), "whole_path_frac": mfma(fps, SR, nb)}
+        out[f"dpdfnet{nb}_16k_256x10s"] = child(f"offline{nb}")
     return out
 
 
@@ -498,7 +522,14 @@ def main() -> None:
     ap.add_argument("--public-api-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--ref-slots", default="", help=argparse.SUPPRESS)
     ap.add_argument("--public-streams-only", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--side-config", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.side_config:
+        import torch
+        torch.cuda.set_device(0)
+        print("SIDE " + json.dumps(other_configs(args.side_config)), flush=True)
+        return
 
     if args.public_streams_only:
         name, sr_, S_ = args.public_streams_only.split(",")
