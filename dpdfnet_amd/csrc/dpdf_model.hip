@@ -48,6 +48,7 @@
 #include "enc_seg.h"
 #include "dec_pyr.h"
 #include "dft2stage.h"
+#include "gru_clusterx.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -433,6 +434,7 @@ struct dpdf_model {
     int dft2 = 1;                      // big launches: STFT / iSTFT as two small matrix stages (0: one [win x 2F] GEMM; A/B)
     HostPipe hp;                       // pinned staging ring + copy streams of the host-pointer batch calls
     int host_pipe = 1;                 // host-pointer batch calls pipelined over time slices (0: one upload, compute, one download; A/B)
+    int gru256_fused_x = 1;            // big batches: GRU-256 input projection inside the four-workgroup cluster scan (gru_clusterx.h; 0: hoisted GEMM + scan, A/B)
     int chunk_io = 0;                  // device-pointer batch calls of several chunks: STFT / iSTFT + overlap-add per chunk beside the frame function (0: two whole-batch launches; A/B)
     int host_prefault = 1;             // pipelined host calls: a helper thread populates the caller's output rows while the first chunk computes (0: A/B)
     int host_copy_threads = 4;         // threads (incl. the caller's) that move rows between the caller's memory and pinned staging
@@ -958,6 +960,25 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
     if (Tc == 1 && !gi_buf && run_gru256_step(m, g, x, out, state, S, hoff, B, which)) return;
     const int M = B * Tc;
     float* gi = gi_buf ? gi_buf : (which ? m->ln->ws.gi2.p : m->ln->ws.gi.p);
+    // Big batches (the four-workgroup cluster form): the input projection runs INSIDE the scan, in the time a wave would otherwise
+    // spend waiting for its peers' granules (gru_clusterx.h) -- no chip-wide GEMM in front, no 3 KB per row through HBM.
+    {
+        const int ntiles = (B + 15) / 16;
+        const bool four = !((m->overlap & 16) && ntiles <= std::max(m->gru256_c16_tiles, m->gru256_c8_tiles));
+        if (m->gru256_fused_x && four && !gi_buf && Tc > 1 && m->use_gru256_cluster && ensure_gru_xbuf(m, ntiles, which) == DPDF_OK) {
+            ProfScope ps(m, "gru256_scan");
+            Lane& L = *m->ln;
+            if (L.gru_epoch[which] > 0xF0000000u) {
+                (void)hipMemsetAsync(L.gru_xbuf[which], 0, (size_t)L.gru_xbuf_tiles[which] * 2 * 16 * 256 * 8, m->cur);
+                L.gru_epoch[which] = 0;
+            }
+            Gru256XArgs a{x, out, m->C(g.hh_frag), m->C(g.ih_as_hh), m->C(g.ih_bias), m->C(g.b_hn), state + hoff, S, B, Tc,
+                          L.gru_xbuf[which], L.gru_epoch[which], m->d_err};
+            L.gru_epoch[which] += (unsigned)Tc;
+            hipLaunchKernelGGL(gru256_clusterx_kernel, dim3(ntiles * 4), dim3(256), 0, m->cur, a);
+            return;
+        }
+    }
     run_gru256_proj(m, g, x, gi, M);
     {
         ProfScope ps(m, "gru256_scan");
@@ -2070,6 +2091,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "host_prefault") m->host_prefault = value != 0;
     else if (n == "dft2") m->dft2 = value != 0;
     else if (n == "chunk_io") m->chunk_io = value != 0;
+    else if (n == "gru256_fused_x") m->gru256_fused_x = value != 0;
     else if (n == "host_copy_threads") m->host_copy_threads = value < 1 ? 1 : value;
     else if (n == "single_chunk_inline") m->single_chunk_inline = value != 0;
     else if (n == "fuse_dec") m->fuse_dec = value != 0;

@@ -464,8 +464,8 @@ def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
 
 
 def test_every_gru256_scan_form_agrees(be):
-    """The forms of the GRU-256 recurrence -- single-workgroup scan (`gru256_cluster` = 0), 4-workgroup cluster, 8- and
-    16-workgroup clusters for small launches, the two cells of a decoder stack as one wavefront launch (gru_stack.h) -- on
+    """The forms of the GRU-256 recurrence -- single-workgroup scan (`gru256_cluster` = 0), 4-workgroup cluster with the input
+    projection hoisted or inside the scan, 8- and 16-workgroup clusters for small launches, the two cells of a decoder stack as one wavefront launch (gru_stack.h) -- on
     the same input: equal to rounding, state included."""
     g, meta = load_golden("16k_nb1")
     blob = golden_blob(meta)
@@ -474,7 +474,8 @@ def test_every_gru256_scan_form_agrees(be):
     spec = np.stack([o.stft(synth_clip(3000, 16000, 900 + i)) for i in range(40)])      # 40 streams = 3 tiles
     st0 = np.tile(m.initial_state(), (40, 1))
     outs = {}
-    for tag, opts, ov in (("cluster", {"gru256_c16_tiles": 0, "gru256_cluster": 1, "gru256_stack": 0}, 27 & ~16),
+    for tag, opts, ov in (("cluster", {"gru256_c16_tiles": 0, "gru256_cluster": 1, "gru256_stack": 0, "gru256_fused_x": 0}, 27 & ~16),
+                          ("cluster_x", {"gru256_fused_x": 1}, 27 & ~16),      # the input projection inside the four-workgroup scan (gru_clusterx.h)
                           ("cluster8", {"gru256_c16_tiles": 0}, 27), ("cluster16", {"gru256_c16_tiles": 4}, 27),
                           ("stack16", {"gru256_c16_tiles": 4, "gru256_stack": 1}, 27), ("stack16_serial", {}, 16),
                           ("single_wg", {"gru256_cluster": 0}, 27)):
@@ -484,6 +485,7 @@ def test_every_gru256_scan_form_agrees(be):
         outs[tag] = m.run_frames(spec, st0)
     m.set_option("gru256_cluster", 1); m.set_option("gru256_c16_tiles", 2); m.set_overlap(27)
     assert not np.array_equal(outs["stack16"][0], outs["cluster16"][0])         # the stacked form really ran
+    assert not np.array_equal(outs["cluster_x"][0], outs["cluster"][0])         # ... and so did the fused-projection form
     ref, st_ref = outs["cluster"]
     scale = float(np.abs(ref).max())
     for tag, (out, st) in outs.items():

@@ -1,6 +1,7 @@
 #!/bin/bash
 # What does a kernel class COST in the pipeline?  Offline 256 x 10 s step with a debug build that can leave out launches
-# (results are garbage; timing only).  usage: tools/skip_probe.sh <debug.so> sr nb
+# (getenv switches patched into a copy of dpdf_model.hip; results are garbage; timing only).
+# usage: tools/skip_probe.sh <debug.so> sr nb
 O=$(realpath $1); SR=$2; NB=$3
 cat > /tmp/skip_one.py <<'PY'
 import sys, time
@@ -20,7 +21,8 @@ m.sync()
 print("ms/step %.2f" % (1e3 * (time.perf_counter() - t0) / 3))
 PY
 for rep in 1 2; do
-  echo "full        $(DPDFNET_HIP_LIB=$O python /tmp/skip_one.py $SR $NB | tail -1)"
-  echo "no conv0    $(DPDFNET_HIP_LIB=$O DPDF_DEBUG_SKIP_CONV0=1 python /tmp/skip_one.py $SR $NB | tail -1)"
-  echo "no dec_convs $(DPDFNET_HIP_LIB=$O DPDF_DEBUG_SKIP_DEC=1 python /tmp/skip_one.py $SR $NB | tail -1)"
+  echo "full            $(DPDFNET_HIP_LIB=$O python /tmp/skip_one.py $SR $NB 2>/dev/null | tail -1)"
+  for v in SKIP_CONV0 SKIP_DEC SKIP_PROJ SKIP_SCAN256 SKIP_DPRNN_ERB SKIP_DPRNN_DF; do
+    echo "no $v   $(env DPDFNET_HIP_LIB=$O DPDF_DEBUG_$v=1 python /tmp/skip_one.py $SR $NB 2>/dev/null | tail -1)"
+  done
 done

@@ -33,9 +33,9 @@ def run(budget: float = 60.0, seed: int = 1) -> dict:
         F = m.freq_bins
         spec = (rng.standard_normal((B, T, F, 2)) * 3.0).astype(np.float32)
         st0 = np.tile(m.initial_state()[None, :], (B, 1))
-        m.set_overlap(0); m.set_fuse_dprnn("never"); m.set_chunk_frames(-1)
+        m.set_overlap(0); m.set_fuse_dprnn("never"); m.set_chunk_frames(-1); m.set_option("gru256_fused_x", 0)
         ref, sref = m.run_frames(spec, st0.copy())
-        m.set_overlap(27); m.set_fuse_dprnn("auto"); m.set_chunk_frames(int(rng.choice([0, 0, 1, 2, 7, 64])))
+        m.set_overlap(27); m.set_fuse_dprnn("auto"); m.set_chunk_frames(int(rng.choice([0, 0, 1, 2, 7, 64]))); m.set_option("gru256_fused_x", 1)
         out, s1 = m.run_frames(spec, st0.copy())
         out2, s2 = m.run_frames(spec, st0.copy())
         scale = float(np.abs(ref).max()) + 1e-12
