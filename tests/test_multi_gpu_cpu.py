@@ -59,3 +59,33 @@ def test_gather_world_size_2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok and means == [0.0, 1.0]
+
+
+def test_bench_plain_invocation_becomes_its_own_launcher(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-launches itself under torch.distributed.run with N ranks
+    on 127.0.0.1 and passes its own arguments through (bench.self_launch); under a launcher (WORLD_SIZE set) it does not."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(root))
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 0)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--backend", "gloo"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--backend", "gloo"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # main(): plain invocation with --gpus 4 -> SystemExit(rc of the launcher); with WORLD_SIZE set it goes on to the rank path
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 0 and seen["cmd"][1:3] == ["-m", "torch.distributed.run"]
