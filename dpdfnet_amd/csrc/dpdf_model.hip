@@ -434,6 +434,7 @@ struct dpdf_model {
     int dft2 = 1;                      // big launches: STFT / iSTFT as two small matrix stages (0: one [win x 2F] GEMM; A/B)
     HostPipe hp;                       // pinned staging ring + copy streams of the host-pointer batch calls
     int host_pipe = 1;                 // host-pointer batch calls pipelined over time slices (0: one upload, compute, one download; A/B)
+    int gru256_fused_x_tiles = 6;      // ... from this many 16-row tiles on
     int gru256_fused_x = 1;            // big batches: GRU-256 input projection inside the four-workgroup cluster scan (gru_clusterx.h; 0: hoisted GEMM + scan, A/B)
     int chunk_io = 0;                  // device-pointer batch calls of several chunks: STFT / iSTFT + overlap-add per chunk beside the frame function (0: two whole-batch launches; A/B)
     int host_prefault = 1;             // pipelined host calls: a helper thread populates the caller's output rows while the first chunk computes (0: A/B)
@@ -965,7 +966,9 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
     {
         const int ntiles = (B + 15) / 16;
         const bool four = !((m->overlap & 16) && ntiles <= std::max(m->gru256_c16_tiles, m->gru256_c8_tiles));
-        if (m->gru256_fused_x && four && !gi_buf && Tc > 1 && m->use_gru256_cluster && ensure_gru_xbuf(m, ntiles, which) == DPDF_OK) {
+        // (from six tiles = the throughput regime of the chunk schedule on: 80 clips 44.0 -> 44.4 ms -- there the stage-2 chain's latency
+        // counts and a step is 6.0 instead of 5.1 us --, 128 clips 59.1 -> 58.6, 256 clips 106.5 -> 105.5, 512 clips 208.0 -> 203.3)
+        if (m->gru256_fused_x && four && ntiles >= m->gru256_fused_x_tiles && !gi_buf && Tc > 1 && m->use_gru256_cluster && ensure_gru_xbuf(m, ntiles, which) == DPDF_OK) {
             ProfScope ps(m, "gru256_scan");
             Lane& L = *m->ln;
             if (L.gru_epoch[which] > 0xF0000000u) {
@@ -2092,6 +2095,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "dft2") m->dft2 = value != 0;
     else if (n == "chunk_io") m->chunk_io = value != 0;
     else if (n == "gru256_fused_x") m->gru256_fused_x = value != 0;
+    else if (n == "gru256_fused_x_tiles") m->gru256_fused_x_tiles = value < 1 ? 1 : value;
     else if (n == "host_copy_threads") m->host_copy_threads = value < 1 ? 1 : value;
     else if (n == "single_chunk_inline") m->single_chunk_inline = value != 0;
     else if (n == "fuse_dec") m->fuse_dec = value != 0;

@@ -475,7 +475,7 @@ def test_every_gru256_scan_form_agrees(be):
     st0 = np.tile(m.initial_state(), (40, 1))
     outs = {}
     for tag, opts, ov in (("cluster", {"gru256_c16_tiles": 0, "gru256_cluster": 1, "gru256_stack": 0, "gru256_fused_x": 0}, 27 & ~16),
-                          ("cluster_x", {"gru256_fused_x": 1}, 27 & ~16),      # the input projection inside the four-workgroup scan (gru_clusterx.h)
+                          ("cluster_x", {"gru256_fused_x": 1, "gru256_fused_x_tiles": 1}, 27 & ~16),      # the input projection inside the four-workgroup scan (gru_clusterx.h)
                           ("cluster8", {"gru256_c16_tiles": 0}, 27), ("cluster16", {"gru256_c16_tiles": 4}, 27),
                           ("stack16", {"gru256_c16_tiles": 4, "gru256_stack": 1}, 27), ("stack16_serial", {}, 16),
                           ("single_wg", {"gru256_cluster": 0}, 27)):

@@ -9,7 +9,8 @@ from dpdfnet_amd import backend as be
 from dpdfnet_amd.weights import synth_blob
 from bench import synth_clips
 sr, nb = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (16000, 4)
-B, N = 256, 10 * sr
+import os
+B, N = int(os.environ.get("CLIPS", "256")), 10 * sr
 wav = torch.from_numpy(synth_clips(B, N, sr, 1)).cuda()
 m = be.HipModel(sr, nb, synth_blob(be.manifest(sr, nb), 20260417), 0)
 T = m.num_frames(N)
