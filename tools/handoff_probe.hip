@@ -5,6 +5,7 @@
 //     agent-scope atomics, the payload written with plain stores + __threadfence() = release / acquire at agent scope): us per phase
 // (c) the same with the payload published as {epoch, value} granules (sc1 write-through stores, relaxed agent-scope polling loads: the
 //     GRU-256 cluster scans' protocol) from every workgroup to its ring neighbour -- no fences, no counter: us per phase
+// (d) see flagged_kernel.
 // The decision they inform: a persistent DPRNN-branch kernel replaces 2 nb kernel boundaries + entry phases
 // by 2 nb in-kernel hand-offs of (b) or (c).
 #include <hip/hip_runtime.h>
@@ -62,6 +63,32 @@ __global__ void granule_kernel(unsigned long long* gbuf, float* out, int phases,
     if (threadIdx.x == 0) out[g] = acc;
 }
 
+// (d) payload as plain agent-scope (write-through) stores, ONE {epoch} flag granule per workgroup behind them (stores drained: the
+//     workgroup barrier's release waits for vmcnt(0)); the consumer polls the flag, then reads the payload with agent-scope loads
+__global__ void flagged_kernel(float* buf, unsigned long long* flags, float* out, int phases, int n_per_wg, unsigned base) {
+    const int G = gridDim.x, g = blockIdx.x;
+    float acc = 0.f;
+    for (int p = 0; p < phases; ++p) {
+        float* mine = buf + ((size_t)(p & 1) * G + g) * n_per_wg;
+        const float* peer = buf + ((size_t)(p & 1) * G + (g + 1) % G) * n_per_wg;
+        const unsigned epoch = base + (unsigned)p + 1u;
+        for (int i = threadIdx.x; i < n_per_wg; i += blockDim.x)
+            __hip_atomic_store(mine + i, acc + (float)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);                 // every store of this wave has been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flags + g, (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            while ((int)((unsigned)__hip_atomic_load(flags + (g + 1) % G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) ;
+        }
+        __syncthreads();
+        float got = 0.f;
+        for (int i = threadIdx.x; i < n_per_wg; i += blockDim.x) got += __hip_atomic_load(peer + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc = got * 1e-3f;
+    }
+    if (threadIdx.x == 0) out[g] = acc;
+}
+
 int main() {
     CK(hipSetDevice(0));
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -100,6 +127,23 @@ int main() {
                 double dt = now() - t0;
                 ebase += P;
                 if (rep) printf("(c) granule ring (sc1 data = flag),   %3d workgroups, %5d granules each: %.2f us per phase\n", G, npw, dt / P);
+            }
+        }
+    }
+    unsigned long long* flags; CK(hipMalloc(&flags, 256 * 8)); CK(hipMemset(flags, 0, 256 * 8));
+    float* pay; CK(hipMalloc(&pay, (size_t)2 * 256 * 32768 * 4));
+    unsigned fbase = 0;
+    for (int G : {2, 32, 192, 224}) {
+        for (int npw : {256, 4096, 16384}) {    // 1 KB / 16 KB / 64 KB per workgroup and phase
+            const int P = 2000;
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipDeviceSynchronize());
+                double t0 = now();
+                hipLaunchKernelGGL(flagged_kernel, dim3(G), dim3(256), 0, st, pay, flags, b, P, npw, fbase);
+                CK(hipStreamSynchronize(st));
+                double dt = now() - t0;
+                fbase += P;
+                if (rep) printf("(d) write-through payload + one flag,  %3d workgroups, %5d floats each: %.2f us per phase\n", G, npw, dt / P);
             }
         }
     }
