@@ -71,6 +71,39 @@ def test_baseline_batch_configs_full_size(be, nb, B, check_oracle):
     m.close()
 
 
+def test_every_slot_of_the_headline_batch_against_the_oracle(be):
+    """The headline workload (dpdfnet4, 256 x 10 s, automatic chunk schedule) with EVERY slot checked against the CPU oracle --
+    256 different signals, one oracle per host thread (1003 frames x 256 clips: about half a minute on 16 cores).  The spot
+    checks above would miss an error confined to a slot, a row tile or a band of the batch that they do not sample."""
+    import os
+    import threading
+    from oracle import oracle as orc
+    sr, n, nb, B = 16000, 160000, 4, 256
+    m, blob = _model(be, sr, nb)
+    base = [synth_clip(n, sr, 9300 + i) for i in range(8)]
+    gain = 0.3 + 0.7 * ((np.arange(B) * 53) % 97) / 96.0
+    wav = np.stack([np.roll(base[b % 8], 977 * b) * gain[b] for b in range(B)]).astype(np.float32)
+    out = m.enhance_batch(wav, None)
+    m.close()
+    assert np.isfinite(out).all()
+    nthr = max(1, min(len(os.sched_getaffinity(0)), 64))
+    errs = np.full(B, np.inf)
+
+    def work(k):
+        o = orc.Oracle(sr, nb, blob)
+        for b in range(k, B, nthr):
+            errs[b] = rms(out[b] - o.enhance(wav[b]))
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(nthr)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    worst = int(np.argmax(errs))
+    assert errs[worst] < WAVE_TOL, (worst, float(errs[worst]))
+    print(f"256 slots vs oracle: worst {errs.max():.2e} (slot {worst}), median {np.median(errs):.2e}, {nthr} host threads")
+
+
 def test_whole_config3_batch_on_one_gpu(be):
     """configs[2] (dpdfnet4, 2048 clips x 10 s = 2.05 M frames) UNSHARDED through ONE engine call -- what a single
     288 GB GPU is sized for; guards the 64-bit indexing of spectra / frame buffers (B*T*win = 657 M floats), the auto
