@@ -44,6 +44,7 @@
 #include "gru_stack.h"
 #include "fcln_gi.h"
 #include "gru_scan4.h"
+#include "dprnn_hop_block.h"
 #include "small_fused_mfma.h"
 #include "enc_seg.h"
 #include "dec_pyr.h"
@@ -295,6 +296,7 @@ struct Lane {
     // GRU-256 cluster exchange granules: [0] embedding + ERB-decoder cells, [1] DF-decoder cells (they may run concurrently)
     unsigned long long* gru_xbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int gru_xbuf_tiles[5] = {0, 0, 0, 0, 0}; unsigned gru_epoch[5] = {0, 0, 0, 0, 0};
     // stacked decoder pairs (gru256_stack16_kernel): per pair [tiles][Tcap + 2][16][256] granules = cell A's per-frame ring + cell B's two slots
+    unsigned* hop_flags[2] = {nullptr, nullptr}; int hop_flags_n[2] = {0, 0}; unsigned hop_epoch[2] = {0, 0};   // dprnn_hop_block_kernel: [0] DF stack, [1] ERB stack (they run side by side)
     unsigned* arrive[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int arrive_tiles[5] = {0, 0, 0, 0, 0}; unsigned arrive_count[5] = {0, 0, 0, 0, 0};   // gru256_step_kernel
     unsigned long long* gru_sbuf[2] = {nullptr, nullptr}; int gru_sbuf_tiles[2] = {0, 0}, gru_sbuf_T[2] = {0, 0}; unsigned gru_sepoch[2] = {0, 0};
     const float* dbg_e3d = nullptr; const float* dbg_c1d = nullptr; const float* dbg_emb = nullptr; int dbg_B = 0, dbg_Tc = 0, dbg_parity = 0;
@@ -371,6 +373,7 @@ struct dpdf_model {
     int gru256_stack = 1;              // one or two tiles: the two cells of each decoder stack as one wavefront launch (gru_stack.h)
     int tail_frames = 32;              // throughput regime: frames of the short chunk split off a long last chunk (pipeline drain; 0 = off)
     int gru256_step = 1;               // single-hop streaming: input projection + GRUCell(256) step as one launch per cell
+    int hop_fused = 1;                 // ... and that glue in the SAME launch as the scan in front of it (dprnn_hop_block.h): one launch per block
     int hop_glue = 1;                  // single-hop streaming: one glue launch per DPRNN block between the intra-band scans (fcln_gi.h)
     int fcln_gi = 1;                   // small batches: fc + LayerNorm GEMMs of the DPRNN also produce the next recurrence's input projection (fcln_gi.h)
     int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
@@ -1050,6 +1053,47 @@ struct DprnnWalk {
     }
     size_t size() const { return blocks.size(); }
     float* result() const { return x; }
+    HopGlueArgs glue_args(size_t bi) const {
+        const DprnnW& w = blocks[bi];
+        const bool next = bi + 1 < blocks.size();
+        return HopGlueArgs{hcat, x, y, m->C(w.fci_frag), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b),
+                           m->C(w.inter.wfrag), m->C(w.inter.bias), state + soff + (long)bi * Fp * 64, S, 64, Fp,
+                           m->C(w.fce_frag), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b),
+                           gibuf.p, next ? m->C(blocks[bi + 1].intra.ih_frag) : nullptr, next ? m->C(blocks[bi + 1].intra.ih_bias) : nullptr, M};
+    }
+    void after_glue(size_t bi) {
+        intra_gi_ready = bi + 1 < blocks.size();
+        float* freed = x == xin ? xb : x;
+        x = y; y = freed;
+    }
+    // single-hop streaming: the intra-band scan and the glue behind it as ONE launch (dprnn_hop_block.h); false: not available
+    bool hop_block(size_t bi, const Gru64Args& ai) {
+        Lane& L = *m->ln;
+        const int br = df ? 0 : 1, nx = (ai.nrows + 3) / 4;
+        if (!m->d_err) {
+            if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return false;
+            (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->cur);
+        }
+        if (L.hop_flags_n[br] < 2 * nx || L.hop_epoch[br] > 0xF0000000u) {
+            if (L.hop_flags_n[br] < 2 * nx) {
+                if (L.hop_flags[br]) { L.sync_all(); (void)hipFree(L.hop_flags[br]); L.hop_flags[br] = nullptr; L.hop_flags_n[br] = 0; }
+                const int n = std::max(2 * nx, 64);
+                if (hipMalloc((void**)&L.hop_flags[br], (size_t)n * sizeof(unsigned)) != hipSuccess) return false;
+                L.hop_flags_n[br] = n;
+            }
+            (void)hipMemsetAsync(L.hop_flags[br], 0, (size_t)L.hop_flags_n[br] * sizeof(unsigned), m->cur);
+            L.hop_epoch[br] = 0;
+        }
+        const DprnnW& w = blocks[bi];
+        ProfScope ps(m, "dprnn_hop_block");
+        const bool next = bi + 1 < blocks.size();
+        HopBlockArgs ha{ai, m->C(w.intra.hh4), (const float*)gibuf.p, 384, glue_args(bi), L.hop_flags[br], ++L.hop_epoch[br], nx, Fp, m->d_err};
+        const unsigned grid = (unsigned)(2 * nx + (M + 15) / 16);
+        if (next) hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_block_kernel<true>), dim3(grid), dim3(512), 0, m->cur, ha);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_block_kernel<false>), dim3(grid), dim3(512), 0, m->cur, ha);
+        after_glue(bi);
+        return true;
+    }
     void block(size_t bi) {
         const DprnnW& w = blocks[bi];
         bool inter_gi_ready = false;
@@ -1078,7 +1122,9 @@ struct DprnnWalk {
                     BiasActStore<4> ep{gibuf.p, 384, 64, m->C(w.intra.ih_bias), 64, 64, ACT_NONE};
                     launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.intra.ih_frag), ep, M, 64, 6);
                 }
-                if (((ai.nrows + 3) / 4) * 2 <= m->scan4_max_wgs && (size_t)M * 384 < (1u << 30))     // (32-bit lane offsets in the kernel)
+                const bool scan4 = ((ai.nrows + 3) / 4) * 2 <= m->scan4_max_wgs && (size_t)M * 384 < (1u << 30);     // (32-bit lane offsets in the kernel)
+                if (scan4 && hop_glue && m->glue8 && m->hop_fused && hop_block(bi, ai)) return;
+                if (scan4)
                     hipLaunchKernelGGL(gru64_scan4_gi_kernel, dim3((ai.nrows + 3) / 4, 2), dim3(256), 0, m->cur, ai, m->C(w.intra.hh4), (const float*)gibuf.p, 384);
                 else
                     hipLaunchKernelGGL(gru64_scan_gi_kernel, dim3((ai.nrows + 15) / 16, 2), dim3(256), 0, m->cur, ai, (const float*)gibuf.p, 384);
@@ -1091,19 +1137,14 @@ struct DprnnWalk {
                 // intra input projection as ONE launch (fcln_gi.h); the block output goes to y, x0 becomes the free buffer
                 ProfScope ps(m, "dprnn_hop_glue");
                 const bool next = bi + 1 < blocks.size();
-                HopGlueArgs ha{hcat, x, y, m->C(w.fci_frag), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b),
-                               m->C(w.inter.wfrag), m->C(w.inter.bias), state + soff + (long)bi * Fp * 64, S, 64, Fp,
-                               m->C(w.fce_frag), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b),
-                               gibuf.p, next ? m->C(blocks[bi + 1].intra.ih_frag) : nullptr, next ? m->C(blocks[bi + 1].intra.ih_bias) : nullptr, M};
+                const HopGlueArgs ha = glue_args(bi);
                 if (m->glue8) {      // eight waves per tile: half the dependent MFMAs and operand loads per wave (fcln_gi.h)
                     if (next) hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue8_kernel<true>), dim3((M + 15) / 16), dim3(512), 0, m->cur, ha);
                     else hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue8_kernel<false>), dim3((M + 15) / 16), dim3(512), 0, m->cur, ha);
                 }
                 else if (next) hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue_kernel<true>), dim3((M + 15) / 16), dim3(256), 0, m->cur, ha);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_glue_kernel<false>), dim3((M + 15) / 16), dim3(256), 0, m->cur, ha);
-                intra_gi_ready = next;
-                float* freed = x == xin ? xb : x;
-                x = y; y = freed;
+                after_glue(bi);
                 return;
             }
             {   // fc_intra + ln_intra + residual (+ the inter-band cell's input projection)
@@ -1970,6 +2011,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
         L.sync_all();
         L.ws.release();
         for (int k = 0; k < 5; ++k) if (L.gru_xbuf[k]) (void)hipFree(L.gru_xbuf[k]);
+        for (int k = 0; k < 2; ++k) if (L.hop_flags[k]) (void)hipFree(L.hop_flags[k]);
         for (int k = 0; k < 2; ++k) if (L.gru_sbuf[k]) (void)hipFree(L.gru_sbuf[k]);
         for (int k = 0; k < 5; ++k) if (L.arrive[k]) (void)hipFree(L.arrive[k]);
     }
@@ -2075,6 +2117,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "stft_ksplit") m->stft_ksplit = value & 7;
     else if (n == "gru256_step") m->gru256_step = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
+    else if (n == "hop_fused") m->hop_fused = value != 0;
     else if (n == "hop_feat") m->hop_feat = value != 0;
     else if (n == "glue8") m->glue8 = value != 0;
     else if (n == "fuse_gl") m->fuse_gl = value != 0;

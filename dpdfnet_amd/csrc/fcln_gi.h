@@ -13,6 +13,7 @@
 // form to rounding (the same MFMA order per output).
 #pragma once
 #include "common.h"
+#include "gru_scan.h"
 
 struct FclnGiArgs {
     const float* a; int lda;          // fc input rows [M][K1]
@@ -313,8 +314,12 @@ __device__ unsigned long long dpdf_trace_buf[32];
 #else
 #define DPDF_STAMP(i) do {} while (0)
 #endif
-template <bool NEXT>
-__global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
+// HANDOFF (dprnn_hop_block.h): the tile's hcat rows come from scan workgroups of the SAME launch -- everything that does not depend
+// on them (operands, residual rows, carried state) is fetched first, then the tile waits for its scans' flags and reads the rows with
+// agent-scope loads
+struct HopHandoff { const unsigned* flags; unsigned epoch; int nscan_x, Fp; int* err; };
+template <bool NEXT, bool HANDOFF>
+__device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int tile, const HopHandoff& ho) {
     __shared__ __attribute__((aligned(16))) float As[16][132];
     __shared__ __attribute__((aligned(16))) float Fs[2][16][68];
     __shared__ __attribute__((aligned(16))) float Ys[16][68];      // y1, later y2
@@ -323,9 +328,9 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int wc = w & 3, wk = w >> 2;
     const int cl = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * 16;
+    const int row0 = tile * 16;
     DPDF_STAMP(0);
-    {
+    if (!HANDOFF) {
         const int r = tid >> 5, c4 = tid & 31;
         int row = row0 + r; if (row >= g.M) row = g.M - 1;
         *(float4*)&As[r][4 * c4] = *(const float4*)(g.hcat + (size_t)row * 128 + 4 * c4);
@@ -364,6 +369,26 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
         }
     }
     const float bfi = g.fci_b[16 * wc + cl], bfe = g.fce_b[16 * wc + cl];
+    if (HANDOFF) {
+        // scan workgroup x = stream / 4 of either direction has published flag[dir * nscan_x + x] = epoch behind its last row
+        const int last = (row0 + 15 < g.M ? row0 + 15 : g.M - 1);
+        const int x_lo = (row0 / ho.Fp) >> 2, x_hi = (last / ho.Fp) >> 2, nx = x_hi - x_lo + 1;
+        if (tid < 2 * nx) {
+            const unsigned* f = ho.flags + (tid / nx) * ho.nscan_x + x_lo + tid % nx;
+            unsigned spins = 0; bool dead = false;
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ho.epoch) < 0) {
+                if (cluster_spin_expired(spins, ho.err, dead)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 512 * k, r = idx >> 7, c = idx & 127;
+            int row = row0 + r; if (row >= g.M) row = g.M - 1;
+            As[r][c] = __hip_atomic_load(g.hcat + (size_t)row * 128 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     __syncthreads();
     DPDF_STAMP(1);
     auto layer_norm_res = [&](const float4 v, const float4 res, const float* gam, const float* bet) {
@@ -497,4 +522,9 @@ __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
         }
     }
     DPDF_STAMP(9);
+}
+
+template <bool NEXT>
+__global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
+    dprnn_hop_glue8_body<NEXT, false>(g, blockIdx.x, HopHandoff{nullptr, 0u, 0, 1, nullptr});
 }

@@ -48,11 +48,12 @@ __device__ __forceinline__ void quad_transpose4(f32x4& v, bool odd, bool hi) {
     DPDF_M4(V, 8, acc0) DPDF_M4(V, 9, acc1) DPDF_M4(V, 10, acc0) DPDF_M4(V, 11, acc1) DPDF_M4(V, 12, acc0) DPDF_M4(V, 13, acc1) DPDF_M4(V, 14, acc0) DPDF_M4(V, 15, acc1)
 
 // wfrag4: [dir][wave 4][k 64][lane 64] (build_gru64), bias: the 16-row kernels' [dir][4][64]
-__global__ __launch_bounds__(256) void gru64_scan4_gi_kernel(Gru64Args a, const float* wfrag4, const float* gi, int gw) {
+// HANDOFF (dprnn_hop_block.h): h' leaves through agent-scope (write-through) stores and the caller publishes a flag behind them
+template <bool HANDOFF>
+__device__ __forceinline__ void gru64_scan4_body(const Gru64Args& a, const float* wfrag4, const float* gi, int gw, int bx, int dir) {
     __shared__ __attribute__((aligned(16))) float Hs[2][256];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int dir = blockIdx.y;
-    const int row0 = blockIdx.x * 4;
+    const int row0 = bx * 4;
     const int u = lane >> 2, j = lane & 3;
     const bool odd = j & 1, hi = j & 2;
     float wk[64];
@@ -115,7 +116,10 @@ __global__ __launch_bounds__(256) void gru64_scan4_gi_kernel(Gru64Args a, const 
         const float h = gru64_cell(acc[0], acc[1], acc[3], acc[2], h_own);
         h_own = h;
         Hs[buf ^ 1][lane * 4 + w] = h;
-        if (ok) ocur[o_off] = h;
+        if (ok) {
+            if (HANDOFF) __hip_atomic_store(ocur + o_off, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else ocur[o_off] = h;
+        }
         ocur += odelta;
         __syncthreads();
         buf ^= 1;
@@ -129,4 +133,8 @@ __global__ __launch_bounds__(256) void gru64_scan4_gi_kernel(Gru64Args a, const 
     for (int d = 0; d < PF - 1; ++d)
         if (s + d < a.nsteps) step(s + d, g[d]);
     if (hp && ok) *hp = h_own;
+}
+
+__global__ __launch_bounds__(256) void gru64_scan4_gi_kernel(Gru64Args a, const float* wfrag4, const float* gi, int gw) {
+    gru64_scan4_body<false>(a, wfrag4, gi, gw, blockIdx.x, blockIdx.y);
 }

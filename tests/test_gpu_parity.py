@@ -438,14 +438,15 @@ def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
     """Everything a single streaming hop does differently from a general call -- stage 2 on the main stream, staging + FIFO import
     + state copy as one prologue launch, one combined FIFO export behind the overlap-add (the host waits for the output event
     only), the decoders' GRU-256 steps pairwise in one launch, the DF decoder's pathway conv inside the front-end launch, the
-    encoder / decoder pyramids -- against the same streams with all of it switched off, on fresh models: audio equal to rounding
+    encoder / decoder pyramids, a DPRNN block's scan and glue as one launch -- against the same streams with all of it switched off, on fresh models: audio equal to rounding
     hop by hop, and so is every stream's state afterwards (read right after the last hop: the getter must see the late export)."""
     from dpdfnet_amd.weights import synth_blob
     blob = synth_blob(be.manifest(sr, nb), 4711)
     rng = np.random.default_rng(5)
     runs = {}
-    for tag, opts in (("hop", {}), ("plain", {"single_chunk_inline": 0, "hop_prologue": 0, "late_export": 0, "dual_step": 0, "hop_pconv": 0,
-                                               "fuse_enc": 0, "fuse_dec": 0, "snapshot": 0})):
+    for tag, opts in (("hop", {}), ("two_launch", {"hop_fused": 0}),
+                      ("plain", {"single_chunk_inline": 0, "hop_prologue": 0, "late_export": 0, "dual_step": 0, "hop_pconv": 0,
+                                 "fuse_enc": 0, "fuse_dec": 0, "snapshot": 0, "hop_fused": 0})):
         m = be.HipModel(sr, nb, blob, 0)
         for k, v in opts.items():
             m.set_option(k, v)
@@ -461,6 +462,10 @@ def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
     for a_, b_ in zip(runs["hop"][0], runs["plain"][0]):
         assert a_.shape == b_.shape and rms(a_ - b_) < 1e-6
     assert np.abs(runs["hop"][1] - runs["plain"][1]).max() < 5e-5
+    # scan + glue of a DPRNN block as one launch (dprnn_hop_block.h) against the two launches: the same arithmetic, bit for bit
+    for a_, b_ in zip(runs["hop"][0], runs["two_launch"][0]):
+        np.testing.assert_array_equal(a_, b_)
+    np.testing.assert_array_equal(runs["hop"][1], runs["two_launch"][1])
 
 
 def test_every_gru256_scan_form_agrees(be):
