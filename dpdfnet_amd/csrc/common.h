@@ -59,3 +59,8 @@ __device__ __forceinline__ float row16_allreduce_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
     return v;
 }
+
+#ifdef DPDF_PHASE_TRACE
+// timing builds only (tools/glue_trace.py): s_memtime stamps of one workgroup per role of the streaming hop's DPRNN launches
+__device__ unsigned long long dpdf_trace_buf[32];
+#endif

@@ -37,6 +37,9 @@ __global__ __launch_bounds__(512) void dprnn_hop_block_kernel(HopBlockArgs b) {
         __builtin_amdgcn_s_waitcnt(0);                 // every store of this wave has been acknowledged
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(b.flags + dir * b.nscan_x + x, b.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef DPDF_PHASE_TRACE
+        if (NEXT && b.Fp >= 48 && blockIdx.x == 0 && threadIdx.x == 0) dpdf_trace_buf[19] = __builtin_amdgcn_s_memtime();
+#endif
     } else {
         dprnn_hop_glue8_body<NEXT, true>(b.glue, (int)blockIdx.x - nscan, HopHandoff{b.flags, b.epoch, b.nscan_x, b.Fp, b.err});
     }

@@ -309,8 +309,7 @@ __global__ __launch_bounds__(256) void dprnn_hop_glue_kernel(HopGlueArgs g) {
 //   (direction x gate, column tile) pairs (48 MFMAs) -- 120 MFMAs and 120 weight registers per wave.
 // Same operands, same packings; sums are taken in a different order than the four-wave form (equal to rounding).
 #ifdef DPDF_PHASE_TRACE
-__device__ unsigned long long dpdf_trace_buf[32];
-#define DPDF_STAMP(i) do { if (NEXT && blockIdx.x == 0 && threadIdx.x == 0) dpdf_trace_buf[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DPDF_STAMP(i) do { if (NEXT && g.rdiv >= 48 && tile == 0 && threadIdx.x == 0) dpdf_trace_buf[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DPDF_STAMP(i) do {} while (0)
 #endif

@@ -49,11 +49,17 @@ __device__ __forceinline__ void quad_transpose4(f32x4& v, bool odd, bool hi) {
 
 // wfrag4: [dir][wave 4][k 64][lane 64] (build_gru64), bias: the 16-row kernels' [dir][4][64]
 // HANDOFF (dprnn_hop_block.h): h' leaves through agent-scope (write-through) stores and the caller publishes a flag behind them
+#ifdef DPDF_PHASE_TRACE
+#define DPDF_SSTAMP(i) do { if (HANDOFF && a.nsteps >= 48 && bx == 0 && dir == 0 && threadIdx.x == 0) dpdf_trace_buf[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DPDF_SSTAMP(i) do {} while (0)
+#endif
 template <bool HANDOFF>
 __device__ __forceinline__ void gru64_scan4_body(const Gru64Args& a, const float* wfrag4, const float* gi, int gw, int bx, int dir) {
     __shared__ __attribute__((aligned(16))) float Hs[2][256];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int row0 = bx * 4;
+    DPDF_SSTAMP(16);
     const int u = lane >> 2, j = lane & 3;
     const bool odd = j & 1, hi = j & 2;
     float wk[64];
@@ -98,6 +104,7 @@ __device__ __forceinline__ void gru64_scan4_body(const Gru64Args& a, const float
         if (d + 1 < a.nsteps) gnext += gdelta;                                          // (clamped at the last step)
     }
     __syncthreads();
+    DPDF_SSTAMP(17);
     int buf = 0;
     auto step = [&](int s, float (&gs)[4]) {
         f32x4 acc0, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -132,6 +139,7 @@ __device__ __forceinline__ void gru64_scan4_body(const Gru64Args& a, const float
 #pragma unroll
     for (int d = 0; d < PF - 1; ++d)
         if (s + d < a.nsteps) step(s + d, g[d]);
+    DPDF_SSTAMP(18);
     if (hp && ok) *hp = h_own;
 }
 
