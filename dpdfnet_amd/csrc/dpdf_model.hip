@@ -216,7 +216,7 @@ BnFold fold_bn(const Blob& B, const std::string& p, int ch) {
 struct SepConvW { size_t dw, pwfrag, bias; int nsub; };        // arena offsets
 struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs;
-                size_t hh4;                   // W_hh for the 4-row scan (gru_scan4.h): [dir][wave 4][k 64][lane 4u+j]: gate j of unit 16 wave + u (j = 3: zero)
+                size_t hh4;                   // W_hh for the 4-row scan (gru_scan4.h): [dir][wave 4][instruction 64][lane 4b+i]: gate i of unit 16 wave + b (i = 3: zero)
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
 struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
 struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn, ih_as_hh; };   // ih_as_hh: W_ih packed like hh_frag (second cell of a stacked pair, gru_stack.h)   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
@@ -623,12 +623,15 @@ GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::str
         }
     }
     g.wfrag = A.add(frag); g.bias = A.add(bias);
-    {   // 4-row scan (gru_scan4.h): B operand of k-step k of wave w, lane 4u + j = scaled W_hh[gate j][unit 16w + u][k]
+    {   // 4-row scan (gru_scan4.h): A operand of instruction t = 4m + g of wave w, lane 4b + i = scaled W_hh[gate i][unit 16w + b][k],
+        // k = 4m + ((g + b) & 3) -- the k that block b meets under the B operand's lane-group broadcast g (i = 3: zero)
         std::vector<float> f4((size_t)g.ndirs * 4 * 64 * 64, 0.f);
         for (int d = 0; d < g.ndirs; ++d) {
             const float* whh = B.get(dirs[d].first + ".weight_hh" + dirs[d].second);
-            for (int w = 0; w < 4; ++w) for (int k = 0; k < 64; ++k) for (int u = 0; u < 16; ++u) for (int j = 0; j < 3; ++j)
-                f4[(((size_t)(d * 4 + w) * 64) + k) * 64 + 4 * u + j] = whh[(size_t)(j * 64 + 16 * w + u) * 64 + k] * gate_scale[j];
+            for (int w = 0; w < 4; ++w) for (int t = 0; t < 64; ++t) for (int b = 0; b < 16; ++b) for (int i = 0; i < 3; ++i) {
+                const int k = 4 * (t >> 2) + (((t & 3) + b) & 3);
+                f4[(((size_t)(d * 4 + w) * 64) + t) * 64 + 4 * b + i] = whh[(size_t)(i * 64 + 16 * w + b) * 64 + k] * gate_scale[i];
+            }
         }
         g.hh4 = A.add(f4);
     }
@@ -1123,7 +1126,8 @@ struct DprnnWalk {
                     launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w.intra.ih_frag), ep, M, 64, 6);
                 }
                 const bool scan4 = ((ai.nrows + 3) / 4) * 2 <= m->scan4_max_wgs && (size_t)M * 384 < (1u << 30);     // (32-bit lane offsets in the kernel)
-                if (scan4 && hop_glue && m->glue8 && m->hop_fused && hop_block(bi, ai)) return;
+                // (use_gru256_cluster = 0 is the recovery re-run: no kernel that waits for another workgroup)
+                if (scan4 && hop_glue && m->glue8 && m->hop_fused && m->use_gru256_cluster && hop_block(bi, ai)) return;
                 if (scan4)
                     hipLaunchKernelGGL(gru64_scan4_gi_kernel, dim3((ai.nrows + 3) / 4, 2), dim3(256), 0, m->cur, ai, m->C(w.intra.hh4), (const float*)gibuf.p, 384);
                 else

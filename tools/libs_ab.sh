@@ -6,7 +6,7 @@ for rep in 1 2 3; do
   for cfg in $CFGS; do
     line="$cfg"
     for so in "$@"; do
-      v=$(DPDFNET_HIP_LIB=$(realpath $so) python bench.py --side-config $cfg 2>/dev/null | grep '^SIDE' | python -c "import sys,json; d=json.loads(sys.stdin.read()[5:]); print(d.get('us_per_call', d.get('ms_per_step')))")
+      v=$(DPDFNET_HIP_LIB=$(realpath $so) python bench.py --side-config $cfg 2>/dev/null | grep '^SIDE' | python -c "import sys,json; d=json.loads(sys.stdin.read()[5:]); print(d.get('us_per_call', d.get('ms_per_step', d.get('ms_per_call'))))")
       line="$line  $(basename $so) $v"
     done
     echo "$line"
