@@ -324,6 +324,7 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
     __shared__ __attribute__((aligned(16))) float Ys[16][68];      // y1, later y2
     __shared__ __attribute__((aligned(16))) float Hs[16][68];      // h, later h'
     __shared__ __attribute__((aligned(16))) float Gs[4][3][4][64]; // h-part accumulators of the wk = 1 waves
+    __shared__ __attribute__((aligned(16))) float Ln[4][64];       // LayerNorm gains / shifts (intra g, b; inter g, b): fetched at entry, read from LDS in their phases
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int wc = w & 3, wk = w >> 2;
     const int cl = lane & 15, q = lane >> 4;
@@ -333,6 +334,10 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
         const int r = tid >> 5, c4 = tid & 31;
         int row = row0 + r; if (row >= g.M) row = g.M - 1;
         *(float4*)&As[r][4 * c4] = *(const float4*)(g.hcat + (size_t)row * 128 + 4 * c4);
+    }
+    if (tid < 256) {                                                 // (a load issued inside a phase costs its L2 -- or, first touch on this XCD, memory -- latency there)
+        const float* src = tid < 64 ? g.lni_g : (tid < 128 ? g.lni_b : (tid < 192 ? g.lne_g : g.lne_b));
+        Ln[tid >> 6][tid & 63] = src[tid & 63];
     }
     const bool ln_role = tid < 256;                                  // row-contiguous pieces: row tid >> 4, columns 4 (tid & 15) .. + 3
     const int rr = (tid >> 4) & 15, rc4 = 4 * (tid & 15);
@@ -368,6 +373,11 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
         }
     }
     const float bfi = g.fci_b[16 * wc + cl], bfe = g.fce_b[16 * wc + cl];
+    float bih[3] = {0.f, 0.f, 0.f};
+    if (NEXT) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { const int pr = w + 8 * p; bih[p] = g.ih_bias[(pr >> 2) * 64 + (pr & 3) * 16 + cl]; }
+    }
     if (HANDOFF) {
         // scan workgroup x = stream / 4 of either direction has published flag[dir * nscan_x + x] = epoch behind its last row
         const int last = (row0 + 15 < g.M ? row0 + 15 : g.M - 1);
@@ -423,7 +433,7 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
     float4 y1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ln_role) {
         const float4 u = *(const float4*)&Fs[0][rr][rc4], v2 = *(const float4*)&Fs[1][rr][rc4];
-        y1 = layer_norm_res(make_float4(u.x + v2.x, u.y + v2.y, u.z + v2.z, u.w + v2.w), xres, g.lni_g, g.lni_b);
+        y1 = layer_norm_res(make_float4(u.x + v2.x, u.y + v2.y, u.z + v2.z, u.w + v2.w), xres, Ln[0], Ln[1]);
         *(float4*)&Ys[rr][rc4] = y1;
     }
     __syncthreads();
@@ -488,7 +498,7 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
     DPDF_STAMP(7);
     if (ln_role) {
         const float4 u = *(const float4*)&Fs[0][rr][rc4], v2 = *(const float4*)&Fs[1][rr][rc4];
-        const float4 y2 = layer_norm_res(make_float4(u.x + v2.x, u.y + v2.y, u.z + v2.z, u.w + v2.w), y1, g.lne_g, g.lne_b);
+        const float4 y2 = layer_norm_res(make_float4(u.x + v2.x, u.y + v2.y, u.z + v2.z, u.w + v2.w), y1, Ln[2], Ln[3]);
         if (rok) *(float4*)(g.y2 + (size_t)(row0 + rr) * 64 + rc4) = y2;
         if (NEXT) *(float4*)&Ys[rr][rc4] = y2;   // the x-part waves read y1 out of Ys three barriers ago
     }
@@ -509,10 +519,13 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
 #pragma unroll
                 for (int p = 0; p < 3; ++p) acc[p] = mfma16(yv[kb], fih[NEXT ? p * 16 + c * 4 + kb : 0], acc[p]);
         }
+#ifdef DPDF_PHASE_TRACE
+        if (g.rdiv >= 48 && tile == 0 && threadIdx.x == 0) { asm volatile("s_nop 7\n s_nop 7" ::: "memory"); dpdf_trace_buf[10] = __builtin_amdgcn_s_memtime() + (unsigned long long)(acc[0][0] == 12345.f); }
+#endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int pr = w + 8 * p, col = (pr >> 2) * 64 + (pr & 3) * 16 + cl;
-            const float bv = g.ih_bias[col];
+            const float bv = bih[p];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + 4 * q + i;

@@ -20,11 +20,13 @@ for sr, nb, S in ((16000, 2, 1), (48000, 8, 64)):
         m._L.dpdf_debug_trace.argtypes = [ctypes.c_void_p]
         m._L.dpdf_debug_trace(buf)
         t = np.array(buf[:10], dtype=np.int64)
+        t10 = int(buf[10]) - int(buf[8])
         ts = np.array(buf[16:20], dtype=np.int64)      # scan role of the one-launch form (dprnn_hop_block.h): entry, first step, behind the last step, flag out
-        d = np.concatenate([np.diff(t), np.diff(ts)])
+        d = np.concatenate([np.diff(t), np.diff(ts), [t10]])
         if i >= 10: acc = d if acc is None else acc + d
     a = (acc / 20).astype(int).tolist()
     print(sr, nb, S, "s_memtime ticks (~shader clock; counters of different XCDs are not comparable) between stamps, avg of 20 hops, last <true> launch of the DF stack:")
     print("   glue tile 0: entry -> operands in + rows in -> fc_intra -> LN -> ... -> exit:", a[:9])
     print("   scan (0, fwd): entry -> first step -> behind the last step -> flag out:", a[9:12])
+    print("   glue: stamp 8 -> matrix part of the next projection done:", a[12])
     st.close(); m.close()

@@ -6,6 +6,9 @@
 #include <cstdlib>
 #include <vector>
 #include "gru_scan4.h"
+__global__ __launch_bounds__(256) void scan4_handoff_kernel(Gru64Args a, const float* wfrag4, const float* gi, int gw) {
+    gru64_scan4_body<true>(a, wfrag4, gi, gw, blockIdx.x, blockIdx.y);      // h' through agent-scope (write-through) stores, as in dprnn_hop_block.h
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 int main(int argc, char** argv) {
     const int rows = argc > 1 ? atoi(argv[1]) : 64;
@@ -37,6 +40,13 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost));
         double cs = 0; for (float v : out) cs += v;
         printf("rows %d nsteps %d: %.2f us per launch, %.3f us per step incl. launch; checksum %.6f\n", rows, nsteps, 1e3 * ms / reps, 1e3 * ms / reps / nsteps, cs);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(scan4_handoff_kernel, dim3((rows + 3) / 4, 2), dim3(256), 0, 0, a, dw, (const float*)dgi, 384);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(scan4_handoff_kernel, dim3((rows + 3) / 4, 2), dim3(256), 0, 0, a, dw, (const float*)dgi, 384);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("   with write-through stores: %.2f us per launch, %.3f us per step incl. launch\n", 1e3 * ms / reps, 1e3 * ms / reps / nsteps);
         (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dgi); (void)hipFree(dout);
     }
     return 0;
