@@ -378,7 +378,32 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
 #pragma unroll
         for (int p = 0; p < 3; ++p) { const int pr = w + 8 * p; bih[p] = g.ih_bias[(pr >> 2) * 64 + (pr & 3) * 16 + cl]; }
     }
+    // inter-band GRUCell step, one operand: wk = 0 W_ih . y1 (+ input-side biases), wk = 1 W_hh . h (+ b_hn) -- three accumulators
+    f32x4 a0, a1, a2;
+    auto gru_part = [&](const float (*src)[68]) {
+        if (wk == 0) { a0 = (f32x4){b_r, b_r, b_r, b_r}; a1 = (f32x4){b_z, b_z, b_z, b_z}; a2 = (f32x4){b_in, b_in, b_in, b_in}; }
+        else { a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0; a2 = (f32x4){b_hn, b_hn, b_hn, b_hn}; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 x4 = *(const float4*)&src[cl][16 * c + 4 * q];
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                a0 = mfma16(xv[kb], wg[0][c * 4 + kb], a0);
+                a1 = mfma16(xv[kb], wg[1][c * 4 + kb], a1);
+                a2 = mfma16(xv[kb], wg[2][c * 4 + kb], a2);
+            }
+        }
+        if (wk == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { Gs[wc][0][i][lane] = a0[i]; Gs[wc][1][i][lane] = a1[i]; Gs[wc][2][i][lane] = a2[i]; }
+        }
+    };
     if (HANDOFF) {
+        // the h part of the cell step depends on the carried state only: its 48 matrix instructions per wave run while the scans do
+        // (they share the SIMDs' matrix pipes with the x part otherwise: 3 072 of the phase's 3 600 cycles)
+        __syncthreads();
+        if (wk == 1) gru_part(Hs);
         // scan workgroup x = stream / 4 of either direction has published flag[dir * nscan_x + x] = epoch behind its last row
         const int last = (row0 + 15 < g.M ? row0 + 15 : g.M - 1);
         const int x_lo = (row0 / ho.Fp) >> 2, x_hi = (last / ho.Fp) >> 2, nx = x_hi - x_lo + 1;
@@ -441,25 +466,7 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
     // ---- inter-band GRUCell step: wk = 0 the x part, wk = 1 the h part
     float hn[4];
     {
-        f32x4 a0, a1, a2;
-        if (wk == 0) { a0 = (f32x4){b_r, b_r, b_r, b_r}; a1 = (f32x4){b_z, b_z, b_z, b_z}; a2 = (f32x4){b_in, b_in, b_in, b_in}; }
-        else { a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = a0; a2 = (f32x4){b_hn, b_hn, b_hn, b_hn}; }
-        const float (*src)[68] = wk ? Hs : Ys;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 x4 = *(const float4*)&src[cl][16 * c + 4 * q];
-            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                a0 = mfma16(xv[kb], wg[0][c * 4 + kb], a0);
-                a1 = mfma16(xv[kb], wg[1][c * 4 + kb], a1);
-                a2 = mfma16(xv[kb], wg[2][c * 4 + kb], a2);
-            }
-        }
-        if (wk == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { Gs[wc][0][i][lane] = a0[i]; Gs[wc][1][i][lane] = a1[i]; Gs[wc][2][i][lane] = a2[i]; }
-        }
+        if (!HANDOFF || wk == 0) gru_part(wk ? Hs : Ys);
         __syncthreads();
         DPDF_STAMP(4);
         if (wk == 0) {
