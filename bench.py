@@ -348,14 +348,15 @@ def other_configs(only=None) -> dict:
         d = backend.query_dims(sr_, nb_)
         # Latency model of a hop: the two branches run side by side, each a chain of nb x (F' dependent
         # GRU-64 steps + one glue launch); the DF branch (F' = 48) is the longer one.  Measured minima on this chip
-        # (rocprofv3 trace of single hops, profiles/r*_stream_hop_*): 0.55 us per 4-row scan step (64 x 8.4-cycle
-        # v_mfma_f32_4x4x1 + one LDS round trip + the gate chain), ~1.5 us per dependent kernel boundary.
+        # (tools/scan4_bench.hip, rocprofv3 traces of single hops, profiles/r*_stream_hop_*): 0.41 us per 4-row scan step (64 x
+        # 8.4-cycle v_mfma_f32_4x4x1 + one LDS round trip + the gate chain; 0.55 until round 4), ~1.5 us per dependent kernel boundary.
         # Launches on the chain of a one-chunk call (main stream; the decoders one after the other): prologue / import, STFT,
-        # features, encoder front end (+ projection at 48 kHz x 64), nb x (scan, glue), emb_in, 5 GRU-256 steps, emb_out, df_out,
-        # pathway conv, dec_in, decoder pyramid, mask + deep filter, iSTFT, overlap-add = 2 nb + 19 (it was 2 nb + 30 at mid-round).
+        # features, encoder front end (+ projection at 48 kHz x 64), nb x (scan + glue in one launch, dprnn_hop_block.h), emb_in,
+        # 5 GRU-256 steps, emb_out, df_out, pathway conv, dec_in, decoder pyramid, mask + deep filter, iSTFT, overlap-add = nb + 19
+        # (2 nb + 19 until round 4, 2 nb + 30 in round 3).
         steps = nb_ * d.Fd
-        chain = 2 * nb_ + 19
-        bound_us = steps * 0.55 + chain * 1.5
+        chain = nb_ + 19
+        bound_us = steps * 0.41 + chain * 1.5
         return {"us_per_call": round(1e6 * dt, 1), "frames_per_s": round(S / dt), "rtf": round(dt / (hop / sr_), 4),
                 "mfma_frac": mfma(S / dt, sr_, nb_),
                 "latency_model": {"dependent_gru64_steps": steps, "dependent_launches_on_critical_path": chain,
