@@ -41,3 +41,42 @@ def test_random_host_calls_pipelined_equal_plain():
     rec = mod.run(10.0, 20260929)
     assert not rec.get("FAIL"), rec
     assert rec["cases"] >= 3 and rec["cases_with_pipelined_shape"] >= 1, rec
+
+
+def test_two_engines_hop_side_by_side_without_a_timeout():
+    """Two engine handles (two host threads, 64 x 48 kHz dpdfnet8 streams and 40 x 16 kHz dpdfnet4 streams) hop at the same time:
+    their one-launch DPRNN blocks (dprnn_hop_block.h: glue tiles wait for the scans of their OWN launch) and GRU-256 step kernels share
+    the chip.  Forward progress must not depend on having it alone: every hop equals the same engine run by itself, bit for bit, and
+    no call went through the time-out / recovery path."""
+    import threading
+    import numpy as np
+    from dpdfnet_amd import backend as be
+    from dpdfnet_amd.weights import synth_blob
+
+    def session(sr, nb, S, hops, out, barrier=None):
+        m = be.HipModel(sr, nb, synth_blob(be.manifest(sr, nb), 20260417), 0)
+        st = be.HipStreams(m, S)
+        r = np.random.default_rng(sr + nb)
+        st.prime((0.05 * r.standard_normal((S, m.hop))).astype(np.float32))
+        if barrier is not None:
+            barrier.wait()
+        res = [st.process((0.05 * r.standard_normal((S, m.hop))).astype(np.float32)).copy() for _ in range(hops)]
+        out.append((res, int(m.recovery_count)))
+        st.close(); m.close()
+
+    cfgs = [(48000, 8, 64, 150), (16000, 4, 40, 300)]
+    alone = []
+    for c in cfgs:
+        o = []; session(*c, o); alone.append(o[0])
+    bar = threading.Barrier(2)
+    outs = [[], []]
+    ths = [threading.Thread(target=session, args=(*c, outs[i], bar)) for i, c in enumerate(cfgs)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for i in range(2):
+        res, rec = outs[i][0]
+        assert rec == 0 and alone[i][1] == 0, (i, rec)
+        for a_, b_ in zip(res, alone[i][0]):
+            np.testing.assert_array_equal(a_, b_)
