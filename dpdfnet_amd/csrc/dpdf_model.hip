@@ -277,6 +277,11 @@ struct Workspace {
 // One independent execution lane: its own streams, events, workspace and GRU-256 exchange buffer.
 // Clips are independent, so a batch is split over two lanes whose kernels the GPU interleaves:
 // HBM-bound phases of one lane run under MFMA-bound scans of the other.
+// Engine handles alive in this process.  HIP multiplexes the streams of ALL handles onto a few hardware queues, and a queue runs its
+// kernels in order: a kernel that WAITS for a kernel of another stream (the counter join of a streaming hop, run_stage1) is only
+// safe while no other handle's kernels can sit between the two in a shared queue -- with several handles alive it is not used.
+static std::atomic<int> g_live_models{0};
+
 struct Lane {
     hipStream_t sA = nullptr, sB = nullptr, sC = nullptr, sD = nullptr;   // sD: DF-decoder half of stage 2
     void sync_all() const {
@@ -296,6 +301,7 @@ struct Lane {
     // GRU-256 cluster exchange granules: [0] embedding + ERB-decoder cells, [1] DF-decoder cells (they may run concurrently)
     unsigned long long* gru_xbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int gru_xbuf_tiles[5] = {0, 0, 0, 0, 0}; unsigned gru_epoch[5] = {0, 0, 0, 0, 0};
     // stacked decoder pairs (gru256_stack16_kernel): per pair [tiles][Tcap + 2][16][256] granules = cell A's per-frame ring + cell B's two slots
+    unsigned* join_ctr = nullptr; unsigned join_total = 0; bool join_want = false, join_armed = false;   // streaming hop: stage 2's first kernel waits for the ERB stack's last block by counter, not by event
     unsigned* hop_flags[2] = {nullptr, nullptr}; int hop_flags_n[2] = {0, 0}; unsigned hop_epoch[2] = {0, 0};   // dprnn_hop_block_kernel: [0] DF stack, [1] ERB stack (they run side by side)
     unsigned* arrive[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int arrive_tiles[5] = {0, 0, 0, 0, 0}; unsigned arrive_count[5] = {0, 0, 0, 0, 0};   // gru256_step_kernel
     unsigned long long* gru_sbuf[2] = {nullptr, nullptr}; int gru_sbuf_tiles[2] = {0, 0}, gru_sbuf_T[2] = {0, 0}; unsigned gru_sepoch[2] = {0, 0};
@@ -373,6 +379,8 @@ struct dpdf_model {
     int gru256_stack = 1;              // one or two tiles: the two cells of each decoder stack as one wavefront launch (gru_stack.h)
     int tail_frames = 32;              // throughput regime: frames of the short chunk split off a long last chunk (pipeline drain; 0 = off)
     int gru256_step = 1;               // single-hop streaming: input projection + GRUCell(256) step as one launch per cell
+    bool counted = false;              // this handle is in g_live_models
+    int hop_spin_join = 1;             // ... and stage 2's emb_in waits for the ERB stack's last block by a counter instead of a cross-stream event (~10 us)
     int hop_fused = 1;                 // ... and that glue in the SAME launch as the scan in front of it (dprnn_hop_block.h): one launch per block
     int hop_glue = 1;                  // single-hop streaming: one glue launch per DPRNN block between the intra-band scans (fcln_gi.h)
     int fcln_gi = 1;                   // small batches: fc + LayerNorm GEMMs of the DPRNN also produce the next recurrence's input projection (fcln_gi.h)
@@ -1030,6 +1038,16 @@ void run_gru256(dpdf_model* m, const Gru256W& g, const float* x, float* out, flo
 // stream pipeline of a big batch (256 clips, ERB branch, 128 tiles: 125.6 -> 128.7 ms/step), so it is used below 64.
 // xin is read only (it stays valid for its other consumers: e3 is the decoder's skip input); the blocks ping-pong
 // between xa and xb, so no staging copy of the input is needed.
+// geometry of the grouped linears around the GRU-256 cells that the chained small-launch kernels (small_fused_mfma.h) are written for
+static bool small_gl_dims(const dpdf_model* m) {
+    const dpdf_dims& d = m->d;
+    return m->enc_lin_in.Ig == 64 && m->enc_lin_in.Og == 16 && m->df_fc_emb.Og == 16 && m->df_fc_emb.Ig == 96 &&
+                         (!d.is48 || (m->enc_erb_fc.Og == 16 && m->enc_erb_fc.Ig == 80)) &&
+                         m->enc_lin_out.Ig == 16 && m->enc_lin_out.Og == 32 && m->ed_lin_in.Ig == 32 && m->ed_lin_in.Og == 16 &&
+                         m->df_skip.Ig == 32 && m->df_skip.Og == 16 && m->df_lin_in.Ig == 64 && m->df_lin_in.Og == 32 && m->df_lin_in.G == 8 &&
+                         m->ed_lin_out.Ig == 16 && m->ed_lin_out.Og == 32 && (!d.is48 || (m->ed_erb_fc.Ig == 16 && m->ed_erb_fc.Og == 80)) &&
+                         (d.is48 || d.F3 * 64 == 512);
+}
 // One DPRNN stack as a walk over its blocks: block(bi) enqueues block bi on m->cur.  The two encoder branches are walked
 // alternately by run_stage1 (the DF stack on the main stream, the ERB stack on its own), so that in the latency regime -- where
 // the host is only just ahead of the GPU -- neither chain waits for the other one's ~20 launches to be enqueued.
@@ -1090,7 +1108,17 @@ struct DprnnWalk {
         const DprnnW& w = blocks[bi];
         ProfScope ps(m, "dprnn_hop_block");
         const bool next = bi + 1 < blocks.size();
-        HopBlockArgs ha{ai, m->C(w.intra.hh4), (const float*)gibuf.p, 384, glue_args(bi), L.hop_flags[br], ++L.hop_epoch[br], nx, Fp, m->d_err};
+        unsigned* done = nullptr;
+        if (!next && !df && L.join_want) {
+            if (!L.join_ctr) {
+                if (hipMalloc((void**)&L.join_ctr, sizeof(unsigned)) != hipSuccess) return false;
+                // zeroed and VISIBLE before anything can poll or bump it (this stack's launch and stage 2's emb_in sit on two streams)
+                if (hipMemset(L.join_ctr, 0, sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+                L.join_total = 0;
+            }
+            done = L.join_ctr; L.join_total += (unsigned)((M + 15) / 16); L.join_armed = true;
+        }
+        HopBlockArgs ha{ai, m->C(w.intra.hh4), (const float*)gibuf.p, 384, glue_args(bi), L.hop_flags[br], ++L.hop_epoch[br], nx, Fp, m->d_err, done};
         const unsigned grid = (unsigned)(2 * nx + (M + 15) / 16);
         if (next) hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_block_kernel<true>), dim3(grid), dim3(512), 0, m->cur, ha);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(dprnn_hop_block_kernel<false>), dim3(grid), dim3(512), 0, m->cur, ha);
@@ -1325,6 +1353,11 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     DprnnWalk wdf(m, m->dprnn_df, x.c1.p, x.xd_a.p, x.xd_b.p, w.hcat.p, w.hin.p, w.gi64, d.Fd, state, S, L.dprnn_df, B, Tc);
     DprnnWalk werb(m, m->dprnn_erb, x.e3.p, x.xe_a.p, x.xe_b.p, w.hcat_e.p, w.hin_e.p, w.gi64_e, d.F3, state, S, L.dprnn_erb, B, Tc);
     if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_fk[c.parity], sA)); HIP_TRY(hipStreamWaitEvent(sC, m->ln->ev_fk[c.parity], 0)); }
+    // A streaming hop: the first kernel of stage 2 (emb_in, on this stream) waits for the ERB stack's last block by a counter that
+    // block's tiles bump (DprnnWalk::hop_block) -- a kernel that waits for an EVENT of another stream starts ~10 us after it
+    m->ln->join_want = m->hop_spin_join && g_live_models.load() == 1 && sC != sA && m->ln->single_chunk && Tc == 1 && d.nb > 0 && m->fuse_small && m->fuse_gl &&
+                       BT <= SMALL_M_ROWS && small_gl_dims(m);
+    m->ln->join_armed = false;
     // the small-launch forms of the two front ends (enc_seg.h), with the first DPRNN block's input projection riding along
     const bool small_enc = m->fuse_small && m->fuse_enc && BT <= m->enc_seg_rows;
     const bool df_seg_ok = small_enc && d.D == 2 * d.Fd && d.Fd % 16 == 0;
@@ -1409,7 +1442,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         x.c1d = wdf.result(); x.e3d = werb.result();
     }
     m->cur = sA;
-    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_jn[c.parity], sC)); HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_jn[c.parity], 0)); }
+    if (sC != sA) { HIP_TRY(hipEventRecord(m->ln->ev_jn[c.parity], sC)); if (!m->ln->join_armed) HIP_TRY(hipStreamWaitEvent(sA, m->ln->ev_jn[c.parity], 0)); }
     // stage 2 may start here: the FIFO export below only reads stage-1 tensors that stage 2 does not write, and writes state
     // segments stage 2 does not touch -- it runs beside the first kernels of stage 2 instead of in front of them
     if ((m->overlap & 1) && !m->ln->single_chunk) HIP_TRY(hipEventRecord(m->ln->ev_s1[c.parity], sA));      // (its only waiter: stage 2 on the stage-2 stream)
@@ -1549,18 +1582,16 @@ int run_stage2(dpdf_model* m, const ChunkArgs& c) {
     // Small launches (<= 512 rows): the grouped linears chained in one launch each, per 16-row tile on the matrix cores
     // (small_fused_mfma.h).  (A per-row VALU form was measured too: equal for one row, worse from a few dozen rows on -- every
     // row's workgroup re-reads all weights: 64 x 48 kHz streams 313 -> 340 us -- and is gone.)
-    const bool gl_dims = m->enc_lin_in.Ig == 64 && m->enc_lin_in.Og == 16 && m->df_fc_emb.Og == 16 && m->df_fc_emb.Ig == 96 &&
-                         (!d.is48 || (m->enc_erb_fc.Og == 16 && m->enc_erb_fc.Ig == 80)) &&
-                         m->enc_lin_out.Ig == 16 && m->enc_lin_out.Og == 32 && m->ed_lin_in.Ig == 32 && m->ed_lin_in.Og == 16 &&
-                         m->df_skip.Ig == 32 && m->df_skip.Og == 16 && m->df_lin_in.Ig == 64 && m->df_lin_in.Og == 32 && m->df_lin_in.G == 8 &&
-                         m->ed_lin_out.Ig == 16 && m->ed_lin_out.Og == 32 && (!d.is48 || (m->ed_erb_fc.Ig == 16 && m->ed_erb_fc.Og == 80)) &&
-                         (d.is48 || d.F3 * 64 == 512);
+    const bool gl_dims = small_gl_dims(m);
     const bool smallm = m->fuse_small && m->fuse_gl && BT <= SMALL_M_ROWS && gl_dims;
+    if (m->ln->join_armed && !smallm) { HIP_TRY(hipStreamWaitEvent(st, m->ln->ev_jn[c.parity], 0)); m->ln->join_armed = false; }     // (not reached: join_want asks for the same conditions)
     auto glfrag = [&](const GlW& g) { return GlFrag{m->C(g.frag), m->C(g.bias), g.G, g.Og, g.Ig, g.NT}; };
     const GlFrag nofrag{nullptr, nullptr, 0, 0, 0, 0};
     if (smallm) {
         ProfScope ps(m, "grouped_linear");
-        EmbInMArgs ea{c1d, d.Fd * 64, e3d, d.F3 * 64, glfrag(m->df_fc_emb), d.is48 ? glfrag(m->enc_erb_fc) : nofrag, glfrag(m->enc_lin_in), w.g256a.p, BT};
+        EmbInMArgs ea{c1d, d.Fd * 64, e3d, d.F3 * 64, glfrag(m->df_fc_emb), d.is48 ? glfrag(m->enc_erb_fc) : nofrag, glfrag(m->enc_lin_in), w.g256a.p, BT,
+                      nullptr, 0u, m->d_err};
+        if (m->ln->join_armed) { ea.wait_ctr = m->ln->join_ctr; ea.wait_target = m->ln->join_total; m->ln->join_armed = false; }
         hipLaunchKernelGGL(emb_in_mfma_kernel, dim3((BT + 63) / 64, 16), dim3(256), 0, st, ea);
     } else {
         ProfScope ps(m, "grouped_linear");
@@ -2003,12 +2034,14 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
     HIP_TRY(hipMemset(m->d_err, 0, sizeof(int)));
     HIP_TRY(hipHostMalloc((void**)&m->pin_progress, sizeof(int), hipHostMallocDefault));
     *m->pin_progress = 0;
+    m->counted = true; g_live_models.fetch_add(1);
     *out = m;
     return DPDF_OK;
 }
 
 extern "C" void dpdf_destroy(dpdf_model* m) {
     if (!m) return;
+    if (m->counted) { g_live_models.fetch_sub(1); m->counted = false; }
     (void)hipSetDevice(m->device);
     for (int g = 0; g < 1; ++g) {
         Lane& L = m->lanes[g];
@@ -2016,6 +2049,7 @@ extern "C" void dpdf_destroy(dpdf_model* m) {
         L.ws.release();
         for (int k = 0; k < 5; ++k) if (L.gru_xbuf[k]) (void)hipFree(L.gru_xbuf[k]);
         for (int k = 0; k < 2; ++k) if (L.hop_flags[k]) (void)hipFree(L.hop_flags[k]);
+        if (L.join_ctr) (void)hipFree(L.join_ctr);
         for (int k = 0; k < 2; ++k) if (L.gru_sbuf[k]) (void)hipFree(L.gru_sbuf[k]);
         for (int k = 0; k < 5; ++k) if (L.arrive[k]) (void)hipFree(L.arrive[k]);
     }
@@ -2122,6 +2156,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "gru256_step") m->gru256_step = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
     else if (n == "hop_fused") m->hop_fused = value != 0;
+    else if (n == "hop_spin_join") m->hop_spin_join = value != 0;
     else if (n == "hop_feat") m->hop_feat = value != 0;
     else if (n == "glue8") m->glue8 = value != 0;
     else if (n == "fuse_gl") m->fuse_gl = value != 0;

@@ -24,6 +24,7 @@ struct HopBlockArgs {
     Gru64Args scan; const float* wfrag4; const float* gi_in; int gw;     // the scan half (gru64_scan4_gi_kernel's arguments)
     HopGlueArgs glue;                                                    // the glue half (dprnn_hop_glue8_kernel's)
     unsigned* flags; unsigned epoch; int nscan_x; int Fp; int* err;
+    unsigned* done;                                                      // last block of a stack: see HopHandoff::done
 };
 
 template <bool NEXT>
@@ -41,6 +42,6 @@ __global__ __launch_bounds__(512) void dprnn_hop_block_kernel(HopBlockArgs b) {
         if (NEXT && b.Fp >= 48 && blockIdx.x == 0 && threadIdx.x == 0) dpdf_trace_buf[19] = __builtin_amdgcn_s_memtime();
 #endif
     } else {
-        dprnn_hop_glue8_body<NEXT, true>(b.glue, (int)blockIdx.x - nscan, HopHandoff{b.flags, b.epoch, b.nscan_x, b.Fp, b.err});
+        dprnn_hop_glue8_body<NEXT, true>(b.glue, (int)blockIdx.x - nscan, HopHandoff{b.flags, b.epoch, b.nscan_x, b.Fp, b.err, b.done});
     }
 }

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void dprnn_hop_glue_kernel(HopGlueArgs g) {
 // HANDOFF (dprnn_hop_block.h): the tile's hcat rows come from scan workgroups of the SAME launch -- everything that does not depend
 // on them (operands, residual rows, carried state) is fetched first, then the tile waits for its scans' flags and reads the rows with
 // agent-scope loads
-struct HopHandoff { const unsigned* flags; unsigned epoch; int nscan_x, Fp; int* err; };
+struct HopHandoff { const unsigned* flags; unsigned epoch; int nscan_x, Fp; int* err; unsigned* done; };   // done (last block of a stack, optional): tiles whose output is out -- a consumer on another stream waits for it instead of for an event
 template <bool NEXT, bool HANDOFF>
 __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int tile, const HopHandoff& ho) {
     __shared__ __attribute__((aligned(16))) float As[16][132];
@@ -506,8 +506,20 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
     if (ln_role) {
         const float4 u = *(const float4*)&Fs[0][rr][rc4], v2 = *(const float4*)&Fs[1][rr][rc4];
         const float4 y2 = layer_norm_res(make_float4(u.x + v2.x, u.y + v2.y, u.z + v2.z, u.w + v2.w), y1, Ln[2], Ln[3]);
-        if (rok) *(float4*)(g.y2 + (size_t)(row0 + rr) * 64 + rc4) = y2;
+        if (rok) {
+            float* yo = g.y2 + (size_t)(row0 + rr) * 64 + rc4;
+            if (HANDOFF && !NEXT && ho.done) {          // read by a kernel that is already running on another stream: write-through
+                __hip_atomic_store(yo + 0, y2.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(yo + 1, y2.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(yo + 2, y2.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(yo + 3, y2.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else *(float4*)yo = y2;
+        }
         if (NEXT) *(float4*)&Ys[rr][rc4] = y2;   // the x-part waves read y1 out of Ys three barriers ago
+    }
+    if (HANDOFF && !NEXT && ho.done) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ho.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (NEXT) {
         __syncthreads();
@@ -545,5 +557,5 @@ __device__ __forceinline__ void dprnn_hop_glue8_body(const HopGlueArgs& g, int t
 
 template <bool NEXT>
 __global__ __launch_bounds__(512) void dprnn_hop_glue8_kernel(HopGlueArgs g) {
-    dprnn_hop_glue8_body<NEXT, false>(g, blockIdx.x, HopHandoff{nullptr, 0u, 0, 1, nullptr});
+    dprnn_hop_glue8_body<NEXT, false>(g, blockIdx.x, HopHandoff{nullptr, 0u, 0, 1, nullptr, nullptr});
 }

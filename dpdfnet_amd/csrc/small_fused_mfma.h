@@ -38,6 +38,18 @@ __device__ __forceinline__ void gl_load_a(const float* arow, float4 (&a4)[NCH]) 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) a4[c] = *(const float4*)(arow + 16 * c);
 }
+// the same through agent-scope loads: rows written by a kernel of another stream while this one was already running
+__device__ __forceinline__ float4 ld4_agent(const float* p) {
+    float4 v;
+    v.x = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+template <int NCH>
+__device__ __forceinline__ void gl_load_a_agent(const float* arow, float4 (&a4)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) a4[c] = ld4_agent(arow + 16 * c);
+}
 template <int NT, int NCH>
 __device__ __forceinline__ void gl_mma(const float4 (&a4)[NCH], const float (&wv)[NCH][NT][4], f32x4 (&acc)[NT]) {
 #pragma unroll
@@ -66,10 +78,13 @@ struct EmbInMArgs {
     const float* c1d; int n_c1; const float* e3d; int n_e3;
     GlFrag df_fc, erb_fc, lin_in;       // erb_fc.frag == null: the first 512 inputs of linear_in are e3d itself (16 kHz)
     float* out; int M;                  // [M][256]
+    // optional: e3d comes from a kernel of ANOTHER stream that may still be running (the ERB stack's last one-launch block of a
+    // streaming hop, dprnn_hop_block.h): the workgroups that read it wait until `wait_ctr` has reached `wait_target` (tiles out)
+    const unsigned* wait_ctr; unsigned wait_target; int* err;
 };
 // grid (ceil(M / 64), 16 groups of linear_in): group g2 reads embin[64 g2, 64 g2 + 64) = four 16-wide first-layer groups
 // first layer of emb_in for the four groups gg0 .. gg0 + 3 of one half (block-uniform), two groups per round of loads
-template <int NCH>
+template <int NCH, bool AGENT>
 __device__ __forceinline__ void emb_in_first(const GlFrag& g, const float* xrow, int gg0, float (*Es)[68], int lane) {
     const int cl = lane & 15, q = lane >> 4;
     float b1[4];
@@ -80,7 +95,8 @@ __device__ __forceinline__ void emb_in_first(const GlFrag& g, const float* xrow,
         float4 a4[2][NCH]; float wv[2][NCH][1][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            gl_load_a<NCH>(xrow + (size_t)(gg0 + jj + u) * g.Ig + 4 * q, a4[u]);
+            if (AGENT) gl_load_a_agent<NCH>(xrow + (size_t)(gg0 + jj + u) * g.Ig + 4 * q, a4[u]);
+            else gl_load_a<NCH>(xrow + (size_t)(gg0 + jj + u) * g.Ig + 4 * q, a4[u]);
             gl_load_w<1, NCH>(g, gg0 + jj + u, lane, wv[u]);
         }
 #pragma unroll
@@ -103,13 +119,28 @@ __global__ __launch_bounds__(256) void emb_in_mfma_kernel(EmbInMArgs a) {
     gl_load_w<1, 4>(a.lin_in, g2, lane, w2);
     const float b2 = a.lin_in.bias[g2 * 16 + cl];
     const bool erb = g2 < 8;                              // groups 4 g2 .. 4 g2 + 3 of the first layer: 0..31 ERB half, 32..63 DF half
+    if (erb && a.wait_ctr) {
+        if (tid == 0) {
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(a.wait_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.wait_target) < 0) {
+                if (++spins > (1u << 20)) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    }
     if (erb && !a.erb_fc.frag) {                          // 16 kHz: copy e3d[row][64 g2 ..]
         if (q == 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) *(float4*)&Es[w][cl][4 * i] = *(const float4*)(a.e3d + (size_t)row * a.n_e3 + 64 * g2 + 4 * i);
+            for (int i = 0; i < 16; ++i) {
+                const float* src = a.e3d + (size_t)row * a.n_e3 + 64 * g2 + 4 * i;
+                *(float4*)&Es[w][cl][4 * i] = a.wait_ctr ? ld4_agent(src) : *(const float4*)src;
+            }
         }
-    } else if (erb) emb_in_first<5>(a.erb_fc, a.e3d + (size_t)row * a.n_e3, 4 * g2, Es[w], lane);          // 2560 / 32 = 80 inputs per group
-    else emb_in_first<6>(a.df_fc, a.c1d + (size_t)row * a.n_c1, 4 * g2 - 32, Es[w], lane);                  // 3072 / 32 = 96
+    } else if (erb) {                                                                                      // 2560 / 32 = 80 inputs per group
+        if (a.wait_ctr) emb_in_first<5, true>(a.erb_fc, a.e3d + (size_t)row * a.n_e3, 4 * g2, Es[w], lane);
+        else emb_in_first<5, false>(a.erb_fc, a.e3d + (size_t)row * a.n_e3, 4 * g2, Es[w], lane);
+    } else emb_in_first<6, false>(a.df_fc, a.c1d + (size_t)row * a.n_c1, 4 * g2 - 32, Es[w], lane);        // 3072 / 32 = 96
     __syncthreads();
     f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
     float4 a4[4];

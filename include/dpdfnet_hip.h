@@ -184,7 +184,7 @@ int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
  * workgroups of the ERB decoder's input-linear launch), "hop_dec_fork" (default 0; 1: the DF decoder on its own stream also in
  * one-chunk calls), "snapshot" (default 1; 0 disables the streaming calls' pre-call state copy and with it the automatic
  * recovery -- timing only).  Round 4: "dft2" (1: the analysis / synthesis DFT of big launches as two small matrix stages,
- * dft2stage.h; 0: one [win x 2F] GEMM), "hop_fused" (a streaming hop's DPRNN scan and glue as one launch), "gru256_fused_x" / "gru256_fused_x_tiles" (1 / 6: from six 16-row tiles on the GRU-256
+ * dft2stage.h; 0: one [win x 2F] GEMM), "hop_fused" (a streaming hop's DPRNN scan and glue as one launch), "hop_spin_join" (stage 2 of a hop waits for the ERB stack by counter instead of a cross-stream event; only while this is the process's one engine handle), "gru256_fused_x" / "gru256_fused_x_tiles" (1 / 6: from six 16-row tiles on the GRU-256
  * input projection runs inside the four-workgroup cluster scan, gru_clusterx.h; 0: hoisted GEMM + scan), "host_pipe" (1:
  * host-pointer batch calls pipelined over time slices), "host_copy_threads" (4), "host_prefault" (1: a helper thread populates
  * the caller's output rows while the first chunk computes), "chunk_io" (default 0; 1: per-chunk STFT / iSTFT also for

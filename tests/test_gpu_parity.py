@@ -444,7 +444,7 @@ def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
     blob = synth_blob(be.manifest(sr, nb), 4711)
     rng = np.random.default_rng(5)
     runs = {}
-    for tag, opts in (("hop", {}), ("two_launch", {"hop_fused": 0}),
+    for tag, opts in (("hop", {}), ("two_launch", {"hop_fused": 0}), ("event_join", {"hop_spin_join": 0}),
                       ("plain", {"single_chunk_inline": 0, "hop_prologue": 0, "late_export": 0, "dual_step": 0, "hop_pconv": 0,
                                  "fuse_enc": 0, "fuse_dec": 0, "snapshot": 0, "hop_fused": 0})):
         m = be.HipModel(sr, nb, blob, 0)
@@ -466,6 +466,10 @@ def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
     for a_, b_ in zip(runs["hop"][0], runs["two_launch"][0]):
         np.testing.assert_array_equal(a_, b_)
     np.testing.assert_array_equal(runs["hop"][1], runs["two_launch"][1])
+    # ... and stage 2 waiting for the ERB stack by counter (emb_in spins) against the cross-stream event
+    for a_, b_ in zip(runs["hop"][0], runs["event_join"][0]):
+        np.testing.assert_array_equal(a_, b_)
+    np.testing.assert_array_equal(runs["hop"][1], runs["event_join"][1])
 
 
 def test_every_gru256_scan_form_agrees(be):
