@@ -1,0 +1,166 @@
+// dft64.h -- the ANALYSIS transform in double precision: the float32 product frame * window (exactly the reference's operand,
+// package/src/dpdfnet/stream.py:119 `windowed = in_buf[:win] * window`, audio.py:104-117) goes through a float64 DFT and is
+// rounded to float32 once, which is what the reference's np.fft.rfft delivers (stream.py:120-126: float64 under its pinned
+// numpy 1.26.4, and the same values to the last float32 bit under numpy 2.x) and what oracle/dpdf_oracle.c restates.
+//
+// Why: at 48 kHz the features are 10 log10(|X| + 1e-10) PER BIN (onnx_model/dpdfnet_48khz_hr.py:887-924).  A bin that holds no
+// signal (band-limited speech, 16-bit sources, DC) carries only the quantisation residue of the windowed frame, ~1e-7 of the
+// loud bins -- and an fp32 accumulation chain (f32 MFMA = fmaf chain) or fp32 twiddles leave their own 1e-7 there, so that
+// every fp32 DFT form (one GEMM, two stages, K split) fed the network different -60 .. -100 dB features: 1.6e-3 RMS on the
+// enhanced waveform for band-limited audio, 16 x the parity budget.  In float64 the transform's own error is 1e-16 of the
+// loud bins; the three call sites (offline batch, offline time chunks, streaming hops) now share ONE kernel and one result.
+//
+// Shape: the same Cooley-Tukey split as dft2stage.h (N = 32 x N2, n = N2 n1 + n2, k = k1 + 32 k2), both stages in one launch on
+// v_mfma_f64_16x16x4_f64, the intermediate kept in float64 in LDS (rounding it to float32 would put the 1e-7 back):
+//   workgroup = (16 frames, 8 of the 32 k1)
+//   stage 1: rows (frame, n2), K = 32 samples n1, 16 columns = 8 complex k1          -> Y[frame][n2][k1]        (LDS, f64)
+//   stage 2: per k1, rows = the 16 frames, K = 2 N2 (n2, re/im), columns (k2, re/im), twiddle e^{-2 pi i n2 k1 / N} folded in
+//            -> X[k1 + 32 k2], k <= N / 2, gathered in an LDS tile and written as 64-byte runs of bins.
+// 960: 120 f64 MFMAs per frame (246 kFLOP); the f64 matrix rate is half the f32 one, so 256 x 1003 frames cost ~1 ms of the
+// chip -- under 1 % of the 48 kHz models.  A operands of stage 1 are read straight from the clip (L2-resident, lanes of a
+// quad read 64 contiguous bytes), windowed in float32, converted exactly.
+#pragma once
+#include "common.h"
+#include "gemm_rows.h"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: lane l supplies A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15];
+// D reg i holds D[row = (l >> 4) + 4 i][col = l & 15]  (NOT the f32 shape's 4 (l >> 4) + i).
+__device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int N2>
+struct Dft64Cfg {
+    static constexpr int N = 32 * N2, F = N / 2 + 1, SPEC = 2 * F;
+    static constexpr int NK2 = N2 / 2 + 1;                 // k2 values that reach bins <= N / 2
+    static constexpr int KS = (2 * N2 + 3) / 4;            // K steps of stage 2 (2 N2 real values, 4 per MFMA)
+    static constexpr int NT = (2 * NK2 + 15) / 16;         // column tiles of stage 2
+    static constexpr int MIDW = N2 * 16 + 2;               // doubles per frame of the intermediate (+2: 16 frames land on 16 distinct bank groups)
+    static constexpr size_t TW1 = (size_t)4 * 8 * 64;      // doubles: [k1 group 4][K step 8][lane 64]
+    static constexpr size_t TW2 = (size_t)32 * KS * NT * 64;   // doubles: [k1 32][K step][column tile][lane 64]
+};
+
+struct Dft64Args {
+    const float* wav; int N; int T; int hop; const float* window; const int* lens;
+    RowSeg seg;            // rows of this launch -> (clip, frame): b = row / seg.Tc, t = seg.t0 + row % seg.Tc; spectrum row = seg.map(row)
+    int causal;            // 1: StreamEnhancer analysis, frame t = x[t hop : t hop + win], no padding; x = [tail | wav] when tail != null
+    const float* tail;     // [clips][hop] or null (then wav holds the (T + 1) hop samples of a stream itself)
+    float* spec;           // [..][F][2]
+    int M;                 // rows
+    const double* tw1; const double* tw2;
+};
+
+template <int N2>
+__global__ __launch_bounds__(256) void dft64_fwd_kernel(Dft64Args g) {
+    using C = Dft64Cfg<N2>;
+    __shared__ __attribute__((aligned(16))) double mid[16][C::MIDW];
+    __shared__ __attribute__((aligned(16))) float outs[16][C::NK2][16];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
+    const int fr0 = blockIdx.x * 16, grp = blockIdx.y;
+
+    // ---- stage 1 ----
+    double b1[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) b1[kk] = g.tw1[((size_t)grp * 8 + kk) * 64 + lane];
+    for (int rt = w; rt < N2; rt += 4) {
+        const int r = rt * 16 + cl, f = r / N2, n2 = r - f * N2;
+        const int fr = min(fr0 + f, g.M - 1);
+        const int b = fr / g.seg.Tc, t = g.seg.t0 + (fr - b * g.seg.Tc);
+        const int nb_ = g.lens ? g.lens[b] : g.N, np_ = nb_ + C::N;
+        const bool live = g.causal || !g.lens || t < 1 + np_ / g.hop;
+        float xv[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int n = N2 * (4 * kk + q) + n2;
+            int j = t * g.hop + n;
+            float v = 0.f;
+            if (g.causal) {
+                v = g.tail ? (j < g.hop ? g.tail[(size_t)b * g.hop + j] : g.wav[(size_t)b * (g.N - g.hop) + (j - g.hop)]) : g.wav[(size_t)b * g.N + j];
+            } else {
+                j -= C::N / 2;
+                if (j < 0) j = -j;
+                if (j >= np_) j = 2 * (np_ - 1) - j;
+                if (live && j >= 0 && j < nb_) v = g.wav[(size_t)b * g.N + j];
+            }
+            xv[kk] = v * g.window[n];                   // the float32 product, as the reference forms it
+        }
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc = mfma64((double)xv[kk], b1[kk], acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ro = rt * 16 + q + 4 * i, fo = ro / N2, no = ro - fo * N2;
+            mid[fo][no * 16 + cl] = acc[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: wave w takes k1 = 8 grp + 2 w + j ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k1l = 2 * w + j, k1 = 8 * grp + k1l;
+        const double* bp = g.tw2 + (size_t)k1 * C::KS * C::NT * 64 + lane;
+        f64x4 acc[C::NT];
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) acc[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < C::KS; ++kk) {
+            const int n2 = 2 * kk + (q >> 1);           // K index 4 kk + q = (n2, re / im = q & 1)
+            const double a = n2 < N2 ? mid[cl][n2 * 16 + 2 * k1l + (q & 1)] : 0.0;
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt) acc[nt] = mfma64(a, bp[(size_t)(kk * C::NT + nt) * 64], acc[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = nt * 16 + cl, k2 = col >> 1;
+                if (k2 < C::NK2) outs[q + 4 * i][k2][2 * k1l + (col & 1)] = (float)acc[nt][i];
+            }
+    }
+    __syncthreads();
+    // [16 frames][k2][8 k1] bins of 8 bytes: a (frame, k2) is 8 consecutive bins k = 8 grp + 32 k2 ..
+    for (int idx = tid; idx < 16 * C::NK2 * 8; idx += 256) {
+        const int k1l = idx & 7, rest = idx >> 3, k2 = rest % C::NK2, fl = rest / C::NK2;
+        const int fr = fr0 + fl, k = 8 * grp + k1l + 32 * k2;
+        if (fr < g.M && k < C::F)
+            *(float2*)(g.spec + g.seg.map(fr) * C::SPEC + 2 * k) = *(const float2*)&outs[fl][k2][2 * k1l];
+    }
+}
+
+// host: the two operand tables, doubles in MFMA B-fragment order
+template <int N2>
+static inline void dft64_tables(std::vector<double>& tw1, std::vector<double>& tw2) {
+    using C = Dft64Cfg<N2>;
+    auto ang = [](long num, int den) { return 2.0 * M_PI * (double)(num % den) / den; };
+    tw1.assign(C::TW1, 0.0); tw2.assign(C::TW2, 0.0);
+    for (int grp = 0; grp < 4; ++grp)
+        for (int kk = 0; kk < 8; ++kk)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n1 = 4 * kk + (lane >> 4), col = lane & 15, k1 = 8 * grp + (col >> 1);
+                const double a = ang((long)n1 * k1, 32);
+                tw1[((size_t)grp * 8 + kk) * 64 + lane] = (col & 1) ? -std::sin(a) : std::cos(a);
+            }
+    for (int k1 = 0; k1 < 32; ++k1)
+        for (int kk = 0; kk < C::KS; ++kk)
+            for (int nt = 0; nt < C::NT; ++nt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int k = 4 * kk + (lane >> 4), n2 = k >> 1, cc = k & 1;       // input (n2, re / im)
+                    const int col = nt * 16 + (lane & 15), k2 = col >> 1, cp = col & 1; // output (k2, re / im)
+                    double v = 0.0;
+                    if (n2 < N2 && k2 < C::NK2) {
+                        const double th = ang((long)n2 * (k1 + 32 * k2), C::N);        // times e^{-i th}
+                        v = (cc == cp) ? std::cos(th) : (cc ? std::sin(th) : -std::sin(th));
+                    }
+                    tw2[(((size_t)k1 * C::KS + kk) * C::NT + nt) * 64 + lane] = v;
+                }
+}
+
+static inline void launch_dft64_forward(hipStream_t st, const Dft64Args& a, int win) {
+    if (a.M <= 0) return;
+    const dim3 grid((a.M + 15) / 16, 4);
+    if (win == 960) hipLaunchKernelGGL(HIP_KERNEL_NAME(dft64_fwd_kernel<30>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(dft64_fwd_kernel<10>), grid, dim3(256), 0, st, a);
+}

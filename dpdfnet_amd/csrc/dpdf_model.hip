@@ -50,6 +50,7 @@
 #include "dec_pyr.h"
 #include "dft2stage.h"
 #include "gru_clusterx.h"
+#include "dft64.h"
 
 // ------------------------------------------------------------------------------------------------
 // HIP multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4); the engine runs four
@@ -443,6 +444,9 @@ struct dpdf_model {
     DevBuf dft_mid_f, dft_mid_i;       // its intermediates [frames][30][64] (analysis / synthesis: they may run on different streams)
     long dbg_nspec = 0, dbg_nframes = 0;
     int dft2 = 1;                      // big launches: STFT / iSTFT as two small matrix stages (0: one [win x 2F] GEMM; A/B)
+    size_t dft64_tw1 = 0, dft64_tw2 = 0;   // operands of the float64 analysis DFT (dft64.h; doubles stored in the float arena)
+    int dft64 = 1;                     // analysis STFT in float64 on every call path (dft64.h): 1 = 48 kHz models (per-bin log-magnitude features), 2 = 16 kHz too, 0 = the fp32 forms (A/B)
+    bool use_dft64() const { return (d.win == 960 && dft64 >= 1) || (d.win == 320 && dft64 >= 2); }
     HostPipe hp;                       // pinned staging ring + copy streams of the host-pointer batch calls
     int host_pipe = 1;                 // host-pointer batch calls pipelined over time slices (0: one upload, compute, one download; A/B)
     int gru256_fused_x_tiles = 6;      // ... from this many 16-row tiles on
@@ -1996,6 +2000,15 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
         }));
     }
 
+    if (d.win == 960 || d.win == 320) {
+        // ---- float64 analysis DFT (dft64.h) ----
+        std::vector<double> t1, t2;
+        if (d.win == 960) dft64_tables<30>(t1, t2); else dft64_tables<10>(t1, t2);
+        auto as_floats = [](const std::vector<double>& v) { std::vector<float> f(v.size() * 2); memcpy(f.data(), v.data(), v.size() * sizeof(double)); return f; };
+        m->dft64_tw1 = A.add(as_floats(t1));          // (arena slots start on 256-byte boundaries)
+        m->dft64_tw2 = A.add(as_floats(t2));
+    }
+
     // ---- streams: lane 0 now; the second lane and the sub-stage pipeline's streams only when first used (init_lane):
     // HIP multiplexes streams onto a handful of hardware queues, and streams that merely exist still take part in that
     // mapping -- with 14 streams per handle the four active ones of a second handle ended up sharing queues (one
@@ -2153,6 +2166,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "gru256_stack") m->gru256_stack = value != 0;
     else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
     else if (n == "stft_ksplit") m->stft_ksplit = value & 7;
+    else if (n == "dft64") m->dft64 = value;
     else if (n == "gru256_step") m->gru256_step = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
     else if (n == "hop_fused") m->hop_fused = value != 0;
@@ -2524,6 +2538,12 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
             // A1 for the frames of this chunk, behind its slice's upload
             if (host) HIP_TRY(hipStreamWaitEvent(m->stream, hp.ev_up[k % R], 0));
             const RowSeg seg{Tc, T, t0};
+            if (m->use_dft64()) {
+                Dft64Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, seg, 0, nullptr, m->raw_spec.p, B * Tc,
+                             (const double*)m->C(m->dft64_tw1), (const double*)m->C(m->dft64_tw2)};
+                launch_dft64_forward(m->stream, da, d.win);
+                return DPDF_OK;
+            }
             if (dft2) {
                 Dft2Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, nullptr, m->raw_spec.p, m->dft_mid_f.p, m->C(m->dft_f1), m->C(m->dft_f2), seg, B * Tc};
                 launch_dft2_forward(m->stream, da, d.win);
@@ -2566,7 +2586,11 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         // A1: analysis STFT
         ProfScope ps(m, "stft");
         StftA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window), 0, d_lens};
-        if (B * T <= SMALL_M_ROWS) {
+        if (m->use_dft64()) {
+            Dft64Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, RowSeg{T, T, 0}, 0, nullptr, m->raw_spec.p, B * T,
+                         (const double*)m->C(m->dft64_tw1), (const double*)m->C(m->dft64_tw2)};
+            launch_dft64_forward(m->stream, da, d.win);
+        } else if (B * T <= SMALL_M_ROWS) {
             if ((rc = stft_small(m, ap, m->raw_spec.p, B * T))) return rc;
         } else if (dft2) {
             Dft2Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, nullptr, m->raw_spec.p, m->dft_mid_f.p, m->C(m->dft_f1), m->C(m->dft_f2), RowSeg{T, T, 0}, B * T};
@@ -2776,7 +2800,11 @@ static int streams_enqueue_body(dpdf_streams* s, const StreamView& v, const floa
     {
         StftA<64> ap{in_place ? src : xbuf, (T + 1) * d.hop, T, d.win, d.hop, m->C(m->window), 1};
         if (in_place) ap.tail = v.in_tail;
-        if (S * T <= SMALL_M_ROWS) {
+        if (m->use_dft64()) {
+            Dft64Args da{in_place ? src : xbuf, (T + 1) * d.hop, T, d.hop, m->C(m->window), nullptr, RowSeg{T, T, 0}, 1, in_place ? v.in_tail : nullptr,
+                         s->spec.p, S * T, (const double*)m->C(m->dft64_tw1), (const double*)m->C(m->dft64_tw2)};
+            launch_dft64_forward(m->stream, da, d.win);
+        } else if (S * T <= SMALL_M_ROWS) {
             if ((rc = stft_small(m, ap, s->spec.p, S * T, hop_fused))) return rc;
         } else {
             BiasActStore<2> ep{s->spec.p, (size_t)2 * d.F, 32, nullptr, 0, 32, ACT_NONE};

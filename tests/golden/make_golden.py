@@ -416,6 +416,176 @@ def make_stress_fixtures():
     make_model_fixture("48k_nb1_stiff", 48000, 1, 0.6, SEED + 249, stress="stiff")
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Spectrally SPARSE inputs at 48 kHz (round-4 review, weak #1).  The 48 kHz feature path is 10 log10(|X| + 1e-10) PER BIN
+# (onnx_model/dpdfnet_48khz_hr.py:887-924, MagNorm48 onnx_model/layers.py:575-661): a bin that holds only the rounding noise of
+# the analysis transform becomes a -60 .. -100 dB feature that differs between STFT implementations.  The reference itself has
+# two analyses on its path -- an fp32 FFT (torch.stft here; librosa -> scipy.fft single precision in the package's offline
+# path) and, under its pinned numpy 1.26.4, a float64 FFT of the float32 windowed frame (np.fft.rfft in stream.py:119-126).
+# Each class below is run through the reference frame function fed BOTH ways and both enhanced waveforms are stored, so the
+# fixture carries the reference's own spread next to the float64 variant the oracle restates.
+SPARSE_CLASSES = ("bl_f32", "bl_i16", "dc", "square", "sil_sig")
+
+
+def sparse_clip(cls: str, n: int, sr: int, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    def band_limited(m):
+        spec = np.fft.rfft(rng.standard_normal(m))
+        f = np.fft.rfftfreq(m, 1.0 / sr)
+        spec[f > 6000.0] = 0.0                                          # nothing above 6 kHz: 3/4 of the 481 bins hold no signal
+        x = np.fft.irfft(spec, m)
+        t = np.arange(m) / sr
+        x = x / np.sqrt(np.mean(x ** 2)) * 0.14 * (0.6 + 0.4 * np.sin(2 * np.pi * 3.0 * t))
+        return np.clip(x, -1.0, 1.0)
+    if cls == "bl_f32":
+        return band_limited(n).astype(np.float32)
+    if cls == "bl_i16":                                                 # the same audio as a 16-bit PCM file would deliver it
+        return (np.round(band_limited(n) * 32768.0) / 32768.0).astype(np.float32)
+    if cls == "dc":
+        return np.full(n, 0.5, dtype=np.float32)
+    if cls == "square":                                                 # +-1, period 100 samples (480 Hz)
+        return np.where((np.arange(n) // 50) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    if cls == "sil_sig":                                                # 0.25 s of exact zeros, then the band-limited signal
+        x = band_limited(n)
+        x[: int(0.25 * sr)] = 0.0
+        return x.astype(np.float32)
+    raise ValueError(cls)
+
+
+def _f64_stft_center(wav: np.ndarray, win: int, hop: int, window: np.ndarray) -> np.ndarray:
+    """preprocess_waveform's framing (tail pad win, centre / reflect pad: package/src/dpdfnet/audio.py:104-117, api.py:88) with
+    the transform of stream.py:119-126 under numpy 1.26.4: float32 product frame * window, float64 rfft, result cast to f32."""
+    x = np.pad(wav.astype(np.float32), (0, win))
+    xp = np.pad(x, (win // 2, win // 2), mode="reflect")
+    T = 1 + len(x) // hop
+    out = np.zeros((T, win // 2 + 1, 2), dtype=np.float32)
+    for t in range(T):
+        fr = (xp[t * hop: t * hop + win] * window).astype(np.float32)
+        c = np.fft.rfft(fr.astype(np.float64), n=win)
+        out[t, :, 0] = c.real.astype(np.float32); out[t, :, 1] = c.imag.astype(np.float32)
+    return out
+
+
+def make_sparse_model_fixture(tag: str, nb: int, seconds: float, seed: int):
+    import torch
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import parse_manifest_text, synth_blob
+
+    sr = 48000
+    entries = parse_manifest_text(orc.manifest_text(sr, nb))
+    blob = synth_blob(entries, seed)
+    model = build_reference_model(sr, nb, blob, entries)
+    win = model.stft.win_len
+    window = model.stft.w.numpy().astype(np.float32)
+    n = int(seconds * sr)
+
+    def synth(spec_e):
+        with torch.no_grad():
+            c = torch.view_as_complex(torch.from_numpy(np.ascontiguousarray(spec_e)))[None]
+            audio = model.istft(c.transpose(1, 2))
+            audio = torch.nn.functional.pad(audio[:, win * 2:], (0, win * 2))
+        a = audio[0].numpy()
+        out = np.zeros(n, dtype=np.float32)
+        m = min(n, a.shape[0]); out[:m] = a[:m]
+        return out
+
+    fix, report = {}, {}
+    for i, cls in enumerate(SPARSE_CLASSES):
+        wav = sparse_clip(cls, n, sr, seed + 10 + i)
+        with torch.no_grad():
+            audio_pad = torch.nn.functional.pad(torch.from_numpy(wav)[None], (0, win))
+            spec_t = torch.view_as_real(model.stft(audio_pad).transpose(1, 2)[0]).numpy().astype(np.float32)
+        spec_d = _f64_stft_center(wav, win, win // 2, window)
+        g_t = run_reference_frames(model, spec_t, probe_frames=())
+        g_d = run_reference_frames(model, spec_d, probe_frames=())
+        e_t, e_d = synth(g_t["spec_e"]), synth(g_d["spec_e"])
+        fix[f"wav_{cls}"] = wav
+        fix[f"enh_torch_{cls}"] = e_t
+        fix[f"enh_f64_{cls}"] = e_d
+        fix[f"spec_f64_head_{cls}"] = spec_d[28:32].copy()             # pins the oracle's analysis on these inputs
+        fix[f"spec_e_f64_head_{cls}"] = g_d["spec_e"][28:40].copy()
+        fix[f"state_out_f64_{cls}"] = g_d["state_out"]
+        rms = lambda v: float(np.sqrt(np.mean(np.square(v, dtype=np.float64))))
+        report[cls] = dict(rms_in=rms(wav), rms_out=rms(e_d), torch_vs_f64=rms(e_t - e_d))
+    meta = dict(tag=tag, sample_rate=sr, nb=nb, seed=seed, n=n, classes=list(SPARSE_CLASSES), spread=report)
+    fix["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / f"model_{tag}.npz", **fix)
+    print(f"[golden] model_{tag}.npz", {k: f"{v['torch_vs_f64']:.2e}" for k, v in report.items()})
+    return model
+
+
+def make_sparse_stream_fixture(model, tag: str, seed: int):
+    """The reference's StreamEnhancer (package/src/dpdfnet/stream.py:74-200) on sparse inputs, with np.fft.rfft as numpy 1.26.4
+    (the reference's pin, requirements.txt:4) computes it -- float64 -- and as this container's numpy 2.x does (float32)."""
+    import torch
+    import dpdfnet.stream as ref_stream
+    from dpdfnet.models import ModelInfo, ResolvedModel
+
+    sr, win = 48000, 960
+    F = win // 2 + 1
+
+    class _In:
+        def __init__(self, name, shape): self.name, self.shape = name, shape
+
+    class _Session:
+        def get_inputs(self): return [_In("spec", [1, 1, F, 2]), _In("state_in", [model.state_size()])]
+        def get_outputs(self): return [_In("spec_e", None), _In("state_out", None)]
+        def run(self, _names, feeds):
+            with torch.no_grad():
+                y, st = model(torch.from_numpy(np.ascontiguousarray(feeds["spec"])) * wnorm, torch.from_numpy(feeds["state_in"].copy()))
+            return [(y * inv).numpy(), st.numpy()]
+
+    wnorm = torch.tensor(np.float32(model.wnorm)); inv = torch.tensor(np.float32(1.0 / float(model.wnorm)))
+
+    class _FFT64:                                   # numpy 1.x: rfft of a float32 array is computed in double precision
+        @staticmethod
+        def rfft(x, n=None): return np.fft.rfft(np.asarray(x, dtype=np.float64), n=n)
+        @staticmethod
+        def irfft(x, n=None): return np.fft.irfft(np.asarray(x, dtype=np.complex128), n=n)
+
+    class _NP64:
+        fft = _FFT64
+        def __getattr__(self, k): return getattr(np, k)
+
+    def make(f64: bool):
+        init = model.initial_state(dtype=torch.float32).numpy()
+        rt = ref_stream.RuntimeModel(session=_Session(), init_state=init, in_spec_name="spec",
+                                     in_state_name="state_in", out_spec_name="spec_e", out_state_name="state_out")
+        ref_stream.resolve_model = lambda **kw: ResolvedModel(
+            info=ModelInfo(name="x", sample_rate=sr, frame_ms=20.0, description="", onnx_filename="x.onnx"),
+            onnx_path=Path("/dev/null"))
+        ref_stream.build_runtime_model = lambda _p: rt
+        ref_stream.infer_win_len = lambda _s, _sr: win
+        ref_stream.np = _NP64() if f64 else np
+        return ref_stream.StreamEnhancer(model="x")
+
+    n = int(0.4 * sr) + 37
+    out = {}
+    try:
+        for i, cls in enumerate(("bl_f32", "bl_i16", "sil_sig")):
+            wav = sparse_clip(cls, n, sr, seed + 20 + i)
+            out[f"wav_{cls}"] = wav
+            for name, f64 in (("f64", True), ("f32", False)):
+                for chunk in (win // 2, 171):
+                    if name == "f32" and chunk != win // 2:
+                        continue
+                    se = make(f64)
+                    pieces = [se.process(wav[j:j + chunk]) for j in range(0, n, chunk)]
+                    pieces.append(se.flush())
+                    out[f"{name}_{cls}_chunk{chunk}"] = np.concatenate(pieces).astype(np.float32)
+    finally:
+        ref_stream.np = np
+    np.savez_compressed(OUT / f"stream_{tag}.npz", **out)
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v, dtype=np.float64))))
+    print(f"[golden] stream_{tag}.npz", {c: f"{rms(out[f'f64_{c}_chunk480'] - out[f'f32_{c}_chunk480']):.2e}" for c in ("bl_f32", "bl_i16", "sil_sig")})
+
+
+def make_sparse_fixtures():
+    m1 = make_sparse_model_fixture("48k_nb1_sparse", 1, 0.6, SEED + 301)
+    m8 = make_sparse_model_fixture("48k_nb8_sparse", 8, 0.6, SEED + 308)
+    make_sparse_stream_fixture(m8, "48k_nb8_sparse", SEED + 318)
+
+
 def main():
     assert REF.is_dir(), "reference checkout not mounted; goldens can only be regenerated in the build container"
     _stub_modules()
@@ -427,6 +597,9 @@ def main():
     if "--stress-only" in sys.argv:          # the round-3 additions alone (the other fixtures regenerate bit-for-bit anyway)
         make_stress_fixtures()
         make_einsum_fixture()
+        return
+    if "--sparse-only" in sys.argv:          # the round-5 additions alone
+        make_sparse_fixtures()
         return
 
     make_constants_fixture()
@@ -446,6 +619,7 @@ def main():
     make_checkpoint_keys_fixture()
     make_stress_fixtures()
     make_einsum_fixture()
+    make_sparse_fixtures()
 
 
 if __name__ == "__main__":
