@@ -13,9 +13,10 @@
 // Shape: the same Cooley-Tukey split as dft2stage.h (N = 32 x N2, n = N2 n1 + n2, k = k1 + 32 k2), both stages in one launch on
 // v_mfma_f64_16x16x4_f64, the intermediate kept in float64 in LDS (rounding it to float32 would put the 1e-7 back):
 //   workgroup = (16 frames, 8 of the 32 k1)
-//   stage 1: rows (frame, n2), K = 32 samples n1, 16 columns = 8 complex k1          -> Y[frame][n2][k1]        (LDS, f64)
-//   stage 2: per k1, rows = the 16 frames, K = 2 N2 (n2, re/im), columns (k2, re/im), twiddle e^{-2 pi i n2 k1 / N} folded in
-//            -> X[k1 + 32 k2], k <= N / 2, gathered in an LDS tile and written as 64-byte runs of bins.
+//   stage 1: rows (frame, n2), K = 32 samples n1, 16 columns = 8 complex k1, times the middle twiddle e^{-2 pi i n2 k1 / N}
+//            (re / im of a value sit in neighbouring lanes: one DPP swap)            -> Y[frame][n2][k1]        (LDS, f64)
+//   stage 2: rows (frame, k1), K = 2 N2 (n2, re/im), columns (k2, re/im): the plain N2-point DFT, ONE operand for every row,
+//            held in registers                 -> X[k1 + 32 k2], k <= N / 2, gathered in an LDS tile, written as 64-byte runs.
 // 960: 120 f64 MFMAs per frame (246 kFLOP); the f64 matrix rate is half the f32 one, so 256 x 1003 frames cost ~1 ms of the
 // chip -- under 1 % of the 48 kHz models.  A operands of stage 1 are read straight from the clip (L2-resident, lanes of a
 // quad read 64 contiguous bytes), windowed in float32, converted exactly.
@@ -38,8 +39,9 @@ struct Dft64Cfg {
     static constexpr int KS = (2 * N2 + 3) / 4;            // K steps of stage 2 (2 N2 real values, 4 per MFMA)
     static constexpr int NT = (2 * NK2 + 15) / 16;         // column tiles of stage 2
     static constexpr int MIDW = N2 * 16 + 2;               // doubles per frame of the intermediate (+2: 16 frames land on 16 distinct bank groups)
-    static constexpr size_t TW1 = (size_t)4 * 8 * 64;      // doubles: [k1 group 4][K step 8][lane 64]
-    static constexpr size_t TW2 = (size_t)32 * KS * NT * 64;   // doubles: [k1 32][K step][column tile][lane 64]
+    static constexpr size_t TW1 = (size_t)4 * 8 * 64;      // doubles: stage-1 operand [k1 group 4][K step 8][lane 64]
+    static constexpr size_t TWM = (size_t)N2 * 32 * 2;     // doubles: middle twiddle e^{-2 pi i n2 k1 / N} as [n2][k1][cos, sin]
+    static constexpr size_t TW2 = (size_t)KS * NT * 64;    // doubles: stage-2 operand (the N2-point DFT) [K step][column tile][lane 64]
 };
 
 struct Dft64Args {
@@ -49,80 +51,132 @@ struct Dft64Args {
     const float* tail;     // [clips][hop] or null (then wav holds the (T + 1) hop samples of a stream itself)
     float* spec;           // [..][F][2]
     int M;                 // rows
-    const double* tw1; const double* tw2;
+    const double* tw1; const double* twm; const double* tw2;
 };
+
+// the other half of a (re, im) lane pair: quad_perm [1, 0, 3, 2] on both dwords
+__device__ __forceinline__ double dft64_pair_swap(double v) {
+    const long long u = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffll), 0xB1, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0xB1, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 
 template <int N2>
 __global__ __launch_bounds__(256) void dft64_fwd_kernel(Dft64Args g) {
     using C = Dft64Cfg<N2>;
     __shared__ __attribute__((aligned(16))) double mid[16][C::MIDW];
     __shared__ __attribute__((aligned(16))) float outs[16][C::NK2][16];
+    __shared__ int f_t[16], f_nb[16]; __shared__ long long f_base[16];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
     const int fr0 = blockIdx.x * 16, grp = blockIdx.y;
+    if (tid < 16) {       // per frame of the tile: first sample index, clip base, clip length (-1: a frame beyond a short clip's last)
+        const int fr = min(fr0 + tid, g.M - 1);
+        const int b = fr / g.seg.Tc, t = g.seg.t0 + (fr - b * g.seg.Tc);
+        const int nb_ = g.lens ? g.lens[b] : g.N;
+        const bool live = g.causal || !g.lens || t < 1 + (nb_ + C::N) / g.hop;
+        f_t[tid] = t * g.hop; f_nb[tid] = live ? nb_ : -1; f_base[tid] = b;
+    }
+    __syncthreads();
 
-    // ---- stage 1 ----
+    // ---- stage 1: rows (frame, n2), one row tile ahead in flight ----
     double b1[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) b1[kk] = g.tw1[((size_t)grp * 8 + kk) * 64 + lane];
-    for (int rt = w; rt < N2; rt += 4) {
+    // (loads only: the products are formed in run_tile, one tile later, so that nothing here waits for memory)
+    struct Tile { float x[8], wv[8]; unsigned ok; double c[4], s[4]; };
+    auto load_tile = [&](int rt, Tile& tl) {
         const int r = rt * 16 + cl, f = r / N2, n2 = r - f * N2;
-        const int fr = min(fr0 + f, g.M - 1);
-        const int b = fr / g.seg.Tc, t = g.seg.t0 + (fr - b * g.seg.Tc);
-        const int nb_ = g.lens ? g.lens[b] : g.N, np_ = nb_ + C::N;
-        const bool live = g.causal || !g.lens || t < 1 + np_ / g.hop;
-        float xv[8];
+        const int t0 = f_t[f], nb_ = f_nb[f], np_ = nb_ + C::N;
+        const size_t b = (size_t)f_base[f];
+        tl.ok = 0;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const int n = N2 * (4 * kk + q) + n2;
-            int j = t * g.hop + n;
-            float v = 0.f;
+            int j = t0 + n;
+            const float* p;
+            bool ok = true;
             if (g.causal) {
-                v = g.tail ? (j < g.hop ? g.tail[(size_t)b * g.hop + j] : g.wav[(size_t)b * (g.N - g.hop) + (j - g.hop)]) : g.wav[(size_t)b * g.N + j];
+                p = g.tail ? (j < g.hop ? g.tail + b * g.hop + j : g.wav + b * (g.N - g.hop) + (j - g.hop)) : g.wav + b * g.N + j;
             } else {
                 j -= C::N / 2;
                 if (j < 0) j = -j;
                 if (j >= np_) j = 2 * (np_ - 1) - j;
-                if (live && j >= 0 && j < nb_) v = g.wav[(size_t)b * g.N + j];
+                ok = j >= 0 && j < nb_;
+                p = g.wav + b * g.N + (ok ? j : 0);
             }
-            xv[kk] = v * g.window[n];                   // the float32 product, as the reference forms it
+            tl.x[kk] = *p; tl.wv[kk] = g.window[n];
+            tl.ok |= (unsigned)ok << kk;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                   // middle twiddles of the four result rows of this lane
+            const int ro = rt * 16 + q + 4 * i, no = ro % N2;
+            const double2 cs = *(const double2*)(g.twm + ((size_t)no * 32 + 8 * grp + (cl >> 1)) * 2);
+            tl.c[i] = cs.x; tl.s[i] = cs.y;
+        }
+    };
+    auto run_tile = [&](int rt, const Tile& tl) {
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) acc = mfma64((double)xv[kk], b1[kk], acc);
+        for (int kk = 0; kk < 8; ++kk) {
+            const float xw = ((tl.ok >> kk) & 1) ? tl.x[kk] * tl.wv[kk] : 0.f;     // the float32 product, as the reference forms it
+            acc = mfma64((double)xw, b1[kk], acc);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // (re + i im) e^{-i th} = (re c + im s) + i (im c - re s); this lane holds re (even column) or im (odd), its neighbour the other
+            const double v = acc[i], p = dft64_pair_swap(v);
+            const double o = (cl & 1) ? (v * tl.c[i] - p * tl.s[i]) : (v * tl.c[i] + p * tl.s[i]);
             const int ro = rt * 16 + q + 4 * i, fo = ro / N2, no = ro - fo * N2;
-            mid[fo][no * 16 + cl] = acc[i];
+            mid[fo][no * 16 + cl] = o;
         }
+    };
+    const int nf = min(16, g.M - fr0);                       // live frames of this tile (a streaming hop of a few streams: 1 .. 15)
+    const int nt1 = (nf * N2 + 15) / 16;                     // row tiles of stage 1 that hold a live frame
+    if (w < nt1) {
+        Tile ta, tb;
+        int rt = w;
+        load_tile(rt, ta);
+        for (; rt + 4 < nt1; rt += 8) {
+            load_tile(rt + 4, tb);
+            run_tile(rt, ta);
+            if (rt + 8 < nt1) load_tile(rt + 8, ta);
+            run_tile(rt + 4, tb);
+        }
+        if (rt < nt1) run_tile(rt, ta);
     }
+    // stage-2 operand: the N2-point DFT, the same for every row
+    double b2[C::KS * C::NT];
+#pragma unroll
+    for (int i = 0; i < C::KS * C::NT; ++i) b2[i] = g.tw2[(size_t)i * 64 + lane];
     __syncthreads();
 
-    // ---- stage 2: wave w takes k1 = 8 grp + 2 w + j ----
+    // ---- stage 2: rows (frame, k1), 8 row tiles; wave w takes tiles 2 w, 2 w + 1 ----
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int k1l = 2 * w + j, k1 = 8 * grp + k1l;
-        const double* bp = g.tw2 + (size_t)k1 * C::KS * C::NT * 64 + lane;
+        const int tile = 2 * w + j, fa = 2 * tile + (cl >> 3), k1a = cl & 7;
+        if (2 * tile >= nf) break;                           // (frames of dead tiles: rows of mid that stage 1 did not write)
         f64x4 acc[C::NT];
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt) acc[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < C::KS; ++kk) {
             const int n2 = 2 * kk + (q >> 1);           // K index 4 kk + q = (n2, re / im = q & 1)
-            const double a = n2 < N2 ? mid[cl][n2 * 16 + 2 * k1l + (q & 1)] : 0.0;
+            const double a = n2 < N2 ? mid[fa][n2 * 16 + 2 * k1a + (q & 1)] : 0.0;
 #pragma unroll
-            for (int nt = 0; nt < C::NT; ++nt) acc[nt] = mfma64(a, bp[(size_t)(kk * C::NT + nt) * 64], acc[nt]);
+            for (int nt = 0; nt < C::NT; ++nt) acc[nt] = mfma64(a, b2[kk * C::NT + nt], acc[nt]);
         }
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int col = nt * 16 + cl, k2 = col >> 1;
-                if (k2 < C::NK2) outs[q + 4 * i][k2][2 * k1l + (col & 1)] = (float)acc[nt][i];
+                const int row = q + 4 * i, col = nt * 16 + cl, k2 = col >> 1;
+                if (k2 < C::NK2) outs[2 * tile + (row >> 3)][k2][2 * (row & 7) + (col & 1)] = (float)acc[nt][i];
             }
     }
     __syncthreads();
     // [16 frames][k2][8 k1] bins of 8 bytes: a (frame, k2) is 8 consecutive bins k = 8 grp + 32 k2 ..
-    for (int idx = tid; idx < 16 * C::NK2 * 8; idx += 256) {
+    for (int idx = tid; idx < nf * C::NK2 * 8; idx += 256) {
         const int k1l = idx & 7, rest = idx >> 3, k2 = rest % C::NK2, fl = rest / C::NK2;
         const int fr = fr0 + fl, k = 8 * grp + k1l + 32 * k2;
         if (fr < g.M && k < C::F)
@@ -130,12 +184,12 @@ __global__ __launch_bounds__(256) void dft64_fwd_kernel(Dft64Args g) {
     }
 }
 
-// host: the two operand tables, doubles in MFMA B-fragment order
+// host: the operand tables, doubles in MFMA B-fragment order
 template <int N2>
-static inline void dft64_tables(std::vector<double>& tw1, std::vector<double>& tw2) {
+static inline void dft64_tables(std::vector<double>& tw1, std::vector<double>& twm, std::vector<double>& tw2) {
     using C = Dft64Cfg<N2>;
     auto ang = [](long num, int den) { return 2.0 * M_PI * (double)(num % den) / den; };
-    tw1.assign(C::TW1, 0.0); tw2.assign(C::TW2, 0.0);
+    tw1.assign(C::TW1, 0.0); twm.assign(C::TWM, 0.0); tw2.assign(C::TW2, 0.0);
     for (int grp = 0; grp < 4; ++grp)
         for (int kk = 0; kk < 8; ++kk)
             for (int lane = 0; lane < 64; ++lane) {
@@ -143,19 +197,23 @@ static inline void dft64_tables(std::vector<double>& tw1, std::vector<double>& t
                 const double a = ang((long)n1 * k1, 32);
                 tw1[((size_t)grp * 8 + kk) * 64 + lane] = (col & 1) ? -std::sin(a) : std::cos(a);
             }
-    for (int k1 = 0; k1 < 32; ++k1)
-        for (int kk = 0; kk < C::KS; ++kk)
-            for (int nt = 0; nt < C::NT; ++nt)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int k = 4 * kk + (lane >> 4), n2 = k >> 1, cc = k & 1;       // input (n2, re / im)
-                    const int col = nt * 16 + (lane & 15), k2 = col >> 1, cp = col & 1; // output (k2, re / im)
-                    double v = 0.0;
-                    if (n2 < N2 && k2 < C::NK2) {
-                        const double th = ang((long)n2 * (k1 + 32 * k2), C::N);        // times e^{-i th}
-                        v = (cc == cp) ? std::cos(th) : (cc ? std::sin(th) : -std::sin(th));
-                    }
-                    tw2[(((size_t)k1 * C::KS + kk) * C::NT + nt) * 64 + lane] = v;
+    for (int n2 = 0; n2 < N2; ++n2)
+        for (int k1 = 0; k1 < 32; ++k1) {
+            const double a = ang((long)n2 * k1, C::N);
+            twm[((size_t)n2 * 32 + k1) * 2] = std::cos(a); twm[((size_t)n2 * 32 + k1) * 2 + 1] = std::sin(a);
+        }
+    for (int kk = 0; kk < C::KS; ++kk)
+        for (int nt = 0; nt < C::NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int k = 4 * kk + (lane >> 4), n2 = k >> 1, cc = k & 1;       // input (n2, re / im)
+                const int col = nt * 16 + (lane & 15), k2 = col >> 1, cp = col & 1; // output (k2, re / im)
+                double v = 0.0;
+                if (n2 < N2 && k2 < C::NK2) {
+                    const double th = ang((long)n2 * k2, N2);                      // times e^{-i th}
+                    v = (cc == cp) ? std::cos(th) : (cc ? std::sin(th) : -std::sin(th));
                 }
+                tw2[((size_t)kk * C::NT + nt) * 64 + lane] = v;
+            }
 }
 
 static inline void launch_dft64_forward(hipStream_t st, const Dft64Args& a, int win) {

@@ -444,8 +444,8 @@ struct dpdf_model {
     DevBuf dft_mid_f, dft_mid_i;       // its intermediates [frames][30][64] (analysis / synthesis: they may run on different streams)
     long dbg_nspec = 0, dbg_nframes = 0;
     int dft2 = 1;                      // big launches: STFT / iSTFT as two small matrix stages (0: one [win x 2F] GEMM; A/B)
-    size_t dft64_tw1 = 0, dft64_tw2 = 0;   // operands of the float64 analysis DFT (dft64.h; doubles stored in the float arena)
-    int dft64 = 1;                     // analysis STFT in float64 on every call path (dft64.h): 1 = 48 kHz models (per-bin log-magnitude features), 2 = 16 kHz too, 0 = the fp32 forms (A/B)
+    size_t dft64_tw1 = 0, dft64_twm = 0, dft64_tw2 = 0;   // operands of the float64 analysis DFT (dft64.h; doubles stored in the float arena)
+    int dft64 = 2;                     // analysis STFT in float64 on every call path (dft64.h): 1 = 48 kHz models only (per-bin log-magnitude features), 2 = 16 kHz too (default: one analysis everywhere), 0 = the fp32 forms (A/B)
     bool use_dft64() const { return (d.win == 960 && dft64 >= 1) || (d.win == 320 && dft64 >= 2); }
     HostPipe hp;                       // pinned staging ring + copy streams of the host-pointer batch calls
     int host_pipe = 1;                 // host-pointer batch calls pipelined over time slices (0: one upload, compute, one download; A/B)
@@ -2002,10 +2002,11 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
 
     if (d.win == 960 || d.win == 320) {
         // ---- float64 analysis DFT (dft64.h) ----
-        std::vector<double> t1, t2;
-        if (d.win == 960) dft64_tables<30>(t1, t2); else dft64_tables<10>(t1, t2);
+        std::vector<double> t1, tm, t2;
+        if (d.win == 960) dft64_tables<30>(t1, tm, t2); else dft64_tables<10>(t1, tm, t2);
         auto as_floats = [](const std::vector<double>& v) { std::vector<float> f(v.size() * 2); memcpy(f.data(), v.data(), v.size() * sizeof(double)); return f; };
         m->dft64_tw1 = A.add(as_floats(t1));          // (arena slots start on 256-byte boundaries)
+        m->dft64_twm = A.add(as_floats(tm));
         m->dft64_tw2 = A.add(as_floats(t2));
     }
 
@@ -2540,7 +2541,7 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
             const RowSeg seg{Tc, T, t0};
             if (m->use_dft64()) {
                 Dft64Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, seg, 0, nullptr, m->raw_spec.p, B * Tc,
-                             (const double*)m->C(m->dft64_tw1), (const double*)m->C(m->dft64_tw2)};
+                             (const double*)m->C(m->dft64_tw1), (const double*)m->C(m->dft64_twm), (const double*)m->C(m->dft64_tw2)};
                 launch_dft64_forward(m->stream, da, d.win);
                 return DPDF_OK;
             }
@@ -2588,7 +2589,7 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
         StftA<64> ap{d_wav, N, T, d.win, d.hop, m->C(m->window), 0, d_lens};
         if (m->use_dft64()) {
             Dft64Args da{d_wav, N, T, d.hop, m->C(m->window), d_lens, RowSeg{T, T, 0}, 0, nullptr, m->raw_spec.p, B * T,
-                         (const double*)m->C(m->dft64_tw1), (const double*)m->C(m->dft64_tw2)};
+                         (const double*)m->C(m->dft64_tw1), (const double*)m->C(m->dft64_twm), (const double*)m->C(m->dft64_tw2)};
             launch_dft64_forward(m->stream, da, d.win);
         } else if (B * T <= SMALL_M_ROWS) {
             if ((rc = stft_small(m, ap, m->raw_spec.p, B * T))) return rc;
@@ -2802,7 +2803,7 @@ static int streams_enqueue_body(dpdf_streams* s, const StreamView& v, const floa
         if (in_place) ap.tail = v.in_tail;
         if (m->use_dft64()) {
             Dft64Args da{in_place ? src : xbuf, (T + 1) * d.hop, T, d.hop, m->C(m->window), nullptr, RowSeg{T, T, 0}, 1, in_place ? v.in_tail : nullptr,
-                         s->spec.p, S * T, (const double*)m->C(m->dft64_tw1), (const double*)m->C(m->dft64_tw2)};
+                         s->spec.p, S * T, (const double*)m->C(m->dft64_tw1), (const double*)m->C(m->dft64_twm), (const double*)m->C(m->dft64_tw2)};
             launch_dft64_forward(m->stream, da, d.win);
         } else if (S * T <= SMALL_M_ROWS) {
             if ((rc = stft_small(m, ap, s->spec.p, S * T, hop_fused))) return rc;
