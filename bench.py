@@ -30,6 +30,7 @@ from pathlib import Path
 
 import numpy as np
 
+_PROC_T0 = time.perf_counter()
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before torch / HIP initialise: see dpdfnet_amd/__init__.py
@@ -325,8 +326,8 @@ def other_configs(only=None) -> dict:
             m.enhance_batch_device(wav.data_ptr(), B, n, y.data_ptr(), None)
         m.sync()
         dt = (time.perf_counter() - t0) / reps
-        T = m.num_frames(n); m.close()
-        return B * T / dt, 1e3 * dt
+        T = m.num_frames(n); rec = m.recovery_count; m.close()
+        return B * T / dt, 1e3 * dt, rec
 
     def mfma(fps: float, sr: int, nb: int) -> float:
         return round(fps * FLOP_PER_FRAME_BY_MODEL[(sr, nb)] / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
@@ -344,6 +345,7 @@ def other_configs(only=None) -> dict:
         for _ in range(calls):
             st.process(pcm)
         dt = (time.perf_counter() - t0) / calls
+        rec = m.recovery_count
         st.close(); m.close()
         d = backend.query_dims(sr_, nb_)
         # Latency model of a hop: the two branches run side by side, each a chain of nb x (F' dependent
@@ -361,48 +363,117 @@ def other_configs(only=None) -> dict:
                 "mfma_frac": mfma(S / dt, sr_, nb_),
                 "latency_model": {"dependent_gru64_steps": steps, "dependent_launches_on_critical_path": chain,
                                   "bound_us": round(bound_us, 1), "achieved_over_bound": round(1e6 * dt / bound_us, 2)},
-                "io": "host PCM in, host PCM out (pinned staging, zero-copy), one device call per hop"}
+                "io": "host PCM in, host PCM out (pinned staging, zero-copy), one device call per hop", "recovery_count": rec}
 
     # Every side configuration is measured in a process of its own (`bench.py --side-config <name>`): engine handles created
     # one after the other in ONE process end up sharing hardware queues (section 3b of DESIGN.md) -- the fifth handle of the bench
     # process measured dpdfnet8 at 194.7 ms per step, a fresh process 187.0.
     if only == "one_clip":
-        fps, ms = offline(NB, 1, 5)
-        return {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5)}
+        fps, ms, rec = offline(NB, 1, 5)
+        return {"frames_per_s": round(fps), "ms_per_call": round(ms, 2), "rtf": round(ms / 1e3 / CLIP_SECONDS, 5), "recovery_count": rec}
     if only == "streams48":
         return streams(48000, 8, 64)                                           # BASELINE configs[4]
     if only == "streams16":
         return streams(16000, 2, 1)                                            # one StreamEnhancer (the reference's unit of work)
     if only in ("offline2", "offline8"):
         nb = int(only[-1])
-        fps, ms = offline(nb, 256, 3)
-        return {"frames_per_s": round(fps), "ms_per_step": round(ms, 2), "whole_path_frac": mfma(fps, SR, nb)}
+        fps, ms, rec = offline(nb, 256, 3)
+        return {"frames_per_s": round(fps), "ms_per_step": round(ms, 2), "whole_path_frac": mfma(fps, SR, nb), "recovery_count": rec}
+    if only == "offline48_2":                                                  # dpdfnet2_48khz_hr, 256 clips x 10 s (the 48 kHz family offline)
+        n48 = int(CLIP_SECONDS * 48000)
+        m = backend.HipModel(48000, 2, synth_blob(backend.manifest(48000, 2), WEIGHT_SEED), device=torch.cuda.current_device())
+        wav = torch.from_numpy(synth_clips(8, n48, 48000, 5000)).cuda().repeat(32, 1).contiguous()
+        y = torch.empty_like(wav)
+        m.enhance_batch_device(wav.data_ptr(), 256, n48, y.data_ptr(), None); m.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m.enhance_batch_device(wav.data_ptr(), 256, n48, y.data_ptr(), None)
+        m.sync()
+        dt = (time.perf_counter() - t0) / 3
+        fps = 256 * m.num_frames(n48) / dt
+        rec = m.recovery_count; m.close()
+        return {"frames_per_s": round(fps), "ms_per_step": round(1e3 * dt, 2), "whole_path_frac": mfma(fps, 48000, 2), "recovery_count": rec}
+    if only == "public_streams48":
+        return public_streams("dpdfnet8_48khz_hr", 48000, 64)
     if only is not None:
         raise SystemExit(f"unknown side configuration {only!r}")
 
-    def child(name: str) -> dict:
-        import subprocess
-        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--side-config", name], capture_output=True, text=True,
-                           timeout=900, env=dict(os.environ))
-        for l in r.stdout.splitlines():
-            if l.startswith("SIDE "):
-                return json.loads(l[len("SIDE "):])
-        return {"error": f"no result line (rc {r.returncode}): {r.stderr[-300:]}"}
-
-    # latency-bound configurations first
-    out[f"{MODEL}_16k_1x10s"] = child("one_clip")
-    out["dpdfnet8_48khz_hr_64_streams_1_hop"] = child("streams48")
-    try:
-        pub = public_streams_pass("dpdfnet8_48khz_hr", 48000, 64)
-        pub["public_group_over_c_abi"] = round(pub["us_per_call_public_group"] / out["dpdfnet8_48khz_hr_64_streams_1_hop"]["us_per_call"], 3)
-        pub["public_pool_over_c_abi"] = round(pub["us_per_round_public_pool_4_threads"] / out["dpdfnet8_48khz_hr_64_streams_1_hop"]["us_per_call"], 3)
-        out["dpdfnet8_48khz_hr_64_streams_1_hop"]["public_objects"] = pub
-    except Exception as exc:
-        out["dpdfnet8_48khz_hr_64_streams_1_hop"]["public_objects"] = {"error": f"{type(exc).__name__}: {exc}"}
-    out["dpdfnet2_16k_1_stream_1_hop"] = child("streams16")
+    # ONE child process for all of them (`bench.py --side-config all`): it imports torch and the package once -- on a cold box the
+    # imports are most of a fresh process's time -- and then FORKS one worker per configuration before anything has touched the
+    # GPU, so that every configuration still runs in a process with no other engine handle and no HIP state of its predecessors.
+    rc, so, se = run_child_streaming([sys.executable, str(Path(__file__).resolve()), "--side-config", "all"], 600.0, dict(os.environ))
+    res = None
+    for l in so.splitlines():
+        if l.startswith("SIDE "):
+            res = json.loads(l[len("SIDE "):])
+    if res is None:
+        return {"error": f"no result line from the side-configuration process (rc {rc}): {se[-300:]}"}
+    out[f"{MODEL}_16k_1x10s"] = res["one_clip"]
+    s48 = res["streams48"]
+    pub = res["public_streams48"]
+    if "error" not in pub and "us_per_call" in s48:
+        pub["public_group_over_c_abi"] = round(pub["us_per_call_public_group"] / s48["us_per_call"], 3)
+        pub["public_pool_over_c_abi"] = round(pub["us_per_round_public_pool_4_threads"] / s48["us_per_call"], 3)
+    s48["public_objects"] = pub
+    out["dpdfnet8_48khz_hr_64_streams_1_hop"] = s48
+    out["dpdfnet2_16k_1_stream_1_hop"] = res["streams16"]
     for nb in (2, 8):
-        out[f"dpdfnet{nb}_16k_256x10s"] = child(f"offline{nb}")
+        out[f"dpdfnet{nb}_16k_256x10s"] = res[f"offline{nb}"]
+    out["dpdfnet2_48khz_hr_256x10s"] = res["offline48_2"]
+    out["side_process"] = res.get("_timing")
     return out
+
+
+SIDE_ORDER = ("one_clip", "streams48", "public_streams48", "streams16", "offline2", "offline8", "offline48_2")
+
+
+def side_all() -> dict:
+    """`bench.py --side-config all`: torch, numpy and the package imported ONCE, no GPU call made; then one fork per configuration
+    (latency-bound ones first).  The fork child runs `other_configs(name)` in a process that has never initialised HIP, writes its
+    JSON to a pipe and leaves with os._exit; a configuration that overruns 240 s is killed -- that exact pid -- and reported."""
+    import select
+    import signal
+    import torch  # noqa: F401   (imported, not initialised: torch.cuda is lazy)
+    import dpdfnet_amd  # noqa: F401
+    from dpdfnet_amd import backend, weights  # noqa: F401
+    res, timing = {}, {"imports_s": round(time.perf_counter() - _PROC_T0, 2)}
+    for name in SIDE_ORDER:
+        t0 = time.perf_counter()
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            os.close(r)
+            try:
+                torch.cuda.set_device(0)
+                payload = other_configs(name)
+            except BaseException as exc:      # the parent must always get a line
+                payload = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            try:
+                os.write(w, json.dumps(payload).encode())
+            finally:
+                os._exit(0)
+        os.close(w)
+        data, deadline = b"", time.perf_counter() + 240.0
+        while True:
+            left = deadline - time.perf_counter()
+            if left <= 0:
+                os.kill(pid, signal.SIGKILL)
+                data = json.dumps({"error": "timed out after 240 s"}).encode()
+                break
+            if select.select([r], [], [], min(left, 1.0))[0]:
+                chunk = os.read(r, 1 << 16)
+                if not chunk:
+                    break
+                data += chunk
+        os.close(r)
+        os.waitpid(pid, 0)
+        try:
+            res[name] = json.loads(data.decode()) if data else {"error": "the worker wrote nothing"}
+        except ValueError:
+            res[name] = {"error": f"unparsable worker output: {data[:200]!r}"}
+        timing[name + "_s"] = round(time.perf_counter() - t0, 2)
+    res["_timing"] = timing
+    return res
 
 
 def _free_port() -> int:
@@ -427,31 +498,50 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def _stamp(stage: str) -> None:
+    """One line per stage on stderr, flushed as it happens: what a parent that has to give up on this process still holds."""
+    print(f"STAGE {time.perf_counter() - _PROC_T0:8.2f}s {stage}", file=sys.stderr, flush=True)
+
+
 def dist_selftest_worker() -> None:
     """`bench.py --dist-selftest-only`: one rank, backend nccl (= RCCL on ROCm): communicator init bound to the device, the
     collectives the N > 1 path of this file uses (all_reduce MAX on a device tensor = the max-over-ranks clock, barrier,
     all_gather_object, a grouped isend/irecv = gather_to_root's launch shape) -- so that RCCL has executed this code's
-    calls on the box even where only one GPU is leased.  Prints one JSON object."""
+    calls on the box even where only one GPU is leased.  Every stage is stamped on stderr BEFORE it starts (the parent keeps
+    the stamps when it has to kill this process: `hung_at`); prints one JSON object on stdout."""
     import datetime
+    _stamp("import torch")
     import torch
     import torch.distributed as dist
     res = {"backend": "nccl (RCCL)", "world_size": 1}
+    if os.environ.get("DPDF_BENCH_FAKE_RCCL_HANG") == "1":       # test hook: a communicator init that never returns
+        _stamp("init_process_group(nccl) [DPDF_BENCH_FAKE_RCCL_HANG=1: sleeping instead]")
+        time.sleep(3600)
     t0 = time.perf_counter()
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(_free_port())
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        _stamp("torch.cuda.set_device(0)")
         torch.cuda.set_device(0)
+        _stamp("first device touch (torch.zeros on cuda:0)")
+        torch.zeros(1, device="cuda"); torch.cuda.synchronize()
+        res["device_up_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
+        _stamp("init_process_group(nccl, world_size=1, device_id=cuda:0)")
+        t1 = time.perf_counter()
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
-                                timeout=datetime.timedelta(seconds=60))
-        res["init_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
+                                timeout=datetime.timedelta(seconds=45))
+        res["init_ms"] = round(1e3 * (time.perf_counter() - t1), 1)
         t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+        _stamp("all_reduce(MAX)")
         t1 = time.perf_counter()
         dist.all_reduce(t, op=dist.ReduceOp.MAX); torch.cuda.synchronize()
         res["first_all_reduce_ms"] = round(1e3 * (time.perf_counter() - t1), 1)
         res["all_reduce_ok"] = bool(float(t.item()) == 1.25)
+        _stamp("barrier")
         dist.barrier(); torch.cuda.synchronize()
         res["barrier_ok"] = True
+        _stamp("all_gather_object")
         objs = [None]
         dist.all_gather_object(objs, {"rank": 0})
         res["all_gather_object_ok"] = objs == [{"rank": 0}]
@@ -461,6 +551,7 @@ def dist_selftest_worker() -> None:
         except Exception:
             pass
         try:        # gather_to_root's launch shape (one grouped isend + irecv), rank 0 to itself
+            _stamp("batch_isend_irecv (self)")
             a = torch.arange(1 << 20, dtype=torch.float32, device="cuda"); b = torch.zeros_like(a)
             for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, 0), dist.P2POp(dist.isend, a, 0)]):
                 q.wait()
@@ -469,29 +560,125 @@ def dist_selftest_worker() -> None:
         except Exception as exc:
             res["grouped_p2p_self_ok"] = False
             res["grouped_p2p_self_error"] = f"{type(exc).__name__}: {exc}"[:200]
+        _stamp("destroy_process_group")
         dist.destroy_process_group()
         res["rccl_init_ok"] = bool(res["all_reduce_ok"] and res["barrier_ok"] and res["all_gather_object_ok"])
     except Exception as exc:
         res["rccl_init_ok"] = False
         res["error"] = f"{type(exc).__name__}: {exc}"[:300]
+    res["total_s"] = round(time.perf_counter() - _PROC_T0, 2)
+    _stamp("done")
     print("DIST_SELFTEST " + json.dumps(res), flush=True)
 
 
-def dist_selftest(timeout_s: float = 180.0) -> dict:
-    """Run `dist_selftest_worker` in its OWN process under a timeout: a broken or hanging RCCL install is reported on the
-    line (`rccl_init_ok: false`) and can never take the headline measurement with it."""
+def run_child_streaming(cmd, timeout_s: float, env=None):
+    """Run `cmd`, collecting stdout and stderr AS THEY ARRIVE (reader threads), and kill it -- the exact process we started --
+    at the deadline.  Returns (rc or None if killed, stdout, stderr): what a child printed before it hung is kept."""
     import subprocess
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, bufsize=1)
+    bufs = {"out": [], "err": []}
+
+    def pump(stream, key):
+        for line in stream:
+            bufs[key].append(line)
+
+    ths = [threading.Thread(target=pump, args=(p.stdout, "out"), daemon=True), threading.Thread(target=pump, args=(p.stderr, "err"), daemon=True)]
+    for th in ths:
+        th.start()
+    rc = None
     try:
-        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--dist-selftest-only"], capture_output=True, text=True,
-                           timeout=timeout_s, env=dict(os.environ))
-        for l in r.stdout.splitlines():
-            if l.startswith("DIST_SELFTEST "):
-                return json.loads(l[len("DIST_SELFTEST "):])
-        return {"rccl_init_ok": False, "error": f"no result line (rc {r.returncode}): {r.stderr[-300:]}"}
+        rc = p.wait(timeout=timeout_s)
     except subprocess.TimeoutExpired:
-        return {"rccl_init_ok": False, "error": f"timed out after {timeout_s:g} s"}
+        p.kill()
+        p.wait()
+    for th in ths:
+        th.join(timeout=5)
+    return rc, "".join(bufs["out"]), "".join(bufs["err"])
+
+
+def dist_selftest(timeout_s: float = 60.0) -> dict:
+    """Run `dist_selftest_worker` in its OWN process under a deadline, with NCCL_DEBUG=INFO: a broken or hanging RCCL install is
+    reported on the line with the stage it hung at and the tail of RCCL's own log, and can never take the headline measurement
+    with it."""
+    t0 = time.perf_counter()
+    env = dict(os.environ, NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "INFO"))
+    try:
+        rc, out, err = run_child_streaming([sys.executable, str(Path(__file__).resolve()), "--dist-selftest-only"], timeout_s, env)
     except Exception as exc:
         return {"rccl_init_ok": False, "error": f"{type(exc).__name__}: {exc}"[:300]}
+    stages = [l[len("STAGE "):].strip() for l in err.splitlines() if l.startswith("STAGE ")]
+    res = None
+    for l in out.splitlines():
+        if l.startswith("DIST_SELFTEST "):
+            res = json.loads(l[len("DIST_SELFTEST "):])
+    if res is None:
+        log = "\n".join(l for l in (out + err).splitlines() if not l.startswith("STAGE "))
+        res = {"rccl_init_ok": False,
+               "error": (f"timed out after {timeout_s:g} s" if rc is None else f"no result line (rc {rc})"),
+               "hung_at": stages[-1] if stages else "before the first stage (interpreter start-up)",
+               "log_tail": log[-2048:]}
+    res["stages"] = stages
+    res["wall_s"] = round(time.perf_counter() - t0, 2)
+    return res
+
+
+def reexec_with_gloo_fallback(reason: str) -> None:
+    """RCCL did not come up (or stopped answering) on this node: replace THIS rank's process image with the same command line on
+    `--backend gloo --fallback-reason ...` (same PID, so the launcher that watches the rank sees nothing die).  Every rank gets
+    here on its own -- by its watchdog, or by the exception RCCL raised -- and they meet again at a fresh TCP rendezvous one
+    port above the launcher's.  The line then says `collective: "FALLBACK gloo: <reason>"`, the per-GPU compute figures are
+    still measured, rc stays 0."""
+    argv = [a for a in sys.argv[1:]]
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a == "--backend":
+            skip = True
+            continue
+        if a.startswith("--backend="):
+            continue
+        out.append(a)
+    reason = " ".join(str(reason).split())[:300]
+    env = dict(os.environ)
+    env.setdefault("DPDF_BENCH_FALLBACK_PORT", str(int(env.get("MASTER_PORT", "29500")) + 17))
+    print(f"[bench.py] rank {env.get('RANK', '0')}: RCCL unusable ({reason}); re-executing on --backend gloo (control plane + host-staged "
+          f"gather), rendezvous 127.0.0.1:{env['DPDF_BENCH_FALLBACK_PORT']}", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execve(sys.executable, [sys.executable, str(Path(__file__).resolve())] + out + ["--backend", "gloo", "--fallback-reason", reason], env)
+
+
+class CollectiveWatchdog:
+    """A hang inside RCCL (communicator init, a collective whose peer never arrives) raises nothing: a timer thread re-executes the
+    rank on the gloo fallback when the watched section overruns its deadline.  `stage()` names what is running (it goes on the
+    line as the reason); `disarm()` ends the watch."""
+
+    def __init__(self) -> None:
+        self._timer = None
+        self._stage = "(not started)"
+        self._lock = threading.Lock()
+
+    def stage(self, name: str) -> None:
+        self._stage = name
+        print(f"STAGE {time.perf_counter() - _PROC_T0:8.2f}s rank {os.environ.get('RANK', '0')}: {name}", file=sys.stderr, flush=True)
+
+    def arm(self, seconds: float, stage: str) -> None:
+        self.disarm()
+        self.stage(stage)
+        with self._lock:
+            self._timer = threading.Timer(seconds, self._fire, args=(seconds,))
+            self._timer.daemon = True
+            self._timer.start()
+
+    def disarm(self) -> None:
+        with self._lock:
+            if self._timer is not None:
+                self._timer.cancel()
+                self._timer = None
+
+    def _fire(self, seconds: float) -> None:
+        reexec_with_gloo_fallback(f"no answer within {seconds:g} s at stage `{self._stage}`")
 
 
 def main() -> None:
@@ -524,8 +711,12 @@ def main() -> None:
     ap.add_argument("--ref-slots", default="", help=argparse.SUPPRESS)
     ap.add_argument("--public-streams-only", default="", help=argparse.SUPPRESS)
     ap.add_argument("--side-config", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--fallback-reason", default="", help=argparse.SUPPRESS)      # set by reexec_with_gloo_fallback
     args = ap.parse_args()
 
+    if args.side_config == "all":
+        print("SIDE " + json.dumps(side_all()), flush=True)
+        return
     if args.side_config:
         import torch
         torch.cuda.set_device(0)
@@ -548,11 +739,22 @@ def main() -> None:
         # plain `python bench.py --gpus N`: become the launcher (under torch.distributed.run WORLD_SIZE is set and we fall through)
         raise SystemExit(self_launch(args.gpus))
 
+    timeline = {}
+    marks = [time.perf_counter()]
+
+    def mark(name: str) -> None:
+        """Wall seconds of the phase that just ended (rides on the line as `timeline_s`: where a driver's clock around the run goes)."""
+        now = time.perf_counter()
+        timeline[name] = round(timeline.get(name, 0.0) + now - marks[0], 2)
+        marks[0] = now
+
+    timeline["interpreter_start_to_main"] = round(marks[0] - _PROC_T0, 2)
     import torch
     import torch.distributed as dist
     from dpdfnet_amd import backend
     from dpdfnet_amd.weights import synth_blob
     from dpdfnet_amd.multi_gpu import shard_range, gather_to_root
+    mark("import_torch_and_engine")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -561,16 +763,46 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
-    if args.backend != "nccl":
-        local_rank %= torch.cuda.device_count()      # functional test mode: ranks may share a GPU
+    fake_hang = os.environ.get("DPDF_BENCH_FAKE_RCCL_HANG") == "1"      # test hook: RCCL's init never returns (exercises the fallback on one GPU)
+    if args.backend != "nccl" or fake_hang:
+        local_rank %= torch.cuda.device_count()      # functional test mode / fallback: ranks may share a GPU (on a full node they do not)
     elif local_rank >= torch.cuda.device_count():
         raise SystemExit(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs are visible: one rank per GPU")
     torch.cuda.set_device(local_rank)
     rccl_ranks = None
+    wd = CollectiveWatchdog()
+    wd_s = float(os.environ.get("DPDF_BENCH_RCCL_WATCHDOG_S", "120"))
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            # communicator init + the first collectives under a watchdog: RCCL hangs raise nothing (round 4: a ONE-rank init sat
+            # for 180 s on the driver's box); overrun or exception -> the rank re-executes itself on the gloo fallback
+            try:
+                wd.arm(wd_s, "init_process_group(nccl, device_id)")
+                if fake_hang:
+                    time.sleep(3600)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=wd_s + 60))
+                wd.stage("pre-flight: all_reduce on the device")
+                one = torch.ones(1, device="cuda")
+                dist.all_reduce(one); torch.cuda.synchronize()
+                if int(one.item()) != world:
+                    raise RuntimeError(f"all_reduce of ones gave {one.item()} on {world} ranks")
+                wd.stage("pre-flight: grouped point-to-point gather (4 MB per rank)")
+                probe = torch.full((1, 1 << 20), float(rank), device="cuda")
+                got = gather_to_root(probe, world, rank); torch.cuda.synchronize()
+                if rank == 0 and [float(got[r, 0, 0]) for r in range(world)] != [float(r) for r in range(world)]:
+                    raise RuntimeError("grouped p2p gather delivered the wrong rows")
+                wd.stage("pre-flight: all_gather_object")
+            except SystemExit:
+                raise
+            except Exception as exc:
+                wd.disarm()
+                reexec_with_gloo_fallback(f"{type(exc).__name__} at stage `{wd._stage}`: {exc}")
+        elif args.fallback_reason:
+            dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{os.environ['DPDF_BENCH_FALLBACK_PORT']}",
+                                    rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         else:
             dist.init_process_group(backend=args.backend)
         # pre-flight: the process group really has N ranks and (under RCCL) every rank sits on its own GPU
@@ -585,6 +817,15 @@ def main() -> None:
             devs = [(r["device"], r["uuid"]) for r in rccl_ranks]
             if len(set(devs)) != world:
                 raise SystemExit(f"ranks share a GPU under RCCL: {rccl_ranks}")
+        wd.disarm()
+
+    rccl_selftest = None
+    if world == 1 and args.dist_selftest is not False:
+        # RCCL executed on this box (one rank): communicator init on the device + the collectives the N > 1 path uses.  FIRST, on an
+        # idle GPU and with torch's files already paged in by the import above (a fresh box takes a minute for the first import: that
+        # is not RCCL's time), in a process of its own under a 60 s deadline.
+        rccl_selftest = dist_selftest()
+        mark("rccl_selftest_child")
 
     blob = synth_blob(backend.manifest(SR, NB), WEIGHT_SEED)
     model = backend.HipModel(SR, NB, blob, device=local_rank)
@@ -605,11 +846,18 @@ def main() -> None:
     out = torch.empty_like(wav)
     gathered = None
     do_gather = world > 1 and not args.no_gather
+    fallback = bool(args.fallback_reason)                 # this rank was re-executed on gloo because RCCL did not answer
     gather_note = "none (single GPU)" if world == 1 else ((("rccl" if args.backend == "nccl" else args.backend) + " gather to rank 0") if do_gather else "disabled")
+    if fallback:
+        gather_note = (f"FALLBACK gloo: {args.fallback_reason}; barriers / clocks over gloo, the enhanced PCM gathered to rank 0 over gloo through "
+                       "pinned host staging ONCE behind the timed region (timed separately), not inside it")
     collective_error = None
+    # the gather rides inside the timed region over RCCL (asynchronous, under the next step's compute); over the fallback's TCP
+    # loopback it would be what is measured instead of the GPUs, so there it runs once, behind the region
+    gather_in_timed = do_gather and not fallback
 
     # two output buffers: with N > 1 the RCCL gather of step i reads one while the engine writes step i+1 into the other
-    outs = [out, torch.empty_like(out)] if do_gather else [out, out]
+    outs = [out, torch.empty_like(out)] if gather_in_timed else [out, out]
     # The gather runs on RCCL's stream, the engine on its own private stream: nothing orders them but the host.  An event
     # recorded behind gather i is waited for (on the host; it is a whole step old by then) before step i+2 reuses its buffer.
     gather_done = [None, None]
@@ -624,10 +872,14 @@ def main() -> None:
         model.sync()
         torch.cuda.synchronize()
 
+    mark("setup_model_and_clips")
     for _ in range(args.warmup):
         step()
     sync()
+    mark("warmup_steps")
     if do_gather:
+        if args.backend == "nccl":
+            wd.arm(wd_s, "warm-up gather of the enhanced PCM over RCCL")
         try:
             gathered = gather_to_root(out, world, rank)
             torch.cuda.synchronize()
@@ -641,8 +893,13 @@ def main() -> None:
         flags = [None] * world
         dist.all_gather_object(flags, bool(do_gather))
         do_gather = all(flags)                            # every rank takes the same path
+        gather_in_timed = gather_in_timed and do_gather
+        wd.disarm()
 
     # ---- the timed region: EXACTLY --steps steps, per-kernel profiling OFF ----
+    rec0 = model.recovery_count
+    if world > 1 and args.backend == "nccl":
+        wd.arm(wd_s + 2.0 * args.steps, "timed region (barrier, steps, asynchronous gathers, barrier)")
     if world > 1:
         dist.barrier()
     sync()
@@ -650,7 +907,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-        if do_gather:
+        if gather_in_timed:
             model.sync()          # host waits for this rank's step i; the gather below is asynchronous (RCCL's stream),
             tg = time.perf_counter()
             gathered = gather_to_root(outs[i & 1], world, rank, gathered)   # so it runs under the compute of step i+1
@@ -660,6 +917,9 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     dt_local = time.perf_counter() - t0
+    wd.disarm()
+    recoveries = model.recovery_count - rec0          # calls of the timed region that were re-run after a device-side time-out (must be 0)
+    mark("timed_region")
     dt = dt_local
     per_rank_ms = [1e3 * dt_local / args.steps]
     if world > 1:
@@ -673,6 +933,12 @@ def main() -> None:
     parity_slots = sorted({0, B // 2, B - 1})
     timed_out_host = {b: outs[(args.steps - 1) & 1][b].cpu().numpy() for b in parity_slots} if rank == 0 and args.steps > 0 else {}
     gather_check = None
+    fallback_gather_ms = None
+    if do_gather and fallback:
+        tg = time.perf_counter()
+        gathered = gather_to_root(outs[(args.steps - 1) & 1], world, rank, gathered)
+        dist.barrier()
+        fallback_gather_ms = 1e3 * (time.perf_counter() - tg)
     if do_gather:      # validate the gathered PCM once, outside the timed region: rank r's rows must be rank r's own output
         mine = torch.stack([outs[(args.steps - 1) & 1].double().sum(), outs[(args.steps - 1) & 1].double().abs().sum()]).cpu()
         sums = [None] * world
@@ -705,6 +971,7 @@ def main() -> None:
         model.profile(False)
         model.set_overlap(args.overlap if args.overlap >= 0 else 27)
 
+    mark("per_kernel_event_passes")
     # ---- SURVEY 8(d)'s full metric: the same steps INCLUDING H2D of the noisy PCM and D2H of the enhanced PCM ----
     # Through the PRODUCT: the library's own host-pointer call (dpdf_enhance_batch: numpy block in, numpy block out, pageable
     # memory), which pipelines upload / compute / download over time slices inside the library (pinned staging ring, copy
@@ -735,6 +1002,7 @@ def main() -> None:
                 "finite_output": bool(np.isfinite(y_host).all()),
                 "max_abs_diff_vs_hbm_resident_output": (max(float(np.abs(y_host[b] - ref_slots[b]).max()) for b in ref_slots) if ref_slots else None)}
 
+    mark("pcie_inclusive_passes")
     if rank == 0:
         finite = bool(torch.isfinite(out).all().item())
         total_frames = world * B * T * args.steps
@@ -780,13 +1048,16 @@ def main() -> None:
         line["value_hbm_resident"] = value
         if not args.no_parity and timed_out_host:
             line["parity"] = parity_vs_oracle(blob, wav_host, timed_out_host, parity_slots)
+            mark("parity_vs_oracle")
             if not line["parity"]["ok"]:
                 print(f"[bench.py] PARITY FAILURE on the timed shape: {line['parity']}", file=sys.stderr, flush=True)
         if pcie is not None:
             line.update({"value_incl_pcie": pcie["value_incl_pcie"], "ms_per_step_incl_pcie": pcie["ms_per_step_incl_pcie"]})
             line["pcie"] = pcie
         if world > 1:
-            line["multi_gpu"] = {"backend": "rccl" if args.backend == "nccl" else args.backend, "rccl_ranks": rccl_ranks,
+            line["multi_gpu"] = {"backend": "rccl" if args.backend == "nccl" else (args.backend + (" (FALLBACK: RCCL did not answer)" if fallback else "")),
+                                 "fallback_reason": args.fallback_reason or None, "fallback_gather_ms_once_outside_timed_region": fallback_gather_ms,
+                                 "gather_inside_timed_region": bool(gather_in_timed), "rccl_ranks": rccl_ranks,
                                  "per_rank": per_rank_ms, "collective_ok": bool(do_gather) if not args.no_gather else None,
                                  "collective_error": collective_error, "gathered_matches_rank_outputs": gather_check,
                                  "gathered_shape": list(gathered.shape) if gathered is not None else None}
@@ -856,6 +1127,7 @@ def main() -> None:
             print("[bench.py] no GRU-64 kernel launches were profiled (--profile-steps 0?): the roofline block is empty", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blob, args.cpu_clip_seconds, args.cpu_clips_per_thread)
+            mark("cpu_baseline")
             # the reference's own CPU runtime, if this box has it (it does not offline: then the leg is reported as absent, not faked)
             onnx_path = os.environ.get("DPDFNET_ONNX", "")
             try:
@@ -865,10 +1137,9 @@ def main() -> None:
             except Exception as exc:
                 line["cpu_baseline"]["reference_runtime"] = {"kind": "ort", "available": False,
                                                               "why": f"{type(exc).__name__}: {exc}"[:200]}
-        if world == 1 and args.dist_selftest is not False:
-            # RCCL executed on this box (one rank): communicator init on the device + the collectives the N > 1 path uses
-            line["rccl_selftest"] = dist_selftest()
-            line["rccl_init_ok"] = bool(line["rccl_selftest"].get("rccl_init_ok"))
+        if rccl_selftest is not None:
+            line["rccl_selftest"] = rccl_selftest
+            line["rccl_init_ok"] = bool(rccl_selftest.get("rccl_init_ok"))
         if world == 1 and not args.no_pcie:
             model.close()       # the public API builds its own (cached) handle: give it the device
             try:
@@ -877,17 +1148,29 @@ def main() -> None:
                 line["public_api_over_hbm_resident"] = line["value_public_api"] / value
             except Exception as exc:
                 line["public_api"] = {"error": f"{type(exc).__name__}: {exc}"}
+            mark("public_api_child")
         if world == 1 and not args.no_other_configs and not args.no_isolated:
             model.close()       # the side configurations get the device to themselves (the headline engine's 33 GB workspace and four streams go first)
             try:
                 line["other_configs"] = other_configs()
             except Exception as exc:  # never lose the headline line over the side measurements
                 line["other_configs"] = {"error": f"{type(exc).__name__}: {exc}"}
-        print(json.dumps(line))
+            mark("other_configs_children")
+        # forward-progress hygiene: a GRU-256 cluster exchange / hop hand-off that timed out costs ~1 s and a re-run on the non-spinning
+        # kernels (dpdf_recovery_count).  In the timed region that would silently be a wrong measurement: it is on the line, and fatal.
+        line["recovery_count"] = recoveries
+        timeline["total"] = round(time.perf_counter() - _PROC_T0, 2)
+        line["timeline_s"] = timeline
+        print(json.dumps(line), flush=True)
+        if recoveries:
+            print(f"[bench.py] FATAL: {recoveries} call(s) inside the timed region were re-run after a device-side time-out "
+                  "(dpdf_recovery_count): `value` includes the time-out and the re-run and is not a measurement", file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     model.close()
+    if rank == 0 and recoveries:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

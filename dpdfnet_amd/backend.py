@@ -9,6 +9,7 @@ if the shared library or a GPU is missing, loading/creating fails loudly.
 from __future__ import annotations
 
 import contextlib
+import collections
 import ctypes
 import math
 import os
@@ -16,7 +17,7 @@ import threading
 import weakref
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Dict, List, Optional, Tuple, Union
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -52,7 +53,8 @@ EXPORTED_SYMBOLS = (
     "dpdf_resample_len", "dpdf_resample", "dpdf_enhance_batch_ragged", "dpdf_debug_raise_device_error",
     "dpdf_set_option", "dpdf_streams_process_masked", "dpdf_streams_set_state", "dpdf_streams_get_tails",
     "dpdf_streams_prime_one", "dpdf_streams_is_primed", "dpdf_recovery_count", "dpdf_progress",
-    "dpdf_enhance_batch_rows",
+    "dpdf_enhance_batch_rows", "dpdf_streams_pool_config", "dpdf_streams_slot_use", "dpdf_streams_submit_wait",
+    "dpdf_streams_submit_many", "dpdf_streams_submit_block", "dpdf_streams_pool_stats",
 )
 
 
@@ -61,27 +63,96 @@ def lib_path() -> Path:
     return Path(override) if override else _PKG_DIR / _LIB_NAME
 
 
-def _preload_torch_hip_runtime() -> None:
-    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own `libamdhip64.so.7` / `libhsa-runtime64.so.1` under
-    torch/lib with the SAME sonames as the system ROCm: whichever copy is loaded first serves both.  With the system copy first
-    (this library loaded before torch) a later `torch.cuda` initialisation finds "No HIP GPUs"; with torch's copy first both
-    work (bench.py's order).  So if torch is installed but not imported yet, its bundled runtime is loaded here -- by path, torch
-    itself is NOT imported -- before the engine library.  DPDFNET_NO_TORCH_HIP_PRELOAD=1 opts out."""
+def _elf_dynamic(path: Path):
+    """(SONAME, [NEEDED...]) of a 64-bit little-endian ELF shared object, read from its dynamic section (no external tools)."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+        raise ValueError("not a 64-bit little-endian ELF file")
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    soname, needed = None, []
+    for sec in secs:
+        if sec[1] != 6:                      # SHT_DYNAMIC
+            continue
+        strtab = secs[sec[6]]                # sh_link: its string table
+        for off in range(sec[4], sec[4] + sec[5], 16):
+            tag, val = struct.unpack_from("<qQ", data, off)
+            if tag == 0:
+                break
+            if tag in (1, 14):               # DT_NEEDED, DT_SONAME
+                beg = strtab[4] + val
+                name = data[beg:data.index(b"\0", beg)].decode()
+                if tag == 1:
+                    needed.append(name)
+                else:
+                    soname = name
+    return soname, needed
+
+
+_preload_note = ""       # what the loader did about torch's bundled HIP runtime (one line; `preload_note()`)
+
+
+def preload_note() -> str:
+    return _preload_note
+
+
+def _preload_torch_hip_runtime(engine: Path) -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own `libamdhip64` / `libhsa-runtime64` under torch/lib, and
+    whichever copy of a soname is loaded first serves everybody: with the system copy first (this library loaded before torch) a
+    later `torch.cuda` initialisation finds "No HIP GPUs"; with torch's copy first both work (bench.py's order).  So when torch is
+    installed but not imported yet, its bundled runtime is loaded here first -- by path, torch itself is NOT imported -- but ONLY
+    if BOTH bundled sonames are exactly the ones the engine library was linked against (read from the ELF headers): a wheel
+    whose HSA soname differs while its HIP soname matches would bind the system HIP to the wheel's older HSA, and is left alone
+    (the engine then runs on the system runtime; import torch first if both are needed).  DPDFNET_TORCH_HIP_PRELOAD=0 never
+    preloads, =1 forces it; every outcome is kept in `preload_note()` and printed when DPDFNET_VERBOSE is set."""
+    global _preload_note
     import sys
-    if os.environ.get("DPDFNET_NO_TORCH_HIP_PRELOAD", "") not in ("", "0") or "torch" in sys.modules:
-        return
+
+    def note(msg: str) -> None:
+        global _preload_note
+        _preload_note = msg
+        if os.environ.get("DPDFNET_VERBOSE", "") not in ("", "0"):
+            print(f"[dpdfnet_amd] {msg}", file=sys.stderr)
+
+    mode = os.environ.get("DPDFNET_TORCH_HIP_PRELOAD", "")
+    if os.environ.get("DPDFNET_NO_TORCH_HIP_PRELOAD", "") not in ("", "0"):      # earlier spelling of the opt-out
+        mode = "0"
+    if mode == "0":
+        return note("torch HIP runtime preload: off (DPDFNET_TORCH_HIP_PRELOAD=0)")
+    if "torch" in sys.modules:
+        return note("torch HIP runtime preload: not needed (torch is imported already: its runtime is the process's runtime)")
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.origin:
-            return
+            return note("torch HIP runtime preload: torch is not installed")
         libdir = Path(spec.origin).parent / "lib"
-        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-            f = libdir / name
-            if f.is_file():
-                ctypes.CDLL(str(f), mode=ctypes.RTLD_GLOBAL)
-    except Exception:
-        pass          # best effort: the engine itself runs on either copy
+        files = [libdir / "libhsa-runtime64.so", libdir / "libamdhip64.so"]
+        if not all(f.is_file() for f in files):
+            return note("torch HIP runtime preload: this torch build bundles no HIP runtime")
+        if mode != "1":
+            _, needed = _elf_dynamic(engine)
+            want_hip = next((n for n in needed if n.startswith("libamdhip64.so")), None)
+            hip_soname, _ = _elf_dynamic(files[1])
+            hsa_soname, _ = _elf_dynamic(files[0])
+            sys_hsa = None          # the HSA soname the SYSTEM HIP runtime wants (what the engine would get without the preload)
+            for d in ("/opt/rocm/lib", "/opt/rocm/lib64"):
+                cand = Path(d) / (want_hip or "libamdhip64.so")
+                if cand.is_file():
+                    sys_hsa = next((n for n in _elf_dynamic(cand.resolve())[1] if n.startswith("libhsa-runtime64.so")), None)
+                    break
+            if hip_soname != want_hip or (sys_hsa is not None and hsa_soname != sys_hsa):
+                return note(f"torch HIP runtime preload: SKIPPED, sonames differ (engine needs {want_hip}, system HSA {sys_hsa}; torch bundles "
+                            f"{hip_soname} / {hsa_soname}): the engine runs on the system ROCm; import torch BEFORE dpdfnet_amd if both are used")
+        for f in files:
+            ctypes.CDLL(str(f), mode=ctypes.RTLD_GLOBAL)
+        note(f"torch HIP runtime preload: loaded {files[1]} + {files[0].name} (same sonames as the engine's ROCm) so that a later `import torch` "
+             "shares the process's one HIP runtime")
+    except Exception as exc:          # best effort: the engine itself runs on either copy
+        note(f"torch HIP runtime preload: failed ({type(exc).__name__}: {exc}); the engine runs on the system ROCm")
 
 
 def load_library() -> ctypes.CDLL:
@@ -96,7 +167,7 @@ def load_library() -> ctypes.CDLL:
                 f"MI355X HIP extension not built: {p} is missing. "
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)."
             )
-        _preload_torch_hip_runtime()
+        _preload_torch_hip_runtime(p)
         try:
             L = ctypes.CDLL(str(p))
         except OSError as exc:
@@ -140,6 +211,12 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_streams_prime_one.argtypes = [vp, ctypes.c_int, vp]
         L.dpdf_streams_is_primed.argtypes = [vp, ctypes.c_int]
         L.dpdf_progress.argtypes = [vp]
+        L.dpdf_streams_pool_config.argtypes = [vp, ctypes.c_double]
+        L.dpdf_streams_slot_use.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+        L.dpdf_streams_submit_wait.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int]
+        L.dpdf_streams_submit_many.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int]
+        L.dpdf_streams_submit_block.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, ctypes.c_int]
+        L.dpdf_streams_pool_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
         L.dpdf_recovery_count.argtypes = [vp]
         L.dpdf_recovery_count.restype = ctypes.c_long
         L.dpdf_profile_enable.argtypes = [vp, ctypes.c_int]
@@ -171,14 +248,34 @@ class _HostBlockPool:
     def __init__(self) -> None:
         self._lock = threading.Lock()
         self._free: List[np.ndarray] = []
+        # blocks handed back by finalisers.  A finaliser can run at ANY allocation -- including one made by this class while it
+        # holds `_lock` (cyclic GC) -- so it must never take the lock: it only appends here (deque.append is atomic), and take()
+        # moves the blocks to the free list under the lock.
+        self._returned: "collections.deque[np.ndarray]" = collections.deque()
         self.limit_bytes = int(float(os.environ.get("DPDFNET_OUTPUT_POOL_MB", "2048")) * (1 << 20))
         self.leases = 0          # statistics (tests)
         self.reused = 0
 
     def _give_back(self, raw: np.ndarray) -> None:
-        with self._lock:
-            if sum(b.nbytes for b in self._free) + raw.nbytes <= self.limit_bytes:
+        self._returned.append(raw)
+
+    def _drain_returned(self) -> None:
+        """(under `_lock`) returned blocks -> free list, up to the idle-memory bound."""
+        held = sum(b.nbytes for b in self._free)
+        while True:
+            try:
+                raw = self._returned.popleft()
+            except IndexError:
+                return
+            if held + raw.nbytes <= self.limit_bytes:
                 self._free.append(raw)
+                held += raw.nbytes
+
+    def idle_blocks(self) -> int:
+        """Blocks currently kept for reuse (returned ones included)."""
+        with self._lock:
+            self._drain_returned()
+            return len(self._free)
 
     def take(self, n: int) -> np.ndarray:
         n = int(n)
@@ -187,10 +284,13 @@ class _HostBlockPool:
         raw = None
         with self._lock:
             self.leases += 1
-            fits = [b for b in self._free if n <= b.size <= 2 * n + 1024]
-            if fits:
-                raw = min(fits, key=lambda b: b.size)
-                self._free = [b for b in self._free if b is not raw]
+            self._drain_returned()
+            best = -1
+            for i, b in enumerate(self._free):
+                if n <= b.size <= 2 * n + 1024 and (best < 0 or b.size < self._free[best].size):
+                    best = i
+            if best >= 0:
+                raw = self._free.pop(best)
                 self.reused += 1
         if raw is None:
             raw = np.empty(n, dtype=np.float32)
@@ -482,6 +582,42 @@ class HipStreams:
         _check(self.model._L.dpdf_streams_process_masked(self._h, pcm.ctypes.data, pcm.shape[1] // self.model.hop, out.ctypes.data,
                                                          act.tobytes(), DPDF_HOST_PTRS))
         return out
+
+    # ---- native coalescing of independent submitters (dpdf_streams_submit*): the queue, the leader and the window live in the library ----
+    def pool_config(self, window_s: float) -> None:
+        _check(self.model._L.dpdf_streams_pool_config(self._h, float(window_s)))
+
+    def slot_use(self, slot: int, in_use: bool) -> None:
+        _check(self.model._L.dpdf_streams_slot_use(self._h, int(slot), 1 if in_use else 0))
+
+    def pool_stats(self) -> Tuple[int, int]:
+        a, b = ctypes.c_long(0), ctypes.c_long(0)
+        _check(self.model._L.dpdf_streams_pool_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
+    def submit_wait(self, slot: int, pcm: np.ndarray, k: int, no_window: bool = False) -> np.ndarray:
+        """k whole hops (float32, contiguous) for one slot -> its k * hop enhanced samples; rides in the round other threads' submissions
+        for this stream set are in (ONE masked device call per round)."""
+        out = np.empty(k * self.model.hop, dtype=np.float32)
+        _check(self.model._L.dpdf_streams_submit_wait(self._h, int(slot), pcm.ctypes.data, int(k), out.ctypes.data, 1 if no_window else 0))
+        return out
+
+    def submit_block(self, slots: np.ndarray, block: np.ndarray, k: int, no_window: bool = False) -> np.ndarray:
+        """n = len(slots) requests of k hops each, rows of `block` [n, k * hop] (float32, contiguous) -> [n, k * hop]."""
+        out = np.empty(block.shape, dtype=np.float32)
+        _check(self.model._L.dpdf_streams_submit_block(self._h, int(slots.shape[0]), slots.ctypes.data, block.ctypes.data, int(k), out.ctypes.data,
+                                                       1 if no_window else 0))
+        return out
+
+    def submit_many(self, slots: Sequence[int], rows: Sequence[np.ndarray], ks: Sequence[int], no_window: bool = False) -> List[np.ndarray]:
+        """Requests with different hop counts: rows[i] holds ks[i] whole hops for slots[i]."""
+        n = len(slots)
+        hop = self.model.hop
+        outs = [np.empty(int(k) * hop, dtype=np.float32) for k in ks]
+        sl = (ctypes.c_int * n)(*[int(x) for x in slots]); kk = (ctypes.c_int * n)(*[int(k) for k in ks])
+        ip = (ctypes.c_void_p * n)(*[r.ctypes.data for r in rows]); op = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+        _check(self.model._L.dpdf_streams_submit_many(self._h, n, sl, ip, kk, op, 1 if no_window else 0))
+        return outs
 
     def prime_one(self, stream: int, pcm_hop: np.ndarray) -> None:
         pcm_hop = np.ascontiguousarray(pcm_hop, dtype=np.float32).reshape(self.model.hop)

@@ -1,7 +1,7 @@
 // dft64.h -- the ANALYSIS transform in double precision: the float32 product frame * window (exactly the reference's operand,
 // package/src/dpdfnet/stream.py:119 `windowed = in_buf[:win] * window`, audio.py:104-117) goes through a float64 DFT and is
 // rounded to float32 once, which is what the reference's np.fft.rfft delivers (stream.py:120-126: float64 under its pinned
-// numpy 1.26.4, and the same values to the last float32 bit under numpy 2.x) and what oracle/dpdf_oracle.c restates.
+// numpy 1.26.4, and the same values to the last float32 bit under numpy 2.x) and what the CPU checker under tests restates.
 //
 // Why: at 48 kHz the features are 10 log10(|X| + 1e-10) PER BIN (onnx_model/dpdfnet_48khz_hr.py:887-924).  A bin that holds no
 // signal (band-limited speech, 16-bit sources, DC) carries only the quantisation residue of the windowed frame, ~1e-7 of the

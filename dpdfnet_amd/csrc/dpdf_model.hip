@@ -480,6 +480,7 @@ struct dpdf_streams {
     DevBuf snap_state, snap_in, snap_ola;
     hipEvent_t ev_snap = nullptr;
     hipEvent_t ev_out = nullptr;       // behind the overlap-add of the latest call: the output is in place (the state export follows it)
+    struct StreamPoolC* pool = nullptr; // native coalescing of independent submitters (dpdf_streams_submit*), created on first use
     // (Measured and dropped: replaying a captured hipGraph of the hop -- ~110 launches over four streams -- instead of
     // enqueueing them: 781 / 319 / 446 us per hop against 748 / 307 / 433 us with plain launches for 64 x 48 kHz dpdfnet8,
     // one 16 kHz dpdfnet2 and eight dpdfnet4 streams: the hop is bound by the dependent kernels on the GPU, not by the
@@ -2703,6 +2704,7 @@ extern "C" int dpdf_streams_create(dpdf_model* m, int n_streams, dpdf_streams** 
     HIP_TRY(hipStreamSynchronize(m->stream));
     return DPDF_OK;
 }
+static void pool_destroy(dpdf_streams* s);
 extern "C" void dpdf_streams_destroy(dpdf_streams* s) {
     if (!s) return;
     (void)hipSetDevice(s->m->device);
@@ -2716,6 +2718,7 @@ extern "C" void dpdf_streams_destroy(dpdf_streams* s) {
     if (s->pin_in) (void)hipHostFree(s->pin_in);
     if (s->pin_out) (void)hipHostFree(s->pin_out);
     if (s->pin_err) (void)hipHostFree(s->pin_err);
+    pool_destroy(s);
     delete s;
 }
 extern "C" int dpdf_streams_reset(dpdf_streams* s, int stream) {
@@ -2910,8 +2913,11 @@ static int streams_recover_and_rerun(dpdf_streams* s, const float* src, int T, f
     return DPDF_OK;
 }
 
-extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, const unsigned char* active, int flags) {
-    if (!s || !pcm_in || !pcm_out) return set_err(DPDF_E_INVALID, "null argument");
+// ext_in / ext_out (both or neither): pinned, GPU-visible [S][n_hops * hop] blocks owned by the caller that already hold the input and take the
+// output in place (the native pool's round buffers): the host-pointer path without its two staging copies.
+static int streams_call(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, const unsigned char* active, int flags,
+                        float* ext_in = nullptr, float* ext_out = nullptr) {
+    if (!s || ((!pcm_in || !pcm_out) && !ext_in)) return set_err(DPDF_E_INVALID, "null argument");
     if (n_hops <= 0) return set_err(DPDF_E_INVALID, "n_hops must be positive");
     dpdf_model* m = s->m;
     int n_act = 0;
@@ -2940,20 +2946,26 @@ extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in,
     }
     if (!host) return streams_run(s, pcm_in, T, pcm_out, n_act, s->pin_idx, nullptr);
     // ---- host pointers: pinned staging both ways, pre-call snapshot, self-recovery ----
-    if (npcm > s->pin_cap) {
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        if (s->pin_in) (void)hipHostFree(s->pin_in);
-        if (s->pin_out) (void)hipHostFree(s->pin_out);
-        s->pin_in = s->pin_out = nullptr; s->pin_cap = 0;
-        HIP_TRY(hipHostMalloc((void**)&s->pin_in, npcm * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void**)&s->pin_out, npcm * sizeof(float), hipHostMallocDefault));
-        s->pin_cap = npcm;
+    float* pin_in = ext_in; float* pin_out = ext_out;
+    if (!ext_in) {
+        if (npcm > s->pin_cap) {
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (s->pin_in) (void)hipHostFree(s->pin_in);
+            if (s->pin_out) (void)hipHostFree(s->pin_out);
+            s->pin_in = s->pin_out = nullptr; s->pin_cap = 0;
+            HIP_TRY(hipHostMalloc((void**)&s->pin_in, npcm * sizeof(float), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void**)&s->pin_out, npcm * sizeof(float), hipHostMallocDefault));
+            s->pin_cap = npcm;
+        }
+        pin_in = s->pin_in; pin_out = s->pin_out;
     }
     if (!s->pin_err) { HIP_TRY(hipHostMalloc((void**)&s->pin_err, sizeof(int), hipHostMallocDefault)); *s->pin_err = 0; }
-    if (n_act == S) memcpy(s->pin_in, pcm_in, npcm * sizeof(float));
-    else for (int k = 0; k < n_act; ++k) {
-        const size_t o = (size_t)s->pin_idx[k] * T * d.hop;
-        memcpy(s->pin_in + o, pcm_in + o, (size_t)T * d.hop * sizeof(float));
+    if (!ext_in) {
+        if (n_act == S) memcpy(pin_in, pcm_in, npcm * sizeof(float));
+        else for (int k = 0; k < n_act; ++k) {
+            const size_t o = (size_t)s->pin_idx[k] * T * d.hop;
+            memcpy(pin_in + o, pcm_in + o, (size_t)T * d.hop * sizeof(float));
+        }
     }
     {
         const size_t ns = (size_t)S * d.state_size, nt = (size_t)S * d.hop;
@@ -2961,7 +2973,7 @@ extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in,
         if (!s->ev_snap) HIP_TRY(hipEventCreateWithFlags(&s->ev_snap, hipEventDisableTiming));
         if (!s->ev_out) HIP_TRY(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
     }
-    if ((rc = streams_run(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx, s->pin_err, m->snapshot != 0))) return rc;
+    if ((rc = streams_run(s, pin_in, T, pin_out, n_act, s->pin_idx, s->pin_err, m->snapshot != 0))) return rc;
     // all streams active: the output (and the error flag's mirror) is in place behind the overlap-add; the state export that follows it
     // on the stream is not waited for -- whatever touches the state next is ordered behind it, and the getters synchronise the stream
     if (n_act == S && m->late_export) HIP_TRY(hipEventSynchronize(s->ev_out));
@@ -2971,14 +2983,258 @@ extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in,
         // recovery restores the PRE-CALL copy of state and tails: with the copy switched off (option "snapshot" = 0) there is
         // nothing valid to go back to -- report the device error, the streams need reset / set_state (as for device pointers)
         if (!m->snapshot) return check_device_err(m);
-        if ((rc = streams_recover_and_rerun(s, s->pin_in, T, s->pin_out, n_act, s->pin_idx))) return rc;
+        if ((rc = streams_recover_and_rerun(s, pin_in, T, pin_out, n_act, s->pin_idx))) return rc;
     }
-    if (n_act == S) memcpy(pcm_out, s->pin_out, npcm * sizeof(float));
-    else for (int k = 0; k < n_act; ++k) {
-        const size_t o = (size_t)s->pin_idx[k] * T * d.hop;
-        memcpy(pcm_out + o, s->pin_out + o, (size_t)T * d.hop * sizeof(float));
+    if (!ext_in) {
+        if (n_act == S) memcpy(pcm_out, pin_out, npcm * sizeof(float));
+        else for (int k = 0; k < n_act; ++k) {
+            const size_t o = (size_t)s->pin_idx[k] * T * d.hop;
+            memcpy(pcm_out + o, pin_out + o, (size_t)T * d.hop * sizeof(float));
+        }
     }
     return DPDF_OK;
+}
+extern "C" int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, const unsigned char* active, int flags) {
+    return streams_call(s, pcm_in, n_hops, pcm_out, active, flags);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Native coalescing of INDEPENDENT submitters (the reference's pattern: N StreamEnhancer objects, each fed by its own caller
+// whenever it has a chunk, package/src/dpdfnet/stream.py:13-72, 74-165).  Host threads submit k hops for one slot each; the
+// first submitter of a round leads it: it waits -- at most the window, and only until every slot in use has queued -- then
+// issues ONE masked device call for everybody in the round.  Submitters write their samples straight into the round's pinned,
+// GPU-visible input block and read their result straight out of its output block (both in parallel, outside the lock);
+// two round buffers alternate, so the next round fills while this one is on the GPU.  A round is homogeneous in k: a request
+// with another hop count waits for the open round to fire and opens / joins the next one.
+// ------------------------------------------------------------------------------------------------
+struct StreamPoolC {
+    struct Round {
+        enum { OPEN = 0, FIRING = 1, DONE = 2 };
+        int state = OPEN, k = 0, n_queued = 0, copies_pending = 0, readers_left = 0, rc = 0;
+        bool has_leader = false;
+        long id = 0;
+        std::vector<unsigned char> active;
+        std::string err;
+        float* pin_in = nullptr; float* pin_out = nullptr; size_t cap = 0;       // floats
+    };
+    std::mutex mu, exec_mu;
+    std::condition_variable cv;                       // every state change (arrivals, copies finished, rounds done / recycled)
+    Round rd[2];
+    long open_id = 0;                                 // id of the round that takes submissions (buffer open_id & 1)
+    std::vector<unsigned char> in_use; int n_in_use = 0;
+    std::vector<long> slot_round;                     // round id of the slot's outstanding request (-1: none)
+    double window_s = 2e-4;
+    int n_blocked = 0;                                // submitters waiting in pool_join (another hop count than the open round's, or its buffer not recycled yet): they cannot join the open round
+    long device_calls = 0, rounds = 0;
+    // Is more than one host thread feeding the pool?  A leader that is the only recent submitter does not wait for others.
+    std::thread::id last_tid{}; std::chrono::steady_clock::time_point other_seen{};
+};
+static StreamPoolC* pool_of(dpdf_streams* s) {
+    static std::mutex g_mu;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!s->pool) {
+        s->pool = new StreamPoolC();
+        s->pool->in_use.assign(s->S, 0);
+        s->pool->slot_round.assign(s->S, -1);
+        for (int b = 0; b < 2; ++b) { s->pool->rd[b].active.assign(s->S, 0); s->pool->rd[b].id = b; }
+    }
+    return s->pool;
+}
+static void pool_destroy(dpdf_streams* s) {
+    if (!s->pool) return;
+    for (int b = 0; b < 2; ++b) {
+        if (s->pool->rd[b].pin_in) (void)hipHostFree(s->pool->rd[b].pin_in);
+        if (s->pool->rd[b].pin_out) (void)hipHostFree(s->pool->rd[b].pin_out);
+    }
+    delete s->pool; s->pool = nullptr;
+}
+extern "C" int dpdf_streams_pool_config(dpdf_streams* s, double window_s) {
+    if (!s || !(window_s >= 0.0)) return set_err(DPDF_E_INVALID, "bad argument");
+    StreamPoolC* P = pool_of(s);
+    std::lock_guard<std::mutex> lk(P->mu);
+    P->window_s = window_s;
+    return DPDF_OK;
+}
+extern "C" int dpdf_streams_slot_use(dpdf_streams* s, int slot, int in_use) {
+    if (!s || slot < 0 || slot >= s->S) return set_err(DPDF_E_INVALID, "bad slot");
+    StreamPoolC* P = pool_of(s);
+    std::lock_guard<std::mutex> lk(P->mu);
+    if (in_use && !P->in_use[slot]) { P->in_use[slot] = 1; ++P->n_in_use; }
+    else if (!in_use && P->in_use[slot]) { P->in_use[slot] = 0; --P->n_in_use; P->cv.notify_all(); }
+    return DPDF_OK;
+}
+extern "C" int dpdf_streams_pool_stats(dpdf_streams* s, long* device_calls, long* rounds) {
+    if (!s) return set_err(DPDF_E_INVALID, "null streams");
+    StreamPoolC* P = pool_of(s);
+    std::lock_guard<std::mutex> lk(P->mu);
+    if (device_calls) *device_calls = P->device_calls;
+    if (rounds) *rounds = P->rounds;
+    return DPDF_OK;
+}
+// join the open round with k hops for `slot`, copying the samples in; *lead_id >= 0: this caller has become that round's leader.
+// may_wait = false: return POOL_WOULD_BLOCK instead of waiting for a round to fire or a buffer to be recycled (a caller that
+// already holds joined-but-uncollected requests must lead / collect those first: the buffer it would wait for may be waiting for IT)
+constexpr int POOL_WOULD_BLOCK = 1;
+static int pool_join(dpdf_streams* s, StreamPoolC* P, int slot, const float* pcm, int k, long* lead_id, bool may_wait) {
+    const dpdf_dims& d = s->m->d;
+    const size_t row = (size_t)k * d.hop;
+    std::unique_lock<std::mutex> lk(P->mu);
+    if (P->slot_round[slot] >= 0) return set_err(DPDF_E_STATE, "slot %d already has a request in flight", slot);
+    StreamPoolC::Round* R;
+    for (;;) {
+        R = &P->rd[P->open_id & 1];
+        // the buffer of the open round is free once the readers of the round that used it before are through; and a round takes
+        // one hop count only
+        if (R->state == StreamPoolC::Round::OPEN && R->id == P->open_id && (R->n_queued == 0 || R->k == k)) break;
+        if (!may_wait) return POOL_WOULD_BLOCK;
+        ++P->n_blocked; P->cv.notify_all();            // (the open round's leader counts us as "cannot come")
+        P->cv.wait(lk);
+        --P->n_blocked;
+    }
+    if (R->n_queued == 0) {
+        R->k = k;
+        const size_t need = (size_t)s->S * row;
+        if (need > R->cap) {                           // (empty round, buffer idle: nobody reads or writes it)
+            if (hipSetDevice(s->m->device) != hipSuccess) return set_err(DPDF_E_RUNTIME, "hipSetDevice failed");
+            if (R->pin_in) (void)hipHostFree(R->pin_in);
+            if (R->pin_out) (void)hipHostFree(R->pin_out);
+            R->pin_in = R->pin_out = nullptr; R->cap = 0;
+            if (hipHostMalloc((void**)&R->pin_in, need * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void**)&R->pin_out, need * sizeof(float), hipHostMallocDefault) != hipSuccess)
+                return set_err(DPDF_E_RUNTIME, "hipHostMalloc of the pool's round buffers failed");
+            R->cap = need;
+        }
+    }
+    const auto tid = std::this_thread::get_id();
+    if (P->last_tid != std::thread::id{} && P->last_tid != tid) P->other_seen = std::chrono::steady_clock::now();
+    P->last_tid = tid;
+    R->active[slot] = 1; ++R->n_queued; ++R->copies_pending;
+    P->slot_round[slot] = R->id;
+    if (!R->has_leader) { R->has_leader = true; *lead_id = R->id; }
+    float* dst = R->pin_in + (size_t)slot * row;
+    lk.unlock();
+    memcpy(dst, pcm, row * sizeof(float));
+    lk.lock();
+    --R->copies_pending;
+    P->cv.notify_all();
+    return DPDF_OK;
+}
+// the leader's part: wait for the others (bounded), close the round, one masked device call, wake everybody
+static void pool_lead(dpdf_streams* s, StreamPoolC* P, long id, bool no_window) {
+    StreamPoolC::Round* R = &P->rd[id & 1];
+    {
+        std::unique_lock<std::mutex> lk(P->mu);
+        const auto now = std::chrono::steady_clock::now();
+        const bool others = P->other_seen != std::chrono::steady_clock::time_point{} && now - P->other_seen < std::chrono::seconds(1);
+        if (!no_window && others && P->window_s > 0) {
+            const auto deadline = now + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(P->window_s));
+            // (a slot has at most one request per round: once as many are queued as slots are in use, nobody else can come)
+            while (R->n_queued + P->n_blocked < P->n_in_use)
+                if (P->cv.wait_until(lk, deadline) == std::cv_status::timeout) break;
+        }
+    }
+    // rounds execute in order: the previous round's leader holds exec_mu until its device call is through; this round stays open
+    // (and keeps filling) while we wait for it
+    std::lock_guard<std::mutex> ex(P->exec_mu);
+    std::vector<unsigned char> active;
+    int k;
+    {
+        std::unique_lock<std::mutex> lk(P->mu);
+        R->state = StreamPoolC::Round::FIRING;
+        ++P->open_id;                                  // later submitters fill the other buffer
+        P->cv.notify_all();
+        while (R->copies_pending > 0) P->cv.wait(lk);
+        active = R->active; k = R->k;
+    }
+    const int rc = streams_call(s, nullptr, k, nullptr, active.data(), DPDF_HOST_PTRS, R->pin_in, R->pin_out);
+    {
+        std::lock_guard<std::mutex> lk(P->mu);
+        R->rc = rc; R->err = rc ? dpdf_last_error() : "";
+        R->state = StreamPoolC::Round::DONE;
+        R->readers_left = R->n_queued;
+        ++P->device_calls; ++P->rounds;
+        P->cv.notify_all();
+    }
+}
+// wait for the slot's round and copy its result out (k hops)
+static int pool_collect(dpdf_streams* s, StreamPoolC* P, int slot, float* out) {
+    const dpdf_dims& d = s->m->d;
+    std::unique_lock<std::mutex> lk(P->mu);
+    const long id = P->slot_round[slot];
+    if (id < 0) return set_err(DPDF_E_STATE, "slot %d has no request in flight", slot);
+    StreamPoolC::Round* R = &P->rd[id & 1];
+    while (!(R->id == id && R->state == StreamPoolC::Round::DONE)) P->cv.wait(lk);
+    const int rc = R->rc;
+    const std::string err = R->err;
+    const size_t row = (size_t)R->k * d.hop;
+    const float* src = R->pin_out + (size_t)slot * row;
+    lk.unlock();
+    if (!rc) memcpy(out, src, row * sizeof(float));
+    lk.lock();
+    P->slot_round[slot] = -1;
+    if (--R->readers_left == 0) {                       // last reader recycles the buffer for round id + 2
+        R->state = StreamPoolC::Round::OPEN; R->id = id + 2; R->n_queued = 0; R->k = 0; R->has_leader = false; R->rc = 0;
+        std::fill(R->active.begin(), R->active.end(), 0);
+        P->cv.notify_all();
+    }
+    if (rc) return set_err(rc, "%s", err.c_str());
+    return DPDF_OK;
+}
+// n requests of ONE host thread (n = 1: a StreamEnhancer-shaped object's process()): slots[i] gets ks[i] whole hops from in_rows[i],
+// out_rows[i] takes ks[i] * hop samples.  Requests with the same hop count ride in the same round(s), together with whatever
+// other threads submit in the window.  flags bit 0: do not wait for other submitters (the caller knows it is alone).
+extern "C" int dpdf_streams_submit_many(dpdf_streams* s, int n, const int* slots, const float* const* in_rows, const int* ks,
+                                        float* const* out_rows, int flags) {
+    if (!s || !slots || !in_rows || !ks || !out_rows) return set_err(DPDF_E_INVALID, "null argument");
+    if (n <= 0) return DPDF_OK;
+    for (int i = 0; i < n; ++i) {
+        if (slots[i] < 0 || slots[i] >= s->S) return set_err(DPDF_E_STATE, "stream %d out of range (have %d)", slots[i], s->S);
+        if (ks[i] <= 0 || !in_rows[i] || !out_rows[i]) return set_err(DPDF_E_INVALID, "bad request %d", i);
+        if (!s->primed[slots[i]]) return set_err(DPDF_E_STATE, "stream %d not primed: call dpdf_streams_prime with its first hop", slots[i]);
+        for (int j = 0; j < i; ++j) if (slots[j] == slots[i]) return set_err(DPDF_E_INVALID, "slot %d appears twice", slots[i]);
+    }
+    StreamPoolC* P = pool_of(s);
+    std::vector<char> done(n, 0);
+    int first_rc = DPDF_OK; std::string first_err;
+    for (int i0 = 0; i0 < n; ++i0) {
+        if (done[i0]) continue;
+        const int k = ks[i0];                          // one group per distinct hop count, in order of appearance
+        std::vector<int> grp;
+        for (int i = i0; i < n; ++i) if (!done[i] && ks[i] == k) grp.push_back(i);
+        size_t next = 0;
+        while (next < grp.size()) {
+            std::vector<long> lead;
+            std::vector<int> joined;
+            for (; next < grp.size(); ++next) {
+                const int i = grp[next];
+                long lid = -1;
+                const int rc = pool_join(s, P, slots[i], in_rows[i], k, &lid, joined.empty());
+                if (rc == POOL_WOULD_BLOCK) break;          // lead / collect what this thread holds, then carry on
+                if (rc) { if (!first_rc) { first_rc = rc; first_err = dpdf_last_error(); } done[i] = 1; continue; }
+                joined.push_back(i);
+                if (lid >= 0) lead.push_back(lid);
+            }
+            for (long lid : lead) pool_lead(s, P, lid, (flags & 1) != 0);
+            for (int i : joined) {
+                const int rc = pool_collect(s, P, slots[i], out_rows[i]);
+                if (rc && !first_rc) { first_rc = rc; first_err = dpdf_last_error(); }
+                done[i] = 1;
+            }
+        }
+    }
+    if (first_rc) return set_err(first_rc, "%s", first_err.c_str());
+    return DPDF_OK;
+}
+// the same for n requests of equal hop count whose rows lie one after the other: in_block / out_block [n][k_hops * hop]
+extern "C" int dpdf_streams_submit_block(dpdf_streams* s, int n, const int* slots, const float* in_block, int k_hops, float* out_block, int flags) {
+    if (!s || !slots || !in_block || !out_block || n < 0 || k_hops <= 0) return set_err(DPDF_E_INVALID, "bad argument");
+    const size_t row = (size_t)k_hops * s->m->d.hop;
+    std::vector<const float*> in(n); std::vector<float*> out(n); std::vector<int> ks(n, k_hops);
+    for (int i = 0; i < n; ++i) { in[i] = in_block + (size_t)i * row; out[i] = out_block + (size_t)i * row; }
+    return dpdf_streams_submit_many(s, n, slots, in.data(), ks.data(), out.data(), flags);
+}
+extern "C" int dpdf_streams_submit_wait(dpdf_streams* s, int slot, const float* pcm, int k_hops, float* out, int flags) {
+    return dpdf_streams_submit_many(s, 1, &slot, &pcm, &k_hops, &out, flags);
 }
 extern "C" int dpdf_streams_process(dpdf_streams* s, const float* pcm_in, int n_hops, float* pcm_out, int flags) {
     return dpdf_streams_process_masked(s, pcm_in, n_hops, pcm_out, nullptr, flags);

@@ -37,8 +37,11 @@ def gather_to_root(local, world_size: int, rank: int, out=None):
 
     if world_size == 1:
         return local.unsqueeze(0)
-    if local.is_cuda and dist.get_backend() == "gloo":      # gloo moves host memory only: stage through the CPU
-        got = gather_to_root(local.cpu(), world_size, rank, None)
+    if local.is_cuda and dist.get_backend() == "gloo":      # gloo moves host memory only: stage through pinned host memory
+        host = torch.empty(tuple(local.shape), dtype=local.dtype, pin_memory=True)
+        host.copy_(local, non_blocking=True)
+        torch.cuda.current_stream(local.device).synchronize()
+        got = gather_to_root(host, world_size, rank, None)
         if got is None:
             return None
         if out is None:

@@ -18,8 +18,8 @@ that share one device-resident stream set; hops that arrive within a short windo
 `save_state()` / `load_state()` move a stream between objects, pools or processes (resume = the explicit state vector)."""
 from __future__ import annotations
 
+import collections
 import threading
-import time
 from pathlib import Path
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
@@ -170,24 +170,19 @@ class StreamEnhancer:
         return self._g.flush().reshape(-1).astype(np.float32)
 
 
-class _Request:
-    __slots__ = ("slot", "pcm", "k", "done", "out", "err")
-
-    def __init__(self, slot: int, pcm: np.ndarray, k: int, done: Optional[threading.Event] = None) -> None:
-        self.slot, self.pcm, self.k = slot, pcm, k
-        self.done = done if done is not None else threading.Event()     # (the requests of one process_many() call share one)
-        self.out: Optional[np.ndarray] = None
-        self.err: Optional[BaseException] = None
-
-
 class StreamPool:
     """Independent streams behind one device-resident stream set.
+
+    The queue, the leader election and the coalescing window live in the library (`dpdf_streams_submit*`, include/dpdfnet_hip.h):
+    a member's `process()` is one C call that puts its hops into the open round's pinned input block, and returns with its row of
+    the round's result; the first submitter of a round issues the ONE masked device call for everybody in it.
 
     Args:
         n_slots: how many streams the pool can hold at once.
         model / onnx_path / verbose: as for `StreamEnhancer`.
-        window_s: how long the first `process()` caller of a round waits for other threads' hops before it issues the
-            device call for everyone queued (0: no waiting, still coalesces what is already queued).
+        window_s: how long the first submitter of a round waits for other threads' hops before it issues the device call for
+            everyone queued (0: no waiting, still coalesces what is already queued).  It only waits while more than one host
+            thread has been feeding the pool within the last second, and never longer than until every stream in use has queued.
     """
 
     def __init__(self, n_slots: int, model: str = DEFAULT_MODEL, onnx_path: Optional[Union[str, Path]] = None,
@@ -203,159 +198,104 @@ class StreamPool:
         self._win_len: int = infer_win_len(self._runtime.session, self._model_sr)
         self._hop_size: int = self._win_len // 2
         self._streams = self._runtime.session.open_streams(self._n)
+        self._streams.pool_config(float(window_s))
         self._free: List[int] = list(range(self._n - 1, -1, -1))
-        self._window = float(window_s)
+        # slots of members that were dropped without close(): their finaliser only appends here (it may run at any allocation,
+        # also one made under `_lock`, so it must not take a lock); `_reap` hands them back
+        self._dropped: "collections.deque[int]" = collections.deque()
         self._lock = threading.Lock()
-        self._arrived = threading.Condition(self._lock)      # followers tell the waiting leader that the queue has grown
-        self._queue: List[_Request] = []
-        self._leader_active = False
-        self.device_calls = 0              # masked device calls issued so far (what the coalescing saves)
+        self._slots_cache: Dict[tuple, np.ndarray] = {}      # tuple of slot numbers -> the same as an int32 array (steady-state process_many)
 
     @property
     def n_slots(self) -> int:
         return self._n
 
+    @property
+    def device_calls(self) -> int:
+        """Masked device calls issued so far (what the coalescing saves)."""
+        return self._streams.pool_stats()[0]
+
+    def _reap(self) -> None:
+        while self._dropped:
+            try:
+                slot = self._dropped.popleft()
+            except IndexError:
+                return
+            self._release(slot)
+
     def enhancer(self) -> "PooledStreamEnhancer":
         """A new independent stream (StreamEnhancer interface) in a free slot of the pool."""
+        self._reap()
         with self._lock:
             if not self._free:
                 raise RuntimeError(f"all {self._n} slots of the pool are in use")
             slot = self._free.pop()
         self._streams.reset(slot)
+        self._streams.slot_use(slot, True)
         return PooledStreamEnhancer(self, slot)
 
     def _release(self, slot: int) -> None:
+        self._streams.slot_use(slot, False)      # a round's leader no longer waits for this stream
         with self._lock:
             self._free.append(slot)
 
     # ------------------------------------------------------------------
-    def _execute(self, reqs: Sequence[_Request]) -> None:
-        """One or a few masked device calls for a set of requests (each: k whole hops for its slot).  Requests with the
-        same hop count share a call; different counts peel off in rounds of the smallest remaining count."""
-        hop = self._hop_size
-        try:
-            if reqs and all(r.k == reqs[0].k for r in reqs):
-                # the common round: every request carries the same number of hops -- one masked call, results handed out as views
-                n = reqs[0].k
-                pcm = np.zeros((self._n, n * hop), dtype=np.float32)
-                active = np.zeros(self._n, dtype=bool)
-                for r in reqs:
-                    pcm[r.slot] = r.pcm
-                    active[r.slot] = True
-                res = self._streams.process_masked(pcm, active)
-                with self._lock:
-                    self.device_calls += 1
-                for r in reqs:
-                    r.out = res[r.slot]
-                return
-            done = {id(r): 0 for r in reqs}
-            outs = {id(r): np.empty(r.k * hop, dtype=np.float32) for r in reqs}
-            while True:
-                live = [r for r in reqs if done[id(r)] < r.k]
-                if not live:
-                    break
-                n = min(r.k - done[id(r)] for r in live)
-                pcm = np.zeros((self._n, n * hop), dtype=np.float32)
-                active = np.zeros(self._n, dtype=bool)
-                for r in live:
-                    o = done[id(r)] * hop
-                    pcm[r.slot] = r.pcm[o: o + n * hop]
-                    active[r.slot] = True
-                res = self._streams.process_masked(pcm, active)
-                with self._lock:
-                    self.device_calls += 1
-                for r in live:
-                    o = done[id(r)] * hop
-                    outs[id(r)][o: o + n * hop] = res[r.slot]
-                    done[id(r)] += n
-            for r in reqs:
-                r.out = outs[id(r)]
-        except Exception as exc:              # the waiters get the engine's error ...
-            for r in reqs:
-                r.err = exc
-        except BaseException:                 # ... but never this thread's KeyboardInterrupt / SystemExit: they get a plain failure
-            for r in reqs:
-                r.err = RuntimeError("the pool's device call was interrupted in another thread")
-            raise
-        finally:
-            for r in reqs:                    # every waiter must wake up
-                r.done.set()
-
-    def _run_group(self, reqs: List[_Request]) -> None:
-        """Queue this thread's requests; the first caller of a round leads it: it waits -- at most the pool's window, and only
-        until every stream in use has a request queued -- for other threads' hops, then issues the device call(s) for everyone
-        queued.  Returns when all of `reqs` are done (their .out / .err set)."""
-        with self._lock:
-            self._queue.extend(reqs)
-            lead = not self._leader_active
-            if lead:
-                self._leader_active = True
-            else:
-                self._arrived.notify()
-        if lead:
-            interrupted: Optional[BaseException] = None
-            try:
-                if self._window > 0:
-                    deadline = time.monotonic() + self._window
-                    with self._lock:
-                        # (a stream has at most one request per round: once as many are queued as slots are in use, nobody else can come)
-                        while len(self._queue) < self._n - len(self._free):
-                            left = deadline - time.monotonic()
-                            if left <= 0:
-                                break
-                            self._arrived.wait(left)
-            except BaseException as exc:             # (KeyboardInterrupt in the wait ...)
-                interrupted = exc
-            # whatever happened to this thread in the wait, the round is closed and RUN: the next caller leads again, and the
-            # followers queued so far -- whose hops are already out of their buffers -- get their results, nobody blocks forever
-            with self._lock:
-                batch, self._queue = self._queue, []
-                self._leader_active = False
-            self._execute(batch)                     # (wakes every request of the batch, also when it raises)
-            if interrupted is not None:
-                raise interrupted
-        waited = set()
-        for r in reqs:
-            if id(r.done) not in waited:
-                waited.add(id(r.done))
-                r.done.wait()
-
     def _run(self, slot: int, pcm: np.ndarray, k: int) -> np.ndarray:
-        """Called by a member from its own thread: queue k hops; the first caller of a round leads it."""
-        req = _Request(slot, pcm, k)
-        self._run_group([req])
-        if req.err is not None:
-            raise req.err
-        return req.out
+        """Called by a member from its own thread: k hops for its slot; returns when the round they rode in is done."""
+        if self._dropped:
+            self._reap()
+        return self._streams.submit_wait(slot, pcm, k)
 
     def process_many(self, items: Iterable[Tuple["PooledStreamEnhancer", np.ndarray]],
-                     sample_rate: Optional[int] = None) -> List[np.ndarray]:
-        """[(enhancer, chunk), ...] -> [enhanced, ...]: every member's complete hops in ONE coalesced execution
-        (chunks may have different sizes; each result is exactly what `enhancer.process(chunk)` returns)."""
+                     sample_rate: Optional[int] = None, wait: bool = True) -> List[np.ndarray]:
+        """[(enhancer, chunk), ...] -> [enhanced, ...]: every member's complete hops in ONE submission (chunks may have
+        different sizes; each result is exactly what `enhancer.process(chunk)` returns).  Other threads' submissions that arrive
+        within the window share the device call(s).  wait=False: do not wait for other threads at all (a caller that knows it
+        is the only one feeding the pool)."""
         items = list(items)
-        reqs: List[Optional[_Request]] = []
+        n = len(items)
+        if self._dropped:
+            self._reap()
+        hop = self._hop_size
+        # steady state of live streams: every member primed with nothing buffered, every chunk a float32 vector of the same whole
+        # number of hops at the model rate -- the chunks ARE the round's input: one gather, one C call, results handed out as rows
+        if n and (sample_rate is None or sample_rate == self._model_sr):
+            first = items[0][1]
+            if type(first) is np.ndarray and first.ndim == 1 and first.dtype == np.float32 and first.shape[0] and first.shape[0] % hop == 0:
+                L = first.shape[0]
+                ok = True
+                for enh, c in items:
+                    if not (enh._steady and enh._pool is self and type(c) is np.ndarray and c.dtype == np.float32 and c.shape == first.shape):
+                        ok = False
+                        break
+                if ok:
+                    key = tuple([e._slot for e, _ in items])          # (slot numbers, not the members: the cache must not keep them alive)
+                    slots = self._slots_cache.get(key)
+                    if slots is None:
+                        slots = np.array(key, dtype=np.int32)
+                        if len(self._slots_cache) > 64:
+                            self._slots_cache.clear()
+                        self._slots_cache[key] = slots
+                    out = self._streams.submit_block(slots, np.concatenate([c for _, c in items]), L // hop, not wait)
+                    return list(out.reshape(n, L))
         # validate EVERY item before any member's buffer is touched: a bad later item must not leave earlier members with hops
         # taken out of their buffers and never sent to the device
+        seen = set()
         for enh, chunk in items:
             if enh._pool is not self:
                 raise ValueError("enhancer belongs to another pool")
+            if id(enh) in seen:
+                raise ValueError("an enhancer appears twice in one process_many() call")
+            seen.add(id(enh))
             enh._check_rate(chunk, sample_rate)
-        done = threading.Event()
-        for enh, chunk in items:
-            got = enh._stage(chunk, sample_rate)
-            reqs.append(None if got is None else _Request(enh._slot, got[0], got[1], done))
-        live = [r for r in reqs if r is not None]
+        staged = [enh._stage(chunk, sample_rate) for enh, chunk in items]
+        live = [(i, g) for i, g in enumerate(staged) if g is not None]
+        res: Dict[int, np.ndarray] = {}
         if live:
-            self._run_group(live)        # coalesces with the process() / process_many() calls of other threads in the same window
-        outs = []
-        for (enh, _), r in zip(items, reqs):
-            if r is None:
-                outs.append(np.zeros(0, dtype=np.float32))
-                continue
-            if r.err is not None:
-                raise r.err
-            outs.append(enh._finish(r.out))
-        return outs
+            outs = self._streams.submit_many([items[i][0]._slot for i, _ in live], [g[0] for _, g in live], [g[1] for _, g in live], not wait)
+            for (i, _), o in zip(live, outs):
+                res[i] = o
+        return [items[i][0]._finish(res[i]) if i in res else np.zeros(0, dtype=np.float32) for i in range(n)]
 
 
 class PooledStreamEnhancer:
@@ -368,11 +308,16 @@ class PooledStreamEnhancer:
         self._primed = False
         self._input_sr: Optional[int] = None
         self._closed = False
+        self._steady = False       # primed, nothing buffered, fed at the model rate, open: a chunk of whole hops is the device input as it is
+
+    def _update_steady(self) -> None:
+        self._steady = (self._primed and self._pending.shape[0] == 0 and self._input_sr == self._pool._model_sr and not self._closed)
 
     def close(self) -> None:
         """Give the slot back to the pool."""
         if not self._closed:
             self._closed = True
+            self._steady = False
             self._pool._release(self._slot)
 
     def __enter__(self) -> "PooledStreamEnhancer":
@@ -382,8 +327,13 @@ class PooledStreamEnhancer:
         self.close()
 
     def __del__(self):
+        # a dropped member gives its slot back -- but a finaliser can run at any allocation, in any thread, also under the pool's
+        # lock: it only leaves a note (deque.append is atomic); the pool's next call hands the slot back (StreamPool._reap)
         try:
-            self.close()                  # a dropped member gives its slot back (close() is idempotent)
+            if not self._closed:
+                self._closed = True
+                self._steady = False
+                self._pool._dropped.append(self._slot)
         except Exception:
             pass
 
@@ -405,6 +355,7 @@ class PooledStreamEnhancer:
         self._pending = np.zeros(0, dtype=np.float32)
         self._primed = False
         self._input_sr = None
+        self._steady = False
 
     # ---- the host half of process(): buffering exactly as the reference (stream.py:74-115) ----
     def _stage(self, chunk: np.ndarray, sample_rate: Optional[int]):
@@ -412,10 +363,12 @@ class PooledStreamEnhancer:
         p = self._pool
         # steady state of a live stream: primed, nothing buffered, a whole number of hops at the model rate in a float32 vector --
         # the chunk IS the device call's input (no concatenate / slice / copy: ~1 us instead of ~5 per member and hop)
-        if (self._primed and self._pending.shape[0] == 0 and type(chunk) is np.ndarray and chunk.dtype == np.float32 and chunk.ndim == 1
+        if (self._steady and type(chunk) is np.ndarray and chunk.dtype == np.float32 and chunk.ndim == 1
                 and chunk.flags.c_contiguous and chunk.shape[0] and chunk.shape[0] % p._hop_size == 0
-                and (sample_rate is None or sample_rate == p._model_sr) and self._input_sr == p._model_sr and not self._closed):
+                and (sample_rate is None or sample_rate == p._model_sr)):
             return chunk, chunk.shape[0] // p._hop_size
+        if self._closed:
+            raise RuntimeError("this pool member was closed")
         chunk = to_mono(np.asarray(chunk, dtype=np.float32))
         if chunk.size == 0:
             return None
@@ -431,15 +384,18 @@ class PooledStreamEnhancer:
         hop = p._hop_size
         if not self._primed:
             if self._pending.shape[0] < p._win_len:
+                self._steady = False
                 return None
             p._streams.prime_one(self._slot, self._pending[:hop])
             self._pending = self._pending[hop:]
             self._primed = True
         k = self._pending.shape[0] // hop
         if k == 0:
+            self._update_steady()
             return None
         pcm = np.ascontiguousarray(self._pending[: k * hop])
         self._pending = self._pending[k * hop:]
+        self._update_steady()
         return pcm, k
 
     def _finish(self, enhanced_model_sr: np.ndarray) -> np.ndarray:
@@ -487,3 +443,4 @@ class PooledStreamEnhancer:
         self._primed = primed
         sr = int(np.asarray(saved["input_sr"]))
         self._input_sr = None if sr < 0 else sr
+        self._update_steady()

@@ -375,14 +375,105 @@ def test_pool_of_independent_enhancers_matches_reference_goldens(tag, be, tmp_pa
     t_hop = min(timed(run_pool_hopwise) for _ in range(2))
     calls_per_round = (pool.device_calls - calls0) / (2 * -(-len(wav) // hop))
     print(f"[pool {tag}] staggered {1e3 * t_pool:.1f} ms; hop-wise pool {1e3 * t_hop:.1f} ms vs group {1e3 * t_grp:.1f} ms")
-    # device work within 1.3 x of the lock-step group; on top of it the pool runs the reference's per-object host buffering
-    # (stream.py:74-115) once per member and hop in Python, ~5 us each, which the vectorised group does once per hop
-    # What is asserted is host-speed independent: ONE coalesced device call per round of N members (the device work of the
-    # lock-step group); the wall-clock ratio is asserted with a wide margin only (the per-object Python cost scales with the
-    # host: a box with a slow or shared CPU took 5 x longer over the whole suite with the same GPU work).
+    # ONE coalesced device call per round of N members (the device work of the lock-step group), host-speed independent.  The
+    # wall-clock guard: queueing, staging and wake-ups are native now (dpdf_streams_submit*), what is left per member and hop in
+    # Python is the steady-state check of process_many (< 1 us on the reference box).  The allowance scales with this host's
+    # measured Python speed (boxes of the pool differ 5 x), it is not a fixed wide margin.
     rounds = -(-len(wav) // hop)
     assert 0.5 < calls_per_round <= 1.0, calls_per_round      # (the first hop of a run only fills the analysis buffers)
-    assert t_hop <= 3.0 * t_grp + N * rounds * 40e-6, (t_hop, t_grp)
+    def calib():
+        t = time.perf_counter()
+        acc = 0
+        for i in range(200000):
+            acc += i & 7
+        return time.perf_counter() - t
+    host = max(1.0, min(calib() for _ in range(3)) / 8e-3)    # 200 k loop iterations take ~8 ms on the reference box
+    assert t_hop <= 1.3 * t_grp + N * rounds * 6e-6 * host, (t_hop, t_grp, host)
+    runtime.clear_cache()
+
+
+def test_native_pool_coalesces_threads_mixed_hop_counts_and_errors(be, tmp_path, monkeypatch):
+    """The library's own queue (dpdf_streams_submit*): four host threads' process_many() calls meet in ONE device call per round and the
+    leader does not sit out its window once every stream in use has queued; members submitting different hop counts at the same
+    time are served in successive rounds with exactly the results of a StreamEnhancer of their own; an error of a round's device
+    call reaches its submitters; a dropped member's slot comes back."""
+    import threading, time, gc
+    from dpdfnet_amd import runtime, stream, weights
+    from dpdfnet_amd.models import ModelInfo, ResolvedModel
+    runtime.clear_cache()
+    g, meta = load_golden("16k_nb2")
+    wfile = weights.save_blob(tmp_path / "w.npz", golden_blob(meta))
+    info = ModelInfo(name="test_pool", sample_rate=16000, frame_ms=20.0, description="", onnx_filename="w.onnx", dprnn_num_blocks=2)
+    monkeypatch.setattr(stream, "resolve_model", lambda **_k: ResolvedModel(info=info, onnx_path=wfile))
+    WIN, HOP, N = 320, 160, 8
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((N, WIN + 40 * HOP)) * 0.1).astype(np.float32)
+    want = []
+    for i in range(N):
+        e = stream.StreamEnhancer(model="ignored")
+        want.append(np.concatenate([e.process(x[i, :WIN]), e.process(x[i, WIN:])]))
+    pool = stream.StreamEnhancer.pool(N, window_s=5.0)           # a round that waited for its window would take 5 s
+    ms = [pool.enhancer() for _ in range(N)]
+    first = pool.process_many([(m, x[i, :WIN]) for i, m in enumerate(ms)])
+    outs = {i: [first[i]] for i in range(N)}
+    bar = threading.Barrier(4)
+    base = pool.device_calls
+
+    def feeder(t):
+        mine = list(range(t, N, 4))
+        for r in range(10):
+            bar.wait()
+            res = pool.process_many([(ms[i], x[i, WIN + r * HOP: WIN + (r + 1) * HOP]) for i in mine])
+            for i, o in zip(mine, res):
+                outs[i].append(o)
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=feeder, args=(t,)) for t in range(4)]
+    for th in ths: th.start()
+    for th in ths: th.join(60.0)
+    assert not any(th.is_alive() for th in ths)
+    assert time.perf_counter() - t0 < 4.0                      # fired on the eighth request every round, never on the window
+    calls = pool.device_calls - base
+    assert 10 <= calls <= 12, calls                            # four threads, ONE device call per round (the first round may split: no second thread seen yet)
+    # different hop counts at the same time (k = 1, 2, 3, 4 from four threads), and single-member process() calls: rounds are
+    # homogeneous in the hop count, so these go through successive rounds (each waits its window for the streams that are idle)
+    pool._streams.pool_config(2e-4)
+    pool2_k = {0: 1, 1: 2, 2: 3, 3: 4}
+    pos = WIN + 10 * HOP
+
+    def mixed(t):
+        mine = list(range(t, N, 4))
+        k = pool2_k[t]
+        bar.wait()
+        o0 = ms[mine[0]].process(x[mine[0], pos: pos + k * HOP])                    # the member's own process()
+        o1 = pool.process_many([(ms[mine[1]], x[mine[1], pos: pos + k * HOP])])[0]
+        outs[mine[0]].append(o0); outs[mine[1]].append(o1)
+
+    ths = [threading.Thread(target=mixed, args=(t,)) for t in range(4)]
+    for th in ths: th.start()
+    for th in ths: th.join(60.0)
+    assert not any(th.is_alive() for th in ths)
+    for i in range(N):
+        got = np.concatenate(outs[i])
+        assert rms(got - want[i][: got.shape[0]]) < WAVE_TOL, (i, rms(got - want[i][: got.shape[0]]))
+        assert got.shape[0] == (1 + 10 + pool2_k[i % 4]) * HOP
+    # an error inside the library reaches the submitter; the pool keeps working
+    st = pool._streams
+    with pytest.raises(ValueError, match="not primed"):
+        fresh = stream.StreamEnhancer.pool(2)
+        fresh._streams.submit_wait(0, np.zeros(HOP, np.float32), 1)
+    with pytest.raises((RuntimeError, ValueError)):
+        st.submit_many([0, 0], [np.zeros(HOP, np.float32)] * 2, [1, 1])             # a slot twice in one submission
+    assert ms[0].process(x[0, :HOP]).shape == (HOP,)
+    # a dropped member gives its slot back at the pool's next call, and the leader stops waiting for it
+    slot = ms[-1]._slot
+    del ms[-1], th, ths
+    gc.collect()
+    e = pool.enhancer()
+    assert e._slot == slot
+    t0 = time.perf_counter()
+    e.process(x[0, :WIN + HOP])
+    assert time.perf_counter() - t0 < 4.0
     runtime.clear_cache()
 
 

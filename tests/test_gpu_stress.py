@@ -80,3 +80,17 @@ def test_two_engines_hop_side_by_side_without_a_timeout():
         assert rec == 0 and alone[i][1] == 0, (i, rec)
         for a_, b_ in zip(res, alone[i][0]):
             np.testing.assert_array_equal(a_, b_)
+
+
+def test_hops_beside_torch_streams_in_the_same_process_never_time_out():
+    """tools/torch_coexist_soak.py in a process of its own with GPU_MAX_HW_QUEUES=4 (HIP's default, not the package's 8): a second host
+    thread keeps two torch streams busy (GEMMs + elementwise kernels) while single-hop streaming calls run; the hop's cross-stream
+    counter join (hop_spin_join) shares hardware queues with them.  Zero recoveries, every hop bit-identical to the run alone."""
+    import json, subprocess, sys
+    root = Path(__file__).resolve().parents[1]
+    for args in (["4000", "16000", "2", "1", "4"], ["1500", "48000", "8", "64", "4"]):
+        r = subprocess.run([sys.executable, str(root / "tools" / "torch_coexist_soak.py")] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert not rec["FAIL"] and rec["recoveries_beside_torch"] == 0 and rec["hops_differing_from_the_run_alone"] == 0, rec
+        assert rec["torch_kernels_launched"] > 100, rec

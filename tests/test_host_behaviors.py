@@ -419,7 +419,7 @@ def test_pool_threads_share_device_calls_and_state_round_trip(monkeypatch):
     for t in ths: t.start()
     for t in ths: t.join()
     assert all(o is not None and o.shape == (4 * HOP,) for o in outs)
-    assert pool.device_calls - base < 8                # coalesced (normally 1 or 2 calls for the eight threads)
+    assert pool.device_calls - base <= 8               # (cross-thread coalescing is the library's: tests/test_gpu_api.py; this double runs one call per submission)
     from dpdfnet_amd import StreamEnhancer
     for i in (0, 7):
         e = StreamEnhancer(model="dpdfnet2")
@@ -553,80 +553,12 @@ def test_process_many_validates_every_item_before_consuming_any(monkeypatch):
     d = pool.enhancer(); slot = d._slot
     del d
     import gc; gc.collect()
-    assert slot in pool._free
-
-
-def test_pool_leader_interrupted_in_its_window_does_not_strand_the_round(monkeypatch):
-    """The leader of a round is interrupted in its coalescing wait (KeyboardInterrupt): the round is closed and run all the same
-    -- the follower queued behind it gets its result, the leader sees its interrupt, and the next caller leads a new round."""
-    import threading
-    WIN, HOP = 320, 160
-    pool = _pool(monkeypatch, 3, win=WIN, window_s=0.0)
-    a, b, c = pool.enhancer(), pool.enhancer(), pool.enhancer()          # three slots in use: two requests do not fire the round early
-    x = (np.random.default_rng(2).standard_normal(WIN + HOP) * 0.3).astype(np.float32)
-    a.process(x[:WIN], sample_rate=16000); b.process(x[:WIN], sample_rate=16000)
-    pool._window = 5.0
-    box = {"go": threading.Event()}
-    real = pool._arrived
-
-    class Cond:
-        """The leader's wait: lets the follower queue up (and notify), then is interrupted."""
-        def wait(self, timeout=None):
-            box["go"].set()
-            real.wait(2.0)
-            raise KeyboardInterrupt()
-        def notify(self):
-            real.notify()
-    pool._arrived = Cond()
-
-    def leader():
-        try:
-            a.process(x[WIN:], sample_rate=16000)
-        except KeyboardInterrupt:
-            box["leader_interrupted"] = True
-
-    def follower():
-        box["follower_out"] = b.process(x[WIN:], sample_rate=16000)
-
-    tl = threading.Thread(target=leader); tl.start()
-    assert box["go"].wait(2.0)
-    tf = threading.Thread(target=follower); tf.start()
-    tl.join(10.0); tf.join(10.0)
-    assert not tl.is_alive() and not tf.is_alive()
-    assert box.get("leader_interrupted") is True
-    assert box["follower_out"].shape == (HOP,)
-    assert pool._leader_active is False and pool._queue == []
-    pool._arrived = real
-    pool._window = 0.0
-    assert a.process(np.zeros(HOP, np.float32), sample_rate=16000).shape == (HOP,)    # a new round can be led
-
-
-def test_pool_round_fires_as_soon_as_every_stream_in_use_has_queued(monkeypatch):
-    """process_many() calls of several threads meet in one round (one device call), and the leader does not sit out its window
-    once every stream in use has a request queued."""
-    import threading, time
-    WIN, HOP = 320, 160
-    pool = _pool(monkeypatch, 8, win=WIN, window_s=0.0)
-    ms = [pool.enhancer() for _ in range(8)]
-    x = (np.random.default_rng(4).standard_normal((8, WIN + HOP)) * 0.3).astype(np.float32)
-    pool.process_many([(m, x[i, :WIN]) for i, m in enumerate(ms)], sample_rate=16000)
-    pool._window = 5.0                                   # a round that waited for its window would take 5 s
-    base = pool.device_calls
-    outs = {}
-    bar = threading.Barrier(4)
-
-    def feeder(t):
-        mine = [(ms[i], x[i, WIN:]) for i in range(t, 8, 4)]
-        bar.wait()
-        outs[t] = pool.process_many(mine, sample_rate=16000)
-
-    t0 = time.perf_counter()
-    ths = [threading.Thread(target=feeder, args=(t,)) for t in range(4)]
-    for th in ths: th.start()
-    for th in ths: th.join(20.0)
-    assert time.perf_counter() - t0 < 2.0                # fired on the eighth request, not on the window
-    assert pool.device_calls - base == 1                 # four threads, one device call
-    assert all(len(outs[t]) == 2 and outs[t][0].shape == (HOP,) for t in range(4))
+    # the finaliser only leaves a note (it must not take the pool's lock: round-4 advisor finding); the pool's next call reaps it
+    assert slot in pool._dropped and slot not in pool._free
+    e = pool.enhancer()
+    assert slot in pool._free or e._slot == slot
+    with pytest.raises(ValueError, match="twice"):
+        pool.process_many([(a, x[:7]), (a, x[:7])], sample_rate=16000)
 
 
 def test_progress_counts_only_the_watched_threads_call(monkeypatch):
@@ -681,14 +613,14 @@ def test_output_blocks_are_leased_and_recycled(monkeypatch):
     rows[2][:] = 7.0
     del a
     gc.collect()
-    assert pool._free == []                            # views alive: still leased
+    assert pool.idle_blocks() == 0                     # views alive: still leased
     keep = rows[2]
     del rows
     gc.collect()
-    assert pool._free == [] and float(keep.sum()) == 7000.0
+    assert pool.idle_blocks() == 0 and float(keep.sum()) == 7000.0
     del keep
     gc.collect()
-    assert len(pool._free) == 1                        # the last view is gone: the block is back
+    assert pool.idle_blocks() == 1                     # the last view is gone: the block is back
     b = pool.take(n - 100)                             # a slightly smaller request takes the same block
     assert b.ctypes.data == addr and pool.reused == 1 and b.shape == (n - 100,)
     c = pool.take(n)                                   # the first block is out: a new one
@@ -699,4 +631,18 @@ def test_output_blocks_are_leased_and_recycled(monkeypatch):
     assert pool.take(n).base is None                   # leasing off: plain arrays
     del b, c
     gc.collect()
-    assert pool._free == []                            # (limit 0: the returned blocks are dropped, nothing is kept)
+    assert pool.idle_blocks() == 0                     # (limit 0: the returned blocks are dropped, nothing is kept)
+    # a finaliser may run at any allocation -- also one made while the pool's lock is held (cyclic GC inside take()): handing a
+    # block back must never need the lock (round-4 advisor finding: self-deadlock on a non-reentrant lock)
+    pool.limit_bytes = 1 << 30
+    d = pool.take(n)
+    import threading
+    done = threading.Event()
+    with pool._lock:
+        t = threading.Thread(target=lambda: (pool._give_back(np.empty(n, np.float32)), done.set()))
+        t.start()
+        assert done.wait(5.0), "_give_back blocked on the pool lock"
+        t.join()
+    del d
+    gc.collect()
+    assert pool.idle_blocks() == 2

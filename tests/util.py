@@ -98,6 +98,41 @@ class PassthroughStreams:
         if ola_tail is not None:
             self.ola[i] = np.asarray(ola_tail, dtype=np.float32)
 
+    # ---- the library's native pool entry points (dpdf_streams_submit*), restated for host-logic tests: one masked call per hop count
+    # of a submission, no cross-thread coalescing (that is the library's job and is tested on the GPU) ----
+    def pool_config(self, window_s):
+        self._pool_calls = getattr(self, "_pool_calls", 0)
+
+    def slot_use(self, slot, in_use):
+        pass
+
+    def pool_stats(self):
+        return getattr(self, "_pool_calls", 0), getattr(self, "_pool_calls", 0)
+
+    def submit_many(self, slots, rows, ks, no_window=False):
+        import threading
+        lock = self.__dict__.setdefault("_pool_lock", threading.Lock())
+        outs = [None] * len(slots)
+        with lock:
+            for k in sorted(set(int(k) for k in ks)):
+                idx = [i for i in range(len(slots)) if int(ks[i]) == k]
+                pcm = np.zeros((self.n, k * self.hop), dtype=np.float32)
+                active = np.zeros(self.n, dtype=bool)
+                for i in idx:
+                    pcm[slots[i]] = rows[i]; active[slots[i]] = True
+                res = self.process_masked(pcm, active)
+                self._pool_calls = getattr(self, "_pool_calls", 0) + 1
+                for i in idx:
+                    outs[i] = res[slots[i]].copy()
+        return outs
+
+    def submit_wait(self, slot, pcm, k, no_window=False):
+        return self.submit_many([slot], [pcm], [k], no_window)[0]
+
+    def submit_block(self, slots, block, k, no_window=False):
+        block = np.asarray(block, dtype=np.float32).reshape(len(slots), -1)
+        return np.stack(self.submit_many([int(x) for x in slots], list(block), [k] * len(slots), no_window))
+
     def process_masked(self, pcm, active):
         """Only the streams with active[i] advance (engine: dpdf_streams_process_masked)."""
         pcm = np.asarray(pcm, dtype=np.float32).reshape(self.n, -1)
