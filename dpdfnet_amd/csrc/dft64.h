@@ -62,15 +62,18 @@ __device__ __forceinline__ double dft64_pair_swap(double v) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int N2>
+// FT = frames per workgroup: 16 for big launches; 4 for the few frames of a streaming hop (64 streams = 64 workgroups of ~2 row
+// tiles per wave instead of 16 of ~8: the launch is one workgroup's latency either way)
+template <int N2, int FT>
 __global__ __launch_bounds__(256) void dft64_fwd_kernel(Dft64Args g) {
     using C = Dft64Cfg<N2>;
-    __shared__ __attribute__((aligned(16))) double mid[16][C::MIDW];
-    __shared__ __attribute__((aligned(16))) float outs[16][C::NK2][16];
-    __shared__ int f_t[16], f_nb[16]; __shared__ long long f_base[16];
+    static_assert(FT == 16 || FT == 4, "stage 2 packs two frames per 16-row tile");
+    __shared__ __attribute__((aligned(16))) double mid[FT][C::MIDW];
+    __shared__ __attribute__((aligned(16))) float outs[FT][C::NK2][16];
+    __shared__ int f_t[FT], f_nb[FT]; __shared__ long long f_base[FT];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
-    const int fr0 = blockIdx.x * 16, grp = blockIdx.y;
-    if (tid < 16) {       // per frame of the tile: first sample index, clip base, clip length (-1: a frame beyond a short clip's last)
+    const int fr0 = blockIdx.x * FT, grp = blockIdx.y;
+    if (tid < FT) {       // per frame of the tile: first sample index, clip base, clip length (-1: a frame beyond a short clip's last)
         const int fr = min(fr0 + tid, g.M - 1);
         const int b = fr / g.seg.Tc, t = g.seg.t0 + (fr - b * g.seg.Tc);
         const int nb_ = g.lens ? g.lens[b] : g.N;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void dft64_fwd_kernel(Dft64Args g) {
     // (loads only: the products are formed in run_tile, one tile later, so that nothing here waits for memory)
     struct Tile { float x[8], wv[8]; unsigned ok; double c[4], s[4]; };
     auto load_tile = [&](int rt, Tile& tl) {
-        const int r = rt * 16 + cl, f = r / N2, n2 = r - f * N2;
+        const int r = min(rt * 16 + cl, FT * N2 - 1), f = r / N2, n2 = r - f * N2;      // (FT = 4: the last tile is half rows)
         const int t0 = f_t[f], nb_ = f_nb[f], np_ = nb_ + C::N;
         const size_t b = (size_t)f_base[f];
         tl.ok = 0;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void dft64_fwd_kernel(Dft64Args g) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                   // middle twiddles of the four result rows of this lane
-            const int ro = rt * 16 + q + 4 * i, no = ro % N2;
+            const int ro = min(rt * 16 + q + 4 * i, FT * N2 - 1), no = ro % N2;
             const double2 cs = *(const double2*)(g.twm + ((size_t)no * 32 + 8 * grp + (cl >> 1)) * 2);
             tl.c[i] = cs.x; tl.s[i] = cs.y;
         }
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(256) void dft64_fwd_kernel(Dft64Args g) {
             const double v = acc[i], p = dft64_pair_swap(v);
             const double o = (cl & 1) ? (v * tl.c[i] - p * tl.s[i]) : (v * tl.c[i] + p * tl.s[i]);
             const int ro = rt * 16 + q + 4 * i, fo = ro / N2, no = ro - fo * N2;
-            mid[fo][no * 16 + cl] = o;
+            if (fo < FT) mid[fo][no * 16 + cl] = o;
         }
     };
-    const int nf = min(16, g.M - fr0);                       // live frames of this tile (a streaming hop of a few streams: 1 .. 15)
+    const int nf = min(FT, g.M - fr0);                       // live frames of this tile (a streaming hop of a few streams: 1 .. 15)
     const int nt1 = (nf * N2 + 15) / 16;                     // row tiles of stage 1 that hold a live frame
     if (w < nt1) {
         Tile ta, tb;
@@ -151,10 +154,10 @@ __global__ __launch_bounds__(256) void dft64_fwd_kernel(Dft64Args g) {
     for (int i = 0; i < C::KS * C::NT; ++i) b2[i] = g.tw2[(size_t)i * 64 + lane];
     __syncthreads();
 
-    // ---- stage 2: rows (frame, k1), 8 row tiles; wave w takes tiles 2 w, 2 w + 1 ----
+    // ---- stage 2: rows (frame, k1), FT / 2 row tiles of two frames; wave w takes tiles w, w + 4 ----
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int tile = 2 * w + j, fa = 2 * tile + (cl >> 3), k1a = cl & 7;
+    for (int j = 0; j < (FT + 7) / 8; ++j) {
+        const int tile = w + 4 * j, fa = min(2 * tile + (cl >> 3), FT - 1), k1a = cl & 7;
         if (2 * tile >= nf) break;                           // (frames of dead tiles: rows of mid that stage 1 did not write)
         f64x4 acc[C::NT];
 #pragma unroll
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void dft64_fwd_kernel(Dft64Args g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = q + 4 * i, col = nt * 16 + cl, k2 = col >> 1;
-                if (k2 < C::NK2) outs[2 * tile + (row >> 3)][k2][2 * (row & 7) + (col & 1)] = (float)acc[nt][i];
+                if (k2 < C::NK2 && 2 * tile + (row >> 3) < FT) outs[2 * tile + (row >> 3)][k2][2 * (row & 7) + (col & 1)] = (float)acc[nt][i];
             }
     }
     __syncthreads();
@@ -218,7 +221,13 @@ static inline void dft64_tables(std::vector<double>& tw1, std::vector<double>& t
 
 static inline void launch_dft64_forward(hipStream_t st, const Dft64Args& a, int win) {
     if (a.M <= 0) return;
+    if (a.M <= 256) {           // a few frames (streaming hops, tiny clips): four frames per workgroup
+        const dim3 grid((a.M + 3) / 4, 4);
+        if (win == 960) hipLaunchKernelGGL(HIP_KERNEL_NAME(dft64_fwd_kernel<30, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(dft64_fwd_kernel<10, 4>), grid, dim3(256), 0, st, a);
+        return;
+    }
     const dim3 grid((a.M + 15) / 16, 4);
-    if (win == 960) hipLaunchKernelGGL(HIP_KERNEL_NAME(dft64_fwd_kernel<30>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(dft64_fwd_kernel<10>), grid, dim3(256), 0, st, a);
+    if (win == 960) hipLaunchKernelGGL(HIP_KERNEL_NAME(dft64_fwd_kernel<30, 16>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(dft64_fwd_kernel<10, 16>), grid, dim3(256), 0, st, a);
 }

@@ -9,6 +9,10 @@ if sys.argv[1] == "run":
     from dpdfnet_amd.weights import synth_blob
     sr, nb, S = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     m = be.HipModel(sr, nb, synth_blob(be.manifest(sr, nb), 20260417), 0)
+    for kv in sys.argv[5:]:                       # engine A/B switches: name=int ("overlap=25": the ERB branch on the main stream)
+        k, v = kv.split("=")
+        if k == "overlap": m.set_overlap(int(v))
+        else: m.set_option(k, int(v))
     st = be.HipStreams(m, S)
     rng = np.random.default_rng(0)
     st.prime((0.05 * rng.standard_normal((S, m.hop))).astype(np.float32))
