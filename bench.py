@@ -233,7 +233,7 @@ def public_api_pass(B: int, steps: int, ref_slots: dict, timeout_s: float = 600.
     raise RuntimeError(f"no result line (rc {r.returncode}): {r.stderr[-300:]}")
 
 
-def public_streams(model_name: str, sr_: int, S: int, calls: int = 200) -> dict:
+def public_streams(model_name: str, sr_: int, S: int, calls: int = 200, pool_kw: dict = None) -> dict:
     """configs[4] through the objects a USER holds (reference package/src/dpdfnet/stream.py:74-165): (a) one
     `StreamEnhancer.group(S)` object, one hop of every stream per process() call; (b) S independent `pool.enhancer()` objects
     fed one hop each per round from four host threads (the pool coalesces the hops that arrive within its window into one
@@ -254,7 +254,7 @@ def public_streams(model_name: str, sr_: int, S: int, calls: int = 200) -> dict:
     dt_group = (time.perf_counter() - t0) / calls
     assert y.shape == (S, hop)
     del g
-    pool = StreamEnhancer.pool(S, window_s=2e-4, **kw)
+    pool = StreamEnhancer.pool(S, **dict(dict(window_s=2e-4), **(pool_kw or {})), **kw)
     members = [pool.enhancer() for _ in range(S)]
     pool.process_many([(m_, np.concatenate([pcm[i], pcm[i]])) for i, m_ in enumerate(members)])
     nthreads, rounds = 4, calls
@@ -279,15 +279,36 @@ def public_streams(model_name: str, sr_: int, S: int, calls: int = 200) -> dict:
     for th in ths:
         th.join()
     calls_per_round = (pool.device_calls - dc0) / rounds
+    # the same pattern with NATIVE feeder threads (tools/pool_native_feeders.cpp: four std::threads, each submitting its 16 streams'
+    # hops through dpdf_streams_submit_block): what the library's pool costs without CPython's GIL hand-offs between the feeders
+    native = {}
+    try:
+        import ctypes
+        helper = ctypes.CDLL(str(Path(__file__).resolve().parent / "tools" / "libpool_native_feeders.so"))
+        L = pool._streams.model._L
+        us = ctypes.c_double(0.0)
+        dc1 = pool.device_calls
+        helper.pool_native_feeders.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+        fn = ctypes.cast(L.dpdf_streams_submit_block, ctypes.c_void_p)
+        for _ in range(2):      # (first pass: thread start-up, buffers)
+            rc = helper.pool_native_feeders(pool._streams._h, fn, S, nthreads, rounds, hop, pcm.ctypes.data, None, ctypes.byref(us))
+        native = {"us_per_round_native_feeders_4_threads": round(us.value, 1), "native_feeder_failures": int(rc),
+                  "native_device_calls_per_round": round((pool.device_calls - dc1) / (2 * rounds), 2)}
+    except OSError as e:
+        native = {"native_feeders": f"helper not built ({e})"}
     for m_ in members:
         m_.close()
     del pool, members
     _rt.clear_cache()
     return {"us_per_call_public_group": round(1e6 * dt_group, 1),
-            "us_per_round_public_pool_4_threads": round(1e6 * dt_pool, 1), "pool_device_calls_per_round": round(calls_per_round, 2),
+            "us_per_round_public_pool_4_threads": round(1e6 * dt_pool, 1), "pool_device_calls_per_round": round(calls_per_round, 2), **native,
             "note": "group: StreamEnhancer.group(S).process([S, hop]) per hop; pool: S pool.enhancer() objects, four host threads "
                     "each feeding its 16 members one hop per round through process_many(); the pool coalesces the four threads' requests into one "
-                    "device call per round (the round fires when all 64 streams in use have queued, or after the 200 us window)"}
+                    "device call per round (the round fires when all 64 streams in use have queued; it waits at most 2 ms for streams that rode in "
+                    "the previous round, 200 us for the others); native feeders: the same four-thread pattern from std::threads on the C ABI "
+                    "(tools/pool_native_feeders.cpp) -- the pool's own cost; the difference to the Python threads is CPython (GIL hand-offs "
+                    "between the four feeders + ~20 us of interpreter per process_many call)"}
 
 
 
@@ -414,6 +435,8 @@ def other_configs(only=None) -> dict:
     if "error" not in pub and "us_per_call" in s48:
         pub["public_group_over_c_abi"] = round(pub["us_per_call_public_group"] / s48["us_per_call"], 3)
         pub["public_pool_over_c_abi"] = round(pub["us_per_round_public_pool_4_threads"] / s48["us_per_call"], 3)
+        if "us_per_round_native_feeders_4_threads" in pub:
+            pub["native_pool_over_c_abi"] = round(pub["us_per_round_native_feeders_4_threads"] / s48["us_per_call"], 3)
     s48["public_objects"] = pub
     out["dpdfnet8_48khz_hr_64_streams_1_hop"] = s48
     out["dpdfnet2_16k_1_stream_1_hop"] = res["streams16"]

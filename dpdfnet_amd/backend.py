@@ -53,8 +53,8 @@ EXPORTED_SYMBOLS = (
     "dpdf_resample_len", "dpdf_resample", "dpdf_enhance_batch_ragged", "dpdf_debug_raise_device_error",
     "dpdf_set_option", "dpdf_streams_process_masked", "dpdf_streams_set_state", "dpdf_streams_get_tails",
     "dpdf_streams_prime_one", "dpdf_streams_is_primed", "dpdf_recovery_count", "dpdf_progress",
-    "dpdf_enhance_batch_rows", "dpdf_streams_pool_config", "dpdf_streams_slot_use", "dpdf_streams_submit_wait",
-    "dpdf_streams_submit_many", "dpdf_streams_submit_block", "dpdf_streams_pool_stats",
+    "dpdf_enhance_batch_rows", "dpdf_streams_pool_config", "dpdf_streams_pool_tune", "dpdf_streams_slot_use", "dpdf_streams_submit_wait",
+    "dpdf_streams_submit_many", "dpdf_streams_submit_block", "dpdf_streams_pool_stats", "dpdf_streams_pool_timing",
 )
 
 
@@ -212,10 +212,12 @@ def load_library() -> ctypes.CDLL:
         L.dpdf_streams_is_primed.argtypes = [vp, ctypes.c_int]
         L.dpdf_progress.argtypes = [vp]
         L.dpdf_streams_pool_config.argtypes = [vp, ctypes.c_double]
+        L.dpdf_streams_pool_tune.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.dpdf_streams_slot_use.argtypes = [vp, ctypes.c_int, ctypes.c_int]
         L.dpdf_streams_submit_wait.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int]
         L.dpdf_streams_submit_many.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int]
         L.dpdf_streams_submit_block.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, ctypes.c_int]
+        L.dpdf_streams_pool_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
         L.dpdf_streams_pool_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
         L.dpdf_recovery_count.argtypes = [vp]
         L.dpdf_recovery_count.restype = ctypes.c_long
@@ -587,6 +589,9 @@ class HipStreams:
     def pool_config(self, window_s: float) -> None:
         _check(self.model._L.dpdf_streams_pool_config(self._h, float(window_s)))
 
+    def pool_tune(self, window_s: float, regular_window_s: float, spin_s: float) -> None:
+        _check(self.model._L.dpdf_streams_pool_tune(self._h, float(window_s), float(regular_window_s), float(spin_s)))
+
     def slot_use(self, slot: int, in_use: bool) -> None:
         _check(self.model._L.dpdf_streams_slot_use(self._h, int(slot), 1 if in_use else 0))
 
@@ -594,6 +599,12 @@ class HipStreams:
         a, b = ctypes.c_long(0), ctypes.c_long(0)
         _check(self.model._L.dpdf_streams_pool_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return int(a.value), int(b.value)
+
+    def pool_timing(self) -> Tuple[float, float, float]:
+        """Seconds summed over all rounds: leaders waiting for other submitters, inside device calls, between device calls."""
+        a = (ctypes.c_double * 3)()
+        _check(self.model._L.dpdf_streams_pool_timing(self._h, a))
+        return float(a[0]), float(a[1]), float(a[2])
 
     def submit_wait(self, slot: int, pcm: np.ndarray, k: int, no_window: bool = False) -> np.ndarray:
         """k whole hops (float32, contiguous) for one slot -> its k * hop enhanced samples; rides in the round other threads' submissions
@@ -605,8 +616,10 @@ class HipStreams:
     def submit_block(self, slots: np.ndarray, block: np.ndarray, k: int, no_window: bool = False) -> np.ndarray:
         """n = len(slots) requests of k hops each, rows of `block` [n, k * hop] (float32, contiguous) -> [n, k * hop]."""
         out = np.empty(block.shape, dtype=np.float32)
-        _check(self.model._L.dpdf_streams_submit_block(self._h, int(slots.shape[0]), slots.ctypes.data, block.ctypes.data, int(k), out.ctypes.data,
-                                                       1 if no_window else 0))
+        rc = self.model._L.dpdf_streams_submit_block(self._h, slots.shape[0], slots.ctypes.data, block.ctypes.data, k, out.ctypes.data,
+                                                     1 if no_window else 0)
+        if rc:
+            _check(rc)
         return out
 
     def submit_many(self, slots: Sequence[int], rows: Sequence[np.ndarray], ks: Sequence[int], no_window: bool = False) -> List[np.ndarray]:

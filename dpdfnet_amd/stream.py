@@ -148,10 +148,10 @@ class StreamEnhancer:
 
     @staticmethod
     def pool(n_slots: int, model: str = DEFAULT_MODEL, onnx_path: Optional[Union[str, Path]] = None,
-             verbose: bool = False, window_s: float = 2e-4) -> "StreamPool":
+             verbose: bool = False, window_s: float = 2e-4, **tuning) -> "StreamPool":
         """Up to n_slots INDEPENDENT streams (each a StreamEnhancer-shaped object from `pool.enhancer()`) whose hops are
-        coalesced into shared device calls (`StreamPool`)."""
-        return StreamPool(n_slots, model=model, onnx_path=onnx_path, verbose=verbose, window_s=window_s)
+        coalesced into shared device calls (`StreamPool`; tuning: its `regular_window_s`, `spin_s`)."""
+        return StreamPool(n_slots, model=model, onnx_path=onnx_path, verbose=verbose, window_s=window_s, **tuning)
 
     def reset(self) -> None:
         """Reset RNN state and internal buffers (reference stream.py:62-72)."""
@@ -183,10 +183,15 @@ class StreamPool:
         window_s: how long the first submitter of a round waits for other threads' hops before it issues the device call for
             everyone queued (0: no waiting, still coalesces what is already queued).  It only waits while more than one host
             thread has been feeding the pool within the last second, and never longer than until every stream in use has queued.
+        regular_window_s: the same for streams that rode in the previous round (their callers feed the pool hop after hop and
+            are on their way back: firing without them costs everybody a second device call).
+        spin_s: for this long a round's leader and the callers waiting for its result poll instead of sleeping (a wake-up
+            through the kernel costs tens of microseconds per thread and round; 0: always sleep).  Only threads inside a
+            pool call poll, without the GIL.
     """
 
     def __init__(self, n_slots: int, model: str = DEFAULT_MODEL, onnx_path: Optional[Union[str, Path]] = None,
-                 verbose: bool = False, window_s: float = 2e-4) -> None:
+                 verbose: bool = False, window_s: float = 2e-4, regular_window_s: float = 2e-3, spin_s: float = 1e-3) -> None:
         if int(n_slots) < 1:
             raise ValueError(f"n_slots must be positive, got {n_slots}")
         self._n = int(n_slots)
@@ -198,7 +203,7 @@ class StreamPool:
         self._win_len: int = infer_win_len(self._runtime.session, self._model_sr)
         self._hop_size: int = self._win_len // 2
         self._streams = self._runtime.session.open_streams(self._n)
-        self._streams.pool_config(float(window_s))
+        self._streams.pool_tune(float(window_s), float(regular_window_s), float(spin_s))
         self._free: List[int] = list(range(self._n - 1, -1, -1))
         # slots of members that were dropped without close(): their finaliser only appends here (it may run at any allocation,
         # also one made under `_lock`, so it must not take a lock); `_reap` hands them back
@@ -252,32 +257,38 @@ class StreamPool:
         different sizes; each result is exactly what `enhancer.process(chunk)` returns).  Other threads' submissions that arrive
         within the window share the device call(s).  wait=False: do not wait for other threads at all (a caller that knows it
         is the only one feeding the pool)."""
-        items = list(items)
+        if type(items) is not list:
+            items = list(items)
         n = len(items)
         if self._dropped:
             self._reap()
         hop = self._hop_size
         # steady state of live streams: every member primed with nothing buffered, every chunk a float32 vector of the same whole
         # number of hops at the model rate -- the chunks ARE the round's input: one gather, one C call, results handed out as rows
+        # (this is host code that runs, under the GIL, between a round's result and the caller's next submission: kept short)
         if n and (sample_rate is None or sample_rate == self._model_sr):
             first = items[0][1]
             if type(first) is np.ndarray and first.ndim == 1 and first.dtype == np.float32 and first.shape[0] and first.shape[0] % hop == 0:
-                L = first.shape[0]
+                shape = first.shape
                 ok = True
+                key = []
                 for enh, c in items:
-                    if not (enh._steady and enh._pool is self and type(c) is np.ndarray and c.dtype == np.float32 and c.shape == first.shape):
+                    if not (enh._steady and enh._pool is self and type(c) is np.ndarray and c.dtype == np.float32 and c.shape == shape):
                         ok = False
                         break
+                    key.append(enh._slot)
                 if ok:
-                    key = tuple([e._slot for e, _ in items])          # (slot numbers, not the members: the cache must not keep them alive)
+                    key = tuple(key)                                   # (slot numbers, not the members: the cache must not keep them alive)
                     slots = self._slots_cache.get(key)
                     if slots is None:
+                        if len(set(key)) != n:
+                            raise ValueError("an enhancer appears twice in one process_many() call")
                         slots = np.array(key, dtype=np.int32)
                         if len(self._slots_cache) > 64:
                             self._slots_cache.clear()
                         self._slots_cache[key] = slots
-                    out = self._streams.submit_block(slots, np.concatenate([c for _, c in items]), L // hop, not wait)
-                    return list(out.reshape(n, L))
+                    out = self._streams.submit_block(slots, np.concatenate([c for _, c in items]), shape[0] // hop, not wait)
+                    return list(out.reshape(n, shape[0]))
         # validate EVERY item before any member's buffer is touched: a bad later item must not leave earlier members with hops
         # taken out of their buffers and never sent to the device
         seen = set()

@@ -124,9 +124,13 @@ int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in, int n_hops
                                 const unsigned char* active, int flags);
 /* Native coalescing for INDEPENDENT stream objects (the reference's usage pattern: N StreamEnhancer instances, each fed by its own
  * caller whenever it has a chunk, package/src/dpdfnet/stream.py:13-72, 74-165; replaces the per-object session.run of :129-135).
- * Any host thread submits whole hops for slots it owns; the first submitter of a round leads it: it waits -- at most the window
- * (dpdf_streams_pool_config, default 200 us), only until every slot marked in use (dpdf_streams_slot_use) has queued, and not at
- * all while it is the only thread that has submitted lately -- then issues ONE masked device call for the whole round.  Samples go
+ * Any host thread submits whole hops for slots it owns; the first submitter of a round leads it: it waits -- only until every slot
+ * marked in use (dpdf_streams_slot_use) has queued, and not at all while it is the only thread that has submitted lately; at most
+ * `regular_window_s` (default 2 ms) for the slots that rode in the previous round (their callers are feeding the pool hop after hop
+ * and are on their way back), at most `window_s` (default 200 us) for in-use slots that sat the previous round out -- then issues ONE
+ * masked device call for the whole round.  dpdf_streams_pool_tune sets both windows and `spin_s`: for that long a round's leader and
+ * the submitters waiting for its result poll instead of sleeping on the condition variable (a wake-up through the kernel costs tens of
+ * microseconds per thread, in front of that thread's NEXT submission; default 0 = never poll).  Samples go
  * straight into the round's pinned GPU-visible block and results come straight out of it, copied by the submitting threads
  * themselves, in parallel; the next round fills while this one is on the GPU.
  *   dpdf_streams_submit_wait: k_hops whole hops for one slot in, k_hops * hop samples out (blocks until the round is done).
@@ -136,6 +140,7 @@ int dpdf_streams_process_masked(dpdf_streams* s, const float* pcm_in, int n_hops
  * submitter of that round. */
 #define DPDF_POOL_NO_WINDOW 1
 int dpdf_streams_pool_config(dpdf_streams* s, double window_s);
+int dpdf_streams_pool_tune(dpdf_streams* s, double window_s, double regular_window_s, double spin_s);
 int dpdf_streams_slot_use(dpdf_streams* s, int slot, int in_use);
 int dpdf_streams_submit_wait(dpdf_streams* s, int slot, const float* pcm, int k_hops, float* out, int flags);
 int dpdf_streams_submit_many(dpdf_streams* s, int n, const int* slots, const float* const* in_rows, const int* k_hops,
@@ -143,6 +148,9 @@ int dpdf_streams_submit_many(dpdf_streams* s, int n, const int* slots, const flo
 int dpdf_streams_submit_block(dpdf_streams* s, int n, const int* slots, const float* in_block /* [n][k_hops*hop] */, int k_hops,
                               float* out_block, int flags);
 int dpdf_streams_pool_stats(dpdf_streams* s, long* device_calls, long* rounds);   /* masked device calls issued / rounds run; NULL = skip */
+/* seconds summed over all rounds so far: [0] leaders waiting for the other submitters, [1] inside the device calls, [2] from the end of one
+ * device call to the start of the next (submitters collecting, the caller's own code, coming back, the wait of [0]) */
+int dpdf_streams_pool_timing(dpdf_streams* s, double* out3);
 /* Resume = the explicit state vector (onnx_backend.py:52-78): `state` is the reference's flat state
  * layout (from dpdf_streams_get_state, dpdf_run_frames or the reference's own session loop); in_tail / ola_tail are the
  * StreamEnhancer's analysis buffer and overlap-add buffer (stream.py:62-72, hop floats each).  Host pointers; a NULL part

@@ -103,6 +103,9 @@ class PassthroughStreams:
     def pool_config(self, window_s):
         self._pool_calls = getattr(self, "_pool_calls", 0)
 
+    def pool_tune(self, window_s, regular_window_s, spin_s):
+        self._pool_calls = getattr(self, "_pool_calls", 0)
+
     def slot_use(self, slot, in_use):
         pass
 
