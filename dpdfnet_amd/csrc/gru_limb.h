@@ -1,0 +1,145 @@
+// gru_limb.h -- the GRU(64) scans with every fp32 product formed from THREE bf16 limbs per operand on the bf16 matrix pipe.
+//
+// The fp32 matrix rate of CDNA4 is 256 FLOP/cycle/CU (v_mfma_f32_16x16x4_f32: 32 cycles per SIMD), the bf16 rate 4096
+// (v_mfma_f32_16x16x32_bf16: 16 cycles for eight times the MACs).  The GRU-64 kernels of gru_scan.h sit at 77-81 % matrix-pipe busy
+// -- the fp32 rate IS their bound.  But
+//   * an fp32 value is EXACTLY hi + mid + lo with three bf16 values (8 + 8 + 8 significand bits; hi = rne(x), mid = rne(x - hi),
+//     lo = x - hi - mid: the residues are exact fp32 subtractions and the last one fits bf16 exactly),
+//   * the product of two bf16 values is exact in fp32, and the MFMA accumulates in fp32,
+// so a . w = sum of nine limb products, of which lo.lo, lo.mid, mid.lo are < 2^-24 of the term and are dropped.  Six bf16 MFMAs per
+// fp32 product term: 2.67 x the fp32 matrix rate at the accuracy of the fp32 kernels (tools/gru64_limb_bench.hip measures both against a
+// float64 recurrence: the limb form is the CLOSER one, its products being exact where the fp32 MFMA rounds every partial sum).
+//
+// Layout (one 256-thread workgroup = 16 rows, wave w = hidden units [16w, 16w + 16), as in gru_scan.h), TRANSPOSED against the fp32
+// kernels: D[unit][row] = W[unit][k] . act[row][k], i.e.
+//   * A operand = WEIGHTS: lane (q, m) of k-chunk c holds W[unit 16w + m][32c + 8q .. + 7] -- 6 matrices (ih / hh x r, z, n) x 2 chunks x
+//     3 limbs x 4 VGPRs = 144 VGPRs, resident for the whole scan;
+//   * B operand = ACTIVATIONS: lane (q, n) reads 16 bytes act_limb[row n][32c + 8q .. + 7] from an LDS limb plane ([limb][row][72 bf16]:
+//     144-byte rows, consecutive rows 4 banks apart -- conflict-free ds_read_b128);
+//   * D: lane (q, n), register i = (unit 16w + 4q + i, row n): a lane ends up with FOUR CONSECUTIVE units of one row -- its h' goes to
+//     HBM as one float4 and into the limb planes as three 8-byte stores (the fp32 kernels' C layout has four rows of one unit per lane:
+//     twelve 2-byte stores).
+// The split of h' and of the next x tile into limbs is ~22 VALU instructions per lane and side (v_cvt_pk_bf16_f32 is RNE).
+// Reference: onnx_model/layers.py:159-196, 1235-1259.
+#pragma once
+#include "common.h"
+#include "gru_scan.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int GRU64L_FRAG_PER_WAVE = 6 * 2 * 3;      // [mat = side * 3 + gate][k-chunk][limb] uint4 fragments per lane
+
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // low half = bf16(a), high half = bf16(b), round to nearest even
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// four fp32 values -> three limbs of four bf16 each (exact: v = hi + mid + lo)
+__device__ __forceinline__ void split3(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    hi.x = pk_bf16(v.x, v.y); hi.y = pk_bf16(v.z, v.w);
+    float r0 = v.x - bf_lo(hi.x), r1 = v.y - bf_hi(hi.x), r2 = v.z - bf_lo(hi.y), r3 = v.w - bf_hi(hi.y);
+    mid.x = pk_bf16(r0, r1); mid.y = pk_bf16(r2, r3);
+    r0 -= bf_lo(mid.x); r1 -= bf_hi(mid.x); r2 -= bf_lo(mid.y); r3 -= bf_hi(mid.y);
+    lo.x = pk_bf16(r0, r1); lo.y = pk_bf16(r2, r3);
+}
+
+// the six limb pairs of a product, smallest first: (weight limb, activation limb)
+#define GRU64L_TERMS(F) F(2, 0) F(0, 2) F(1, 1) F(1, 0) F(0, 1) F(0, 0)
+
+// wl: [dir][wave 4][mat 6][chunk 2][limb 3][lane 64] uint4 (build_gru64_limbs); bias: the fp32 kernels' [dir][4][64]
+__global__ __launch_bounds__(256, 2) void gru64_scan_l3_kernel(Gru64Args a, const uint4* wl) {
+    __shared__ __attribute__((aligned(16))) unsigned short Hp[2][3][16][72];
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[2][3][16][72];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dir = blockIdx.y;
+    const int row0 = blockIdx.x * 16;
+    const int cl = lane & 15, q = lane >> 4;
+
+    uint4 wk[6][2][3];
+    {
+        const uint4* wp = wl + ((size_t)(dir * 4 + w) * GRU64L_FRAG_PER_WAVE) * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int l = 0; l < 3; ++l) wk[mt][c][l] = wp[(size_t)((mt * 2 + c) * 3 + l) * 64];
+    }
+    const int u0 = 16 * w + 4 * q;                       // this lane's four hidden units
+    const float* bp = a.bias + (size_t)dir * 256 + u0;
+    const float4 b_r = *(const float4*)bp, b_z = *(const float4*)(bp + 64), b_in = *(const float4*)(bp + 128), b_hn = *(const float4*)(bp + 192);
+
+    // x tiles arrive row-contiguous (lane (w, q, cl): the 16-byte piece [row 4w + q][cols 4cl .. 4cl + 3]), h' leaves from the D layout
+    // (lane (q, cl): [row cl][units u0 .. u0 + 3]); wave-uniform 64-bit bases, 32-bit lane offsets
+    const int hi0 = row0 / a.rdiv, lo0 = row0 - hi0 * a.rdiv;
+    const float* xbase = a.x + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
+    float* obase = a.out + (long)hi0 * a.o_hi + (long)lo0 * a.o_lo + dir * a.o_dir_off;
+    const int srow = 4 * w + q, scol = 4 * cl;
+    unsigned sx_off, o_off; bool o_ok;
+    {
+        int rs = row0 + srow; if (rs >= a.nrows) rs = a.nrows - 1;
+        sx_off = (unsigned)((long)(rs / a.rdiv - hi0) * a.x_hi + (long)(rs % a.rdiv - lo0) * a.x_lo) + scol;
+        int rc = row0 + cl; o_ok = rc < a.nrows; if (!o_ok) rc = a.nrows - 1;
+        o_off = (unsigned)((long)(rc / a.rdiv - hi0) * a.o_hi + (long)(rc % a.rdiv - lo0) * a.o_lo) + u0;
+    }
+    float* hp = nullptr;
+    float4 h_own = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.hstate) {
+        int rc = row0 + cl; if (rc >= a.nrows) rc = a.nrows - 1;
+        hp = a.hstate + (long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + u0;
+        h_own = *(const float4*)hp;
+    }
+    {
+        uint2 l0, l1, l2;
+        split3(h_own, l0, l1, l2);
+        *(uint2*)&Hp[1][0][cl][u0] = l0; *(uint2*)&Hp[1][1][cl][u0] = l1; *(uint2*)&Hp[1][2][cl][u0] = l2;
+        const int p0 = dir ? a.nsteps - 1 : 0;
+        split3(*(const float4*)((xbase + (long)p0 * a.x_step) + sx_off), l0, l1, l2);
+        *(uint2*)&Xp[0][0][srow][scol] = l0; *(uint2*)&Xp[0][1][srow][scol] = l1; *(uint2*)&Xp[0][2][srow][scol] = l2;
+    }
+    __syncthreads();
+
+    for (int s = 0; s < a.nsteps; ++s) {
+        const int buf = s & 1;
+        const int sn = s + 1 < a.nsteps ? s + 1 : s;
+        const float4 xnext = *(const float4*)((xbase + (long)(dir ? a.nsteps - 1 - sn : sn) * a.x_step) + sx_off);
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 xb[2][3], hb[2][3];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                xb[c][l] = *(const uint4*)&Xp[buf][l][cl][32 * c + 8 * q];
+                hb[c][l] = *(const uint4*)&Hp[buf ^ 1][l][cl][32 * c + 8 * q];
+            }
+        f32x4 arx = {b_r.x, b_r.y, b_r.z, b_r.w}, azx = {b_z.x, b_z.y, b_z.z, b_z.w};
+        f32x4 axn = {b_in.x, b_in.y, b_in.z, b_in.w}, ahn = {b_hn.x, b_hn.y, b_hn.z, b_hn.w};
+        f32x4 arh = {0.f, 0.f, 0.f, 0.f}, azh = {0.f, 0.f, 0.f, 0.f};
+#define GRU64L_STEP(WL, AL) \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c) { \
+            arx = mfma_bf16(wk[0][c][WL], xb[c][AL], arx); azx = mfma_bf16(wk[1][c][WL], xb[c][AL], azx); axn = mfma_bf16(wk[2][c][WL], xb[c][AL], axn); \
+            arh = mfma_bf16(wk[3][c][WL], hb[c][AL], arh); azh = mfma_bf16(wk[4][c][WL], hb[c][AL], azh); ahn = mfma_bf16(wk[5][c][WL], hb[c][AL], ahn); \
+        }
+        GRU64L_TERMS(GRU64L_STEP)
+#undef GRU64L_STEP
+        const f32x4 ar = arx + arh, az = azx + azh;
+        float4 hn;
+        hn.x = gru64_cell(ar[0], az[0], axn[0], ahn[0], h_own.x); hn.y = gru64_cell(ar[1], az[1], axn[1], ahn[1], h_own.y);
+        hn.z = gru64_cell(ar[2], az[2], axn[2], ahn[2], h_own.z); hn.w = gru64_cell(ar[3], az[3], axn[3], ahn[3], h_own.w);
+        h_own = hn;
+        if (o_ok) *(float4*)((obase + (long)(dir ? a.nsteps - 1 - s : s) * a.o_step) + o_off) = hn;
+        uint2 l0, l1, l2;
+        split3(hn, l0, l1, l2);
+        *(uint2*)&Hp[buf][0][cl][u0] = l0; *(uint2*)&Hp[buf][1][cl][u0] = l1; *(uint2*)&Hp[buf][2][cl][u0] = l2;
+        __builtin_amdgcn_sched_barrier(0);
+        split3(xnext, l0, l1, l2);
+        *(uint2*)&Xp[buf ^ 1][0][srow][scol] = l0; *(uint2*)&Xp[buf ^ 1][1][srow][scol] = l1; *(uint2*)&Xp[buf ^ 1][2][srow][scol] = l2;
+        __syncthreads();
+    }
+    if (hp && o_ok) *(float4*)hp = h_own;
+}

@@ -180,6 +180,37 @@ class Oracle:
         lib().dpdf_oracle_enhance(self._h, _fp(wav), wav.size, db, _fp(out))
         return out
 
+    def stream(self, wav: np.ndarray) -> np.ndarray:
+        """The reference StreamEnhancer's arithmetic (package/src/dpdfnet/stream.py:74-200) around this oracle's frame function:
+        causal float32 frame * window, float64 rfft rounded to float32 (numpy 1.26.4's np.fft.rfft, the reference's pin), frame
+        function, irfft * window overlap-add, flush() with a zero-padded last window.  Pinned by tests/golden/stream_*.npz."""
+        win, hop = self.win_len, self.hop
+        w = self.window()
+        x = np.asarray(wav, dtype=np.float32)
+        n_full = (len(x) - win) // hop + 1 if len(x) >= win else 0
+        left = x[n_full * hop:]
+        if len(left):                                   # flush(): pad the remainder to one full window, keep len(left) samples (<= hop)
+            x = np.concatenate([x[: n_full * hop], np.pad(left, (0, win - len(left)))])
+        st = self.initial_state()
+        ola = np.zeros(win, dtype=np.float32)
+        out = []
+        n_frames = (len(x) - win) // hop + 1 if len(x) >= win else 0
+        for t in range(n_frames):
+            fr = (x[t * hop: t * hop + win] * w).astype(np.float32)
+            c = np.fft.rfft(fr.astype(np.float64), n=win)
+            spec = np.stack([c.real.astype(np.float32), c.imag.astype(np.float32)], axis=-1)
+            se, st = self.frame(spec, st)
+            y = (np.fft.irfft(se[:, 0].astype(np.float64) + 1j * se[:, 1].astype(np.float64), n=win) * w).astype(np.float32)
+            ola += y
+            out.append(ola[:hop].copy())
+            ola[: win - hop] = ola[hop:]
+            ola[win - hop:] = 0.0
+        y = np.concatenate(out) if out else np.zeros(0, np.float32)
+        if len(left):
+            keep = min(len(left), hop)
+            y = np.concatenate([y[: n_full * hop], y[n_full * hop: n_full * hop + keep]])
+        return y
+
     def erb_widths(self) -> List[int]:
         w = (ctypes.c_int * 64)()
         n = lib().dpdf_oracle_erb_widths(self._h, w, 64)
