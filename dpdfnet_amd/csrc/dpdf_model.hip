@@ -37,6 +37,7 @@
 #include "common.h"
 #include "gemm_rows.h"
 #include "gru_scan.h"
+#include "gru_limb.h"
 #include "misc_kernels.h"
 #include "resample.h"
 #include "df_ring.h"
@@ -218,11 +219,13 @@ struct SepConvW { size_t dw, pwfrag, bias; int nsub; };        // arena offsets
 struct PathW { size_t ps, pb; };
 struct GruW64 { size_t wfrag, bias; int ndirs;
                 size_t hh4;                   // W_hh for the 4-row scan (gru_scan4.h): [dir][wave 4][instruction 64][lane 4b+i]: gate i of unit 16 wave + b (i = 3: zero)
+                size_t wl;                    // the same weights as bf16 limb fragments (gru_limb.h): [dir][wave 4][mat 6][chunk 2][limb 3][lane 64] x 8 bf16
                 size_t ih_frag, ih_bias; };   // W_ih as a gemm_rows operand: [dir*3+gate][chunk][nt][kb][lane] + bias [dir*3+gate][64] (small-batch scan)
 struct GlW { size_t frag, bias; int G, Og, Ig, NT; };
 struct Gru256W { size_t ih_frag_s, ih_bias, hh_frag, b_hn, ih_as_hh; };   // ih_as_hh: W_ih packed like hh_frag (second cell of a stacked pair, gru_stack.h)   // ih_frag_s: the same W_ih in 24 column blocks of 32 (few-row launches)   // hh_frag: [unit-group 16][gate 3][chunk 16][kb 4][lane 64]
 struct DprnnW { GruW64 intra, inter; size_t fci_frag, fci_b, lni_g, lni_b, fce_frag, fce_b, lne_g, lne_b;
-                size_t fci_epi, fce_epi; };   // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
+                size_t fci_epi, fce_epi;      // fc fragments for the fused-epilogue scans: [part][wave][16][lane]
+                size_t fci_lb, fci_lf, fce_l; };   // ... as bf16 limb fragments (gru_limb.h): fc_intra's hb half, its hf half, fc_inter: [wave 4][chunk 2][limb 3][lane 64] x 8 bf16
 
 }  // namespace
 
@@ -445,6 +448,8 @@ struct dpdf_model {
     long dbg_nspec = 0, dbg_nframes = 0;
     int dft2 = 1;                      // big launches: STFT / iSTFT as two small matrix stages (0: one [win x 2F] GEMM; A/B)
     size_t dft64_tw1 = 0, dft64_twm = 0, dft64_tw2 = 0;   // operands of the float64 analysis DFT (dft64.h; doubles stored in the float arena)
+    int gru64_limbs = 1;               // the GRU-64 throughput kernels on bf16 limbs (gru_limb.h: every fp32 product from three bf16 limbs per operand, six
+                                       // bf16 MFMAs per term, fp32 accumulation -- fp32-exact products at 2.67 x the fp32 matrix rate); 0 = the fp32-MFMA kernels of gru_scan.h
     int dft64 = 2;                     // analysis STFT in float64 on every call path (dft64.h): 1 = 48 kHz models only (per-bin log-magnitude features), 2 = 16 kHz too (default: one analysis everywhere), 0 = the fp32 forms (A/B)
     bool use_dft64() const { return (d.win == 960 && dft64 >= 1) || (d.win == 320 && dft64 >= 2); }
     HostPipe hp;                       // pinned staging ring + copy streams of the host-pointer batch calls
@@ -604,6 +609,35 @@ PathW build_path(Arena& A, const Blob& B, const std::string& p) {
     return w;
 }
 
+// fp32 -> three bf16 limbs, v = hi + mid + lo exactly (round to nearest even; the residues are exact fp32 subtractions): gru_limb.h
+static inline unsigned short bf16_rne_bits(float x) {
+    unsigned u; memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float bf16_bits_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline void limbs3(float v, unsigned short out[3]) {
+    out[0] = bf16_rne_bits(v); const float r1 = v - bf16_bits_f(out[0]);
+    out[1] = bf16_rne_bits(r1); const float r2 = r1 - bf16_bits_f(out[1]);
+    out[2] = bf16_rne_bits(r2);
+}
+// limb fragments of `nmat` matrices [16-row wave block 4][k-chunk 2][limb 3][lane 64] x 8 bf16 as an arena blob (bit patterns in floats):
+// A operand of v_mfma_f32_16x16x32_bf16 -- lane (q, m) holds W(mat, row 16 w + m, k = 32 c + 8 q + j), j = 0..7
+template <class Fn>
+static std::vector<float> pack_limb_frags(int nouter, int nmat, Fn w) {      // layout [outer][wave][mat][chunk][limb][lane][8]
+    std::vector<unsigned short> f((size_t)nouter * 4 * nmat * 2 * 3 * 64 * 8);
+    for (int o = 0; o < nouter; ++o) for (int wv = 0; wv < 4; ++wv) for (int mt = 0; mt < nmat; ++mt) for (int c = 0; c < 2; ++c)
+        for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+            unsigned short l3[3];
+            limbs3(w(o, mt, 16 * wv + (lane & 15), 32 * c + 8 * (lane >> 4) + j), l3);
+            for (int l = 0; l < 3; ++l)
+                f[((((((size_t)o * 4 + wv) * nmat + mt) * 2 + c) * 3 + l) * 64 + lane) * 8 + j] = l3[l];
+        }
+    std::vector<float> out(f.size() / 2);
+    memcpy(out.data(), f.data(), f.size() * 2);
+    return out;
+}
+
 // [dir][wave][part][gate][chunk*4+kb][lane] + bias [dir][4][64]
 GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::string, std::string>>& dirs) {
     GruW64 g; g.ndirs = (int)dirs.size();
@@ -636,6 +670,14 @@ GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::str
         }
     }
     g.wfrag = A.add(frag); g.bias = A.add(bias);
+    {   // bf16 limb fragments (gru_limb.h) of the SAME scaled fp32 values: mat = side * 3 + gate
+        std::vector<const float*> wi(g.ndirs), wh(g.ndirs);
+        for (int d = 0; d < g.ndirs; ++d) { wi[d] = B.get(dirs[d].first + ".weight_ih" + dirs[d].second); wh[d] = B.get(dirs[d].first + ".weight_hh" + dirs[d].second); }
+        g.wl = A.add(pack_limb_frags(g.ndirs, 6, [&](int d, int mt, int unit, int k) {
+            const int gate = mt % 3;
+            return (mt < 3 ? wi[d] : wh[d])[(size_t)(gate * 64 + unit) * 64 + k] * gate_scale[gate];
+        }));
+    }
     {   // 4-row scan (gru_scan4.h): A operand of instruction t = 4m + g of wave w, lane 4b + i = scaled W_hh[gate i][unit 16w + b][k],
         // k = 4m + ((g + b) & 3) -- the k that block b meets under the B operand's lane-group broadcast g (i = 3: zero)
         std::vector<float> f4((size_t)g.ndirs * 4 * 64 * 64, 0.f);
@@ -750,6 +792,10 @@ std::vector<DprnnW> build_dprnn(Arena& A, const Blob& B, const std::string& p, i
             fi.insert(fi.end(), fi1.begin(), fi1.end());
             w.fci_epi = A.add(fi);
             w.fce_epi = A.add(pack_epi(B.get(q + ".fc_inter.weight"), 64, 0));
+            const float* fiw = B.get(q + ".fc_intra.weight"); const float* few = B.get(q + ".fc_inter.weight");
+            w.fci_lb = A.add(pack_limb_frags(1, 1, [&](int, int, int n, int k) { return fiw[(size_t)n * 128 + 64 + k]; }));
+            w.fci_lf = A.add(pack_limb_frags(1, 1, [&](int, int, int n, int k) { return fiw[(size_t)n * 128 + k]; }));
+            w.fce_l = A.add(pack_limb_frags(1, 1, [&](int, int, int n, int k) { return few[(size_t)n * 64 + k]; }));
         }
         v.push_back(w);
     }
@@ -1137,7 +1183,20 @@ struct DprnnWalk {
         ai.x = x; ai.wfrag = m->C(w.intra.wfrag); ai.bias = m->C(w.intra.bias); ai.hstate = nullptr;
         ai.nrows = B * Tc; ai.nsteps = Fp; ai.rdiv = 1;
         ai.x_hi = (long)Fp * 64; ai.x_lo = 0; ai.x_step = 64;
-        if (fuse_intra) {
+        if (fuse_intra && m->gru64_limbs) {
+            // bf16-limb kernels (gru_limb.h): the forward scan leaves pf = W_fc[:, 0:64] hf in `hin`, the backward scan adds its own half
+            ai.out = hin; ai.ndirs = 1; ai.o_hi = (long)Fp * 64; ai.o_lo = 0; ai.o_step = 64; ai.o_dir_off = 0;
+            {
+                ProfScope ps(m, df ? "gru64_l3_kernel<0>/intra_fwd_df" : "gru64_l3_kernel<0>/intra_fwd_erb");
+                Gru64LArgs la{ai, (const uint4*)m->C(w.intra.wl), (const uint4*)m->C(w.fci_lf), nullptr, nullptr, nullptr, nullptr, nullptr};
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_l3_kernel<0>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, la);
+            }
+            {
+                ProfScope ps(m, df ? "gru64_l3_kernel<2>/intra_bwd_df" : "gru64_l3_kernel<2>/intra_bwd_erb");
+                Gru64LArgs la{ai, (const uint4*)m->C(w.intra.wl), (const uint4*)m->C(w.fci_lb), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b), hin, y};
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_l3_kernel<2>), dim3((ai.nrows + 15) / 16), dim3(256), 0, m->cur, la);
+            }
+        } else if (fuse_intra) {
             {   // forward direction: plain scan, hf -> `hin` scratch [rows][Fp][64]
                 ProfScope ps(m, df ? "gru64_scan_kernel/intra_fwd_df" : "gru64_scan_kernel/intra_fwd_erb");
                 ai.out = hin; ai.ndirs = 1; ai.o_hi = (long)Fp * 64; ai.o_lo = 0; ai.o_step = 64; ai.o_dir_off = 0;
@@ -1208,7 +1267,12 @@ struct DprnnWalk {
         ae.x_hi = (long)Tc * Fp * 64; ae.x_lo = 64; ae.x_step = (long)Fp * 64;
         ae.o_hi = ae.x_hi; ae.o_lo = 64; ae.o_step = ae.x_step; ae.o_dir_off = 0;
         ae.h_hi = S; ae.h_lo = 64;
-        if (fuse_inter) {   // inter scan + fc_inter + ln_inter + residual
+        if (fuse_inter && m->gru64_limbs) {
+            ProfScope ps(m, df ? "gru64_l3_kernel<1>/inter_df" : "gru64_l3_kernel<1>/inter_erb");
+            ae.out = nullptr;
+            Gru64LArgs la{ae, (const uint4*)m->C(w.inter.wl), (const uint4*)m->C(w.fce_l), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_l3_kernel<1>), dim3((ae.nrows + 15) / 16), dim3(256), 0, m->cur, la);
+        } else if (fuse_inter) {   // inter scan + fc_inter + ln_inter + residual
             ProfScope ps(m, df ? "gru64_epi_kernel<1>/inter_df" : "gru64_epi_kernel<1>/inter_erb");
             ae.out = nullptr;
             Gru64EpiArgs ea{ae, m->C(w.fce_epi), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};
@@ -2169,6 +2233,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "tail_frames") m->tail_frames = value < 0 ? 0 : std::min(value, 48);
     else if (n == "stft_ksplit") m->stft_ksplit = value & 7;
     else if (n == "dft64") m->dft64 = value;
+    else if (n == "gru64_limbs") m->gru64_limbs = value;
     else if (n == "gru256_step") m->gru256_step = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
     else if (n == "hop_fused") m->hop_fused = value != 0;

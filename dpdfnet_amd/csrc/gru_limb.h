@@ -51,41 +51,73 @@ __device__ __forceinline__ void split3(const float4 v, uint2& hi, uint2& mid, ui
 // the six limb pairs of a product, smallest first: (weight limb, activation limb)
 #define GRU64L_TERMS(F) F(2, 0) F(0, 2) F(1, 1) F(1, 0) F(0, 1) F(0, 0)
 
-// wl: [dir][wave 4][mat 6][chunk 2][limb 3][lane 64] uint4 (build_gru64_limbs); bias: the fp32 kernels' [dir][4][64]
-__global__ __launch_bounds__(256, 2) void gru64_scan_l3_kernel(Gru64Args a, const uint4* wl) {
+// ---------------------------------------------------------------------------------------------------------------------------------
+// gru64_l3_kernel<MODE>: the three throughput kernels of a DPRNN block (gru_scan.h: gru64_scan_kernel, gru64_epi_kernel<1>, <2>) on limbs.
+//   MODE 0  intra-band FORWARD scan.  Its h' sequence is needed by nothing but fc_intra (the Linear over [hf | hb], reference
+//           onnx_model/layers.py:178-181), so it leaves as pf(p) = W_fc[:, 0:64] hf(p) -- 64 floats per position like hf itself, and the
+//           backward kernel's fc shrinks to its own half (one fc matrix per kernel: the 24 VGPRs that still fit beside the GRU's 144);
+//   MODE 2  intra-band BACKWARD scan: y(p) = x(p) + LN(pf(p) + W_fc[:, 64:128] hb(p) + b);
+//   MODE 1  inter-band scan (state carried): y(s) = x(s) + LN(W_fc h'(s) + b).
+// The fc product of step s - 1 rides on the h operand of step s (the same limb registers); MODE 0 stores it from the D layout (a float4 of
+// four consecutive channels per lane), MODES 1 / 2 pass it through an LDS tile to the row-contiguous lanes, which hold the residual x and
+// normalise one step later (16 lanes x 4 values = one 64-channel row: statistics are two DPP butterflies) -- output lags by two steps.
+struct Gru64LArgs {
+    Gru64Args g;            // MODE 0: g.out = pf; MODES 1, 2: g.out unused
+    const uint4* wl;        // GRU limb fragments [dir][wave 4][mat 6][chunk 2][limb 3][lane 64]
+    const uint4* fcl;       // fc limb fragments [wave 4][chunk 2][limb 3][lane 64] (the half / matrix this kernel multiplies by its own h')
+    const float* fc_bias; const float* ln_g; const float* ln_b;   // [64] (MODES 1, 2)
+    const float* extra;     // MODE 2: pf, addressed like x
+    float* y;               // MODES 1, 2: output, addressed like x
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
+    const Gru64Args& a = ea.g;
+    constexpr bool EPI = MODE != 0;
     __shared__ __attribute__((aligned(16))) unsigned short Hp[2][3][16][72];
     __shared__ __attribute__((aligned(16))) unsigned short Xp[2][3][16][72];
+    __shared__ __attribute__((aligned(16))) float Xs[EPI ? 4 : 1][EPI ? 16 : 1][EPI ? 68 : 4];     // residual x, fp32: x(s - 2) must outlive x(s + 1)'s staging
+    __shared__ __attribute__((aligned(16))) float Ys[EPI ? 2 : 1][EPI ? 16 : 1][EPI ? 68 : 4];
+    __shared__ __attribute__((aligned(16))) float Lp[7][64];                                       // fc bias | ln gamma | ln beta | GRU biases r, z, in, hn
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int dir = blockIdx.y;
+    const int dir = MODE == 2 ? 1 : 0;
     const int row0 = blockIdx.x * 16;
     const int cl = lane & 15, q = lane >> 4;
 
-    uint4 wk[6][2][3];
+    uint4 wk[6][2][3], wf[2][3];
     {
-        const uint4* wp = wl + ((size_t)(dir * 4 + w) * GRU64L_FRAG_PER_WAVE) * 64 + lane;
+        const uint4* wp = ea.wl + ((size_t)(dir * 4 + w) * GRU64L_FRAG_PER_WAVE) * 64 + lane;
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int l = 0; l < 3; ++l) wk[mt][c][l] = wp[(size_t)((mt * 2 + c) * 3 + l) * 64];
+        const uint4* fp = ea.fcl + ((size_t)w * 6) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) wf[c][l] = fp[(size_t)(c * 3 + l) * 64];
     }
-    const int u0 = 16 * w + 4 * q;                       // this lane's four hidden units
-    const float* bp = a.bias + (size_t)dir * 256 + u0;
-    const float4 b_r = *(const float4*)bp, b_z = *(const float4*)(bp + 64), b_in = *(const float4*)(bp + 128), b_hn = *(const float4*)(bp + 192);
+    const int u0 = 16 * w + 4 * q;                       // this lane's four hidden units / fc output channels
+    if (tid < 64) {
+        if (EPI) { Lp[0][tid] = ea.fc_bias[tid]; Lp[1][tid] = ea.ln_g[tid]; Lp[2][tid] = ea.ln_b[tid]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Lp[3 + k][tid] = a.bias[(size_t)dir * 256 + 64 * k + tid];
+    }
 
-    // x tiles arrive row-contiguous (lane (w, q, cl): the 16-byte piece [row 4w + q][cols 4cl .. 4cl + 3]), h' leaves from the D layout
-    // (lane (q, cl): [row cl][units u0 .. u0 + 3]); wave-uniform 64-bit bases, 32-bit lane offsets
     const int hi0 = row0 / a.rdiv, lo0 = row0 - hi0 * a.rdiv;
     const float* xbase = a.x + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
-    float* obase = a.out + (long)hi0 * a.o_hi + (long)lo0 * a.o_lo + dir * a.o_dir_off;
+    const float* ebase = MODE == 2 ? ea.extra + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo : nullptr;
+    float* ybase = EPI ? ea.y + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo : nullptr;
+    float* obase = MODE == 0 ? a.out + (long)hi0 * a.o_hi + (long)lo0 * a.o_lo : nullptr;
     const int srow = 4 * w + q, scol = 4 * cl;
-    unsigned sx_off, o_off; bool o_ok;
+    unsigned sx_off, o_off = 0; bool s_ok, o_ok;
     {
-        int rs = row0 + srow; if (rs >= a.nrows) rs = a.nrows - 1;
+        int rs = row0 + srow; s_ok = rs < a.nrows; if (!s_ok) rs = a.nrows - 1;
         sx_off = (unsigned)((long)(rs / a.rdiv - hi0) * a.x_hi + (long)(rs % a.rdiv - lo0) * a.x_lo) + scol;
         int rc = row0 + cl; o_ok = rc < a.nrows; if (!o_ok) rc = a.nrows - 1;
-        o_off = (unsigned)((long)(rc / a.rdiv - hi0) * a.o_hi + (long)(rc % a.rdiv - lo0) * a.o_lo) + u0;
+        if (MODE == 0) o_off = (unsigned)((long)(rc / a.rdiv - hi0) * a.o_hi + (long)(rc % a.rdiv - lo0) * a.o_lo) + u0;
     }
     float* hp = nullptr;
     float4 h_own = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -94,51 +126,82 @@ __global__ __launch_bounds__(256, 2) void gru64_scan_l3_kernel(Gru64Args a, cons
         hp = a.hstate + (long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + u0;
         h_own = *(const float4*)hp;
     }
+    const int n = a.nsteps;
+    auto pos_of = [&](int s) { s = s < 0 ? 0 : (s < n ? s : n - 1); return dir ? n - 1 - s : s; };    // clamped: head and tail re-read a valid tile
     {
         uint2 l0, l1, l2;
         split3(h_own, l0, l1, l2);
         *(uint2*)&Hp[1][0][cl][u0] = l0; *(uint2*)&Hp[1][1][cl][u0] = l1; *(uint2*)&Hp[1][2][cl][u0] = l2;
-        const int p0 = dir ? a.nsteps - 1 : 0;
-        split3(*(const float4*)((xbase + (long)p0 * a.x_step) + sx_off), l0, l1, l2);
+        const float4 x0 = *(const float4*)((xbase + (long)pos_of(0) * a.x_step) + sx_off);
+        split3(x0, l0, l1, l2);
         *(uint2*)&Xp[0][0][srow][scol] = l0; *(uint2*)&Xp[0][1][srow][scol] = l1; *(uint2*)&Xp[0][2][srow][scol] = l2;
+        if (EPI) *(float4*)&Xs[0][srow][scol] = x0;
     }
+    float4 e_prev = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    for (int s = 0; s < a.nsteps; ++s) {
+    constexpr int LAG = EPI ? 2 : 1;
+    for (int s = 0; s < n + LAG; ++s) {
         const int buf = s & 1;
-        const int sn = s + 1 < a.nsteps ? s + 1 : s;
-        const float4 xnext = *(const float4*)((xbase + (long)(dir ? a.nsteps - 1 - sn : sn) * a.x_step) + sx_off);
+        // ---- finalize step s - 2: LayerNorm + residual on the row-contiguous pieces, one 16-byte store per lane
+        if (EPI && s >= 2) {
+            float4 yv = *(const float4*)&Ys[buf ^ 1][srow][scol];                 // fc(h'(s - 2)), written during step s - 1
+            const float4 rv = *(const float4*)&Xs[(s - 2) & 3][srow][scol];       // residual x(s - 2)
+            const float4 fb = *(const float4*)&Lp[0][scol];
+            yv.x += fb.x; yv.y += fb.y; yv.z += fb.z; yv.w += fb.w;
+            if (MODE == 2) { yv.x += e_prev.x; yv.y += e_prev.y; yv.z += e_prev.z; yv.w += e_prev.w; }
+            const float mean = row16_allreduce_sum(yv.x + yv.y + yv.z + yv.w) * (1.0f / 64.0f);
+            const float d0 = yv.x - mean, d1 = yv.y - mean, d2 = yv.z - mean, d3 = yv.w - mean;
+            const float s2 = row16_allreduce_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+            const float inv = rsqrtf(s2 * (1.0f / 64.0f) + 1e-5f);
+            const float4 gg = *(const float4*)&Lp[1][scol], bb = *(const float4*)&Lp[2][scol];
+            float4 o;
+            o.x = rv.x + d0 * inv * gg.x + bb.x; o.y = rv.y + d1 * inv * gg.y + bb.y;
+            o.z = rv.z + d2 * inv * gg.z + bb.z; o.w = rv.w + d3 * inv * gg.w + bb.w;
+            if (s_ok) *(float4*)((ybase + (long)pos_of(s - 2) * a.x_step) + sx_off) = o;
+        }
+        // ---- loads for step s + 1 (and the pf tile of step s - 1: consumed by the finalize of the next iteration)
+        const float4 xnext = *(const float4*)((xbase + (long)pos_of(s + 1) * a.x_step) + sx_off);
+        float4 e_ld = xnext;
+        if (MODE == 2) e_ld = *(const float4*)((ebase + (long)pos_of(s - 1) * a.x_step) + sx_off);
         __builtin_amdgcn_sched_barrier(0);
         uint4 xb[2][3], hb[2][3];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
-                xb[c][l] = *(const uint4*)&Xp[buf][l][cl][32 * c + 8 * q];
                 hb[c][l] = *(const uint4*)&Hp[buf ^ 1][l][cl][32 * c + 8 * q];
+                xb[c][l] = *(const uint4*)&Xp[buf][l][cl][32 * c + 8 * q];
             }
-        f32x4 arx = {b_r.x, b_r.y, b_r.z, b_r.w}, azx = {b_z.x, b_z.y, b_z.z, b_z.w};
+        const float4 b_r = *(const float4*)&Lp[3][u0], b_z = *(const float4*)&Lp[4][u0], b_in = *(const float4*)&Lp[5][u0], b_hn = *(const float4*)&Lp[6][u0];
+        f32x4 ar = {b_r.x, b_r.y, b_r.z, b_r.w}, az = {b_z.x, b_z.y, b_z.z, b_z.w};
         f32x4 axn = {b_in.x, b_in.y, b_in.z, b_in.w}, ahn = {b_hn.x, b_hn.y, b_hn.z, b_hn.w};
-        f32x4 arh = {0.f, 0.f, 0.f, 0.f}, azh = {0.f, 0.f, 0.f, 0.f};
+        f32x4 ay = {0.f, 0.f, 0.f, 0.f};
 #define GRU64L_STEP(WL, AL) \
         _Pragma("unroll") for (int c = 0; c < 2; ++c) { \
-            arx = mfma_bf16(wk[0][c][WL], xb[c][AL], arx); azx = mfma_bf16(wk[1][c][WL], xb[c][AL], azx); axn = mfma_bf16(wk[2][c][WL], xb[c][AL], axn); \
-            arh = mfma_bf16(wk[3][c][WL], hb[c][AL], arh); azh = mfma_bf16(wk[4][c][WL], hb[c][AL], azh); ahn = mfma_bf16(wk[5][c][WL], hb[c][AL], ahn); \
+            ar = mfma_bf16(wk[3][c][WL], hb[c][AL], ar); az = mfma_bf16(wk[4][c][WL], hb[c][AL], az); ahn = mfma_bf16(wk[5][c][WL], hb[c][AL], ahn); \
+            ay = mfma_bf16(wf[c][WL], hb[c][AL], ay); \
+            ar = mfma_bf16(wk[0][c][WL], xb[c][AL], ar); az = mfma_bf16(wk[1][c][WL], xb[c][AL], az); axn = mfma_bf16(wk[2][c][WL], xb[c][AL], axn); \
         }
         GRU64L_TERMS(GRU64L_STEP)
 #undef GRU64L_STEP
-        const f32x4 ar = arx + arh, az = azx + azh;
         float4 hn;
         hn.x = gru64_cell(ar[0], az[0], axn[0], ahn[0], h_own.x); hn.y = gru64_cell(ar[1], az[1], axn[1], ahn[1], h_own.y);
         hn.z = gru64_cell(ar[2], az[2], axn[2], ahn[2], h_own.z); hn.w = gru64_cell(ar[3], az[3], axn[3], ahn[3], h_own.w);
-        h_own = hn;
-        if (o_ok) *(float4*)((obase + (long)(dir ? a.nsteps - 1 - s : s) * a.o_step) + o_off) = hn;
+        if (s < n) h_own = hn;                            // (iterations past the last step only drain the epilogue)
         uint2 l0, l1, l2;
         split3(hn, l0, l1, l2);
         *(uint2*)&Hp[buf][0][cl][u0] = l0; *(uint2*)&Hp[buf][1][cl][u0] = l1; *(uint2*)&Hp[buf][2][cl][u0] = l2;
+        if (MODE == 0) {
+            if (s >= 1 && o_ok) *(float4*)((obase + (long)pos_of(s - 1) * a.o_step) + o_off) = make_float4(ay[0], ay[1], ay[2], ay[3]);
+        } else {
+            *(float4*)&Ys[buf][cl][u0] = make_float4(ay[0], ay[1], ay[2], ay[3]);     // fc(h'(s - 1)): read by the finalize of iteration s + 1
+        }
         __builtin_amdgcn_sched_barrier(0);
         split3(xnext, l0, l1, l2);
         *(uint2*)&Xp[buf ^ 1][0][srow][scol] = l0; *(uint2*)&Xp[buf ^ 1][1][srow][scol] = l1; *(uint2*)&Xp[buf ^ 1][2][srow][scol] = l2;
+        if (EPI) *(float4*)&Xs[(s + 1) & 3][srow][scol] = xnext;
+        e_prev = e_ld;
         __syncthreads();
     }
     if (hp && o_ok) *(float4*)hp = h_own;

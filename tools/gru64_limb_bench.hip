@@ -64,64 +64,90 @@ int main() {
         }
     (void)hipMemcpy(wl, wlh.data(), wlh.size() * 2, hipMemcpyHostToDevice);
 
-    Gru64Args a{}; a.x = x; a.out = out; a.wfrag = wf; a.bias = bias; a.hstate = nullptr;
-    a.nrows = rows; a.nsteps = Fp; a.ndirs = 2; a.rdiv = 1; a.x_hi = Fp * 64; a.x_lo = 0; a.x_step = 64;
-    a.o_hi = Fp * 128; a.o_lo = 0; a.o_step = 128; a.o_dir_off = 64;
+    // fc_intra [64 out][128 in] (in 0..63 = hf, 64..127 = hb), fc_inter [64][64], biases, LayerNorm parameters
+    std::vector<float> Fi(64 * 128), Fe(64 * 64), fb(64), lg(64), lb(64);
+    for (auto& v : Fi) v = 0.15f * rnd();
+    for (auto& v : Fe) v = 0.15f * rnd();
+    for (int i = 0; i < 64; ++i) { fb[i] = 0.1f * rnd(); lg[i] = 1.0f + 0.2f * rnd(); lb[i] = 0.1f * rnd(); }
+    auto pack_epi = [&](const float* Wm, int ld, int koff) {
+        std::vector<float> f((size_t)4 * 16 * 64);
+        for (int wv = 0; wv < 4; ++wv) for (int c = 0; c < 4; ++c) for (int kb = 0; kb < 4; ++kb) for (int lane = 0; lane < 64; ++lane)
+            f[((size_t)wv * 16 + c * 4 + kb) * 64 + lane] = Wm[(size_t)(16 * wv + (lane & 15)) * ld + koff + 16 * c + 4 * (lane >> 4) + kb];
+        return f;
+    };
+    auto pack_fcl = [&](const float* Wm, int ld, int koff) {       // [wave][chunk][limb][lane] x 8 bf16
+        std::vector<unsigned short> f((size_t)4 * 6 * 64 * 8);
+        for (int wv = 0; wv < 4; ++wv) for (int c = 0; c < 2; ++c) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+            const float v = Wm[(size_t)(16 * wv + (lane & 15)) * ld + koff + 32 * c + 8 * (lane >> 4) + j];
+            const unsigned short hi = bf16_rne(v); const float r1 = v - bf16_f(hi);
+            const unsigned short mi = bf16_rne(r1); const float r2 = r1 - bf16_f(mi);
+            const unsigned short limbs[3] = {hi, mi, bf16_rne(r2)};
+            for (int l = 0; l < 3; ++l) f[(((size_t)wv * 2 + c) * 3 + l) * 64 * 8 + (size_t)lane * 8 + j] = limbs[l];
+        }
+        return f;
+    };
+    auto up = [&](const void* src, size_t bytes) { void* d; (void)hipMalloc(&d, bytes); (void)hipMemcpy(d, src, bytes, hipMemcpyHostToDevice); return d; };
+    std::vector<float> fi_epi = pack_epi(Fi.data(), 128, 64), fi1 = pack_epi(Fi.data(), 128, 0);
+    fi_epi.insert(fi_epi.end(), fi1.begin(), fi1.end());
+    std::vector<float> fe_epi = pack_epi(Fe.data(), 64, 0);
+    const float* d_fi_epi = (const float*)up(fi_epi.data(), fi_epi.size() * 4); const float* d_fe_epi = (const float*)up(fe_epi.data(), fe_epi.size() * 4);
+    auto fl_b = pack_fcl(Fi.data(), 128, 64), fl_f = pack_fcl(Fi.data(), 128, 0), fl_e = pack_fcl(Fe.data(), 64, 0);
+    const uint4* d_fl_b = (const uint4*)up(fl_b.data(), fl_b.size() * 2); const uint4* d_fl_f = (const uint4*)up(fl_f.data(), fl_f.size() * 2);
+    const uint4* d_fl_e = (const uint4*)up(fl_e.data(), fl_e.size() * 2);
+    const float* d_fb = (const float*)up(fb.data(), 256); const float* d_lg = (const float*)up(lg.data(), 256); const float* d_lb = (const float*)up(lb.data(), 256);
+    float *hf, *pf, *y1, *y2, *hs1, *hs2;
+    const size_t nx = (size_t)rows * Fp * 64;
+    (void)hipMalloc(&hf, nx * 4); (void)hipMalloc(&pf, nx * 4); (void)hipMalloc(&y1, nx * 4); (void)hipMalloc(&y2, nx * 4);
+    (void)hipMalloc(&hs1, (size_t)rows * 64 * 4); (void)hipMalloc(&hs2, (size_t)rows * 64 * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int N = 10;
-    const double flops = (double)rows * Fp * 2 * 49152.0;
-    float ms;
-    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(gru64_scan_kernel, dim3(rows / 16, 2), dim3(256), 0, 0, a);
-    (void)hipEventRecord(e0);
-    for (int it = 0; it < N; ++it) hipLaunchKernelGGL(gru64_scan_kernel, dim3(rows / 16, 2), dim3(256), 0, 0, a);
-    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
-    (void)hipEventElapsedTime(&ms, e0, e1); ms /= N;
-    printf("fp32 MFMA scan      rows %d: %.3f ms  %.1f TFLOP/s useful (%.1f%% of the fp32 peak 157.3)\n", rows, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100);
-    Gru64Args b = a; b.out = out2;
-    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(gru64_scan_l3_kernel, dim3(rows / 16, 2), dim3(256), 0, 0, b, (const uint4*)wl);
-    (void)hipEventRecord(e0);
-    for (int it = 0; it < N; ++it) hipLaunchKernelGGL(gru64_scan_l3_kernel, dim3(rows / 16, 2), dim3(256), 0, 0, b, (const uint4*)wl);
-    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
-    if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
-    float ms2; (void)hipEventElapsedTime(&ms2, e0, e1); ms2 /= N;
-    printf("3-limb bf16 scan    rows %d: %.3f ms  %.1f TFLOP/s useful = %.1f TFLOP/s of bf16 MFMA issued (%.1f%% of 2500)   speed-up %.2f x\n", rows, ms2,
-           flops / ms2 / 1e9, 6 * flops / ms2 / 1e9, 6 * flops / ms2 / 1e9 / 2500 * 100, ms / ms2);
-    // accuracy: both against a double-precision recurrence on the first 32 rows (two tiles), both directions
-    const int R = 32;
-    std::vector<float> o1((size_t)R * Fp * 128), o2((size_t)R * Fp * 128);
-    (void)hipMemcpy(o1.data(), out, o1.size() * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(o2.data(), out2, o2.size() * 4, hipMemcpyDeviceToHost);
-    double e1s = 0, e2s = 0, d12 = 0, sig = 0, m1 = 0, m2 = 0; size_t cnt = 0;
-    for (int r = 0; r < R; ++r) for (int dir = 0; dir < 2; ++dir) {
-        double hh[64] = {0};
-        for (int s = 0; s < Fp; ++s) {
-            const int p = dir ? Fp - 1 - s : s;
-            const float* xr = &h[((size_t)r * Fp + p) * 64];
-            double pre[2][3][64];
-            for (int side = 0; side < 2; ++side) for (int g = 0; g < 3; ++g) for (int u = 0; u < 64; ++u) {
-                double acc = 0;
-                for (int k = 0; k < 64; ++k) acc += (double)Wc(dir, side, g, u, k) * (side ? hh[k] : (double)xr[k]);
-                pre[side][g][u] = acc;
-            }
-            double hn[64];
-            for (int u = 0; u < 64; ++u) {
-                const double ar = pre[0][0][u] + pre[1][0][u] + B[dir * 256 + u], az = pre[0][1][u] + pre[1][1][u] + B[dir * 256 + 64 + u];
-                const double rr = 1.0 / (1.0 + exp2(ar)), zz = 1.0 / (1.0 + exp2(az));
-                const double t = pre[0][2][u] + B[dir * 256 + 128 + u] + rr * (pre[1][2][u] + B[dir * 256 + 192 + u]);
-                const double n = 2.0 / (1.0 + exp2(t)) - 1.0;
-                hn[u] = n + zz * (hh[u] - n);
-            }
-            for (int u = 0; u < 64; ++u) {
-                hh[u] = hn[u];
-                const size_t o = ((size_t)r * Fp + p) * 128 + dir * 64 + u;
-                const double a1 = o1[o] - hn[u], a2 = o2[o] - hn[u];
-                e1s += a1 * a1; e2s += a2 * a2; sig += hn[u] * hn[u]; d12 += ((double)o1[o] - o2[o]) * ((double)o1[o] - o2[o]); ++cnt;
-                if (fabs(a1) > m1) m1 = fabs(a1);
-                if (fabs(a2) > m2) m2 = fabs(a2);
-            }
-        }
+    auto timeit = [&](auto f) { for (int i = 0; i < 2; ++i) f(); (void)hipEventRecord(e0); for (int i = 0; i < N; ++i) f(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                                float ms; (void)hipEventElapsedTime(&ms, e0, e1); return ms / N; };
+    auto cmp = [&](const char* what, const float* da, const float* db, size_t cnt) {
+        std::vector<float> A(cnt), Bv(cnt);
+        (void)hipMemcpy(A.data(), da, cnt * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(Bv.data(), db, cnt * 4, hipMemcpyDeviceToHost);
+        double d = 0, sg = 0, mx = 0; bool fin = true;
+        for (size_t i = 0; i < cnt; ++i) { const double e = (double)A[i] - Bv[i]; d += e * e; sg += (double)A[i] * A[i]; if (fabs(e) > mx) mx = fabs(e); fin = fin && std::isfinite(Bv[i]); }
+        printf("  %s: limb vs fp32 kernels RMS %.3e  max %.3e  (signal RMS %.3f, finite %d)\n", what, sqrt(d / cnt), mx, sqrt(sg / cnt), (int)fin);
+    };
+    // ---- intra-band pair: rows = frames, steps = band positions
+    {
+        Gru64Args a{}; a.x = x; a.wfrag = wf; a.bias = bias; a.hstate = nullptr;
+        a.nrows = rows; a.nsteps = Fp; a.rdiv = 1; a.x_hi = Fp * 64; a.x_lo = 0; a.x_step = 64;
+        a.out = hf; a.ndirs = 1; a.o_hi = Fp * 64; a.o_lo = 0; a.o_step = 64; a.o_dir_off = 0;
+        Gru64EpiArgs e2{a, d_fi_epi, d_fb, d_lg, d_lb, hf, y1};
+        const float t_f = timeit([&] { hipLaunchKernelGGL(gru64_scan_kernel, dim3(rows / 16, 1), dim3(256), 0, 0, a); });
+        const float t_b = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<2>), dim3(rows / 16), dim3(256), 0, 0, e2); });
+        Gru64Args b = a; b.out = pf;
+        Gru64LArgs l0{b, (const uint4*)wl, d_fl_f, nullptr, nullptr, nullptr, nullptr, nullptr};
+        Gru64LArgs l2{b, (const uint4*)wl, d_fl_b, d_fb, d_lg, d_lb, pf, y2};
+        const float u_f = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_l3_kernel<0>), dim3(rows / 16), dim3(256), 0, 0, l0); });
+        const float u_b = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_l3_kernel<2>), dim3(rows / 16), dim3(256), 0, 0, l2); });
+        if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
+        printf("intra forward : fp32 %.3f ms   limbs %.3f ms   %.2f x\nintra backward: fp32 %.3f ms   limbs %.3f ms   %.2f x\n", t_f, u_f, t_f / u_f, t_b, u_b, t_b / u_b);
+        cmp("intra block output y", y1, y2, (size_t)4096 * Fp * 64);
     }
-    printf("against the float64 recurrence (%d rows x %d steps x 2 directions, signal RMS %.3f):\n  fp32 MFMA kernel   RMS %.3e  max %.3e\n  3-limb bf16 kernel RMS %.3e  max %.3e\n  kernel vs kernel   RMS %.3e\n",
-           R, Fp, sqrt(sig / cnt), sqrt(e1s / cnt), m1, sqrt(e2s / cnt), m2, sqrt(d12 / cnt));
+    // ---- inter-band: rows = (clip, band position), steps = frames, carried state
+    {
+        const int Tc = 192, Bc = rows * Fp / (Tc * Fp) , nr = Bc * Fp;          // same number of x elements
+        Gru64Args a{}; a.x = x; a.wfrag = wf; a.bias = bias;
+        a.nrows = nr; a.nsteps = Tc; a.ndirs = 1; a.rdiv = Fp;
+        a.x_hi = (long)Tc * Fp * 64; a.x_lo = 64; a.x_step = (long)Fp * 64; a.o_hi = a.x_hi; a.o_lo = 64; a.o_step = a.x_step; a.o_dir_off = 0;
+        a.h_hi = (long)Fp * 64; a.h_lo = 64; a.out = nullptr;
+        std::vector<float> h0((size_t)rows * 64);
+        for (auto& v : h0) v = 0.5f * rnd();
+        Gru64Args a1 = a; a1.hstate = hs1; Gru64Args a2 = a; a2.hstate = hs2;
+        Gru64EpiArgs e1a{a1, d_fe_epi, d_fb, d_lg, d_lb, nullptr, y1};
+        Gru64LArgs l1{a2, (const uint4*)wl, d_fl_e, d_fb, d_lg, d_lb, nullptr, y2};
+        const float t_e = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<1>), dim3((nr + 15) / 16), dim3(256), 0, 0, e1a); });
+        const float u_e = timeit([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_l3_kernel<1>), dim3((nr + 15) / 16), dim3(256), 0, 0, l1); });
+        printf("inter (%d rows x %d frames): fp32 %.3f ms   limbs %.3f ms   %.2f x\n", nr, Tc, t_e, u_e, t_e / u_e);
+        (void)hipMemcpy(hs1, h0.data(), h0.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(hs2, h0.data(), h0.size() * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_epi_kernel<1>), dim3((nr + 15) / 16), dim3(256), 0, 0, e1a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_l3_kernel<1>), dim3((nr + 15) / 16), dim3(256), 0, 0, l1);
+        (void)hipDeviceSynchronize();
+        cmp("inter block output y", y1, y2, (size_t)16 * Tc * Fp * 64);
+        cmp("inter carried state ", hs1, hs2, (size_t)nr * 64);
+    }
     return 0;
 }
