@@ -38,6 +38,13 @@ __device__ __forceinline__ float gru64_cell(float ar, float az, float axn, float
     return __builtin_fmaf(z, h - n, n);
 }
 
+// A load that is coherent across the chip's eight XCDs (agent scope: not served from a stale line of this XCD's L2).  For tensors whose
+// 128-byte lines are written piecewise by workgroups on DIFFERENT XCDs -- the deep-filter taps: df_out's groups write 240-byte pieces of a
+// coefs row from one workgroup each -- a writer's L2 fills the rest of such a line with the OLD contents and keeps that copy; a reader on
+// the same XCD in the next kernel gets the neighbour's bytes stale (seen as single wrong low-band frames, a few per thousand, in
+// multi-chunk batches once the stage-1 kernels got faster; same-process A/B: 19-59 clips of 256 per run -> 0).
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // K index supplied by lane-quad q (= lane>>4) for MFMA kb (0..3) of 16-wide K chunk c.
 // All A fragments (4 contiguous floats per lane per chunk) and all packed B fragments use it.
 __host__ __device__ inline int kperm(int c, int q, int kb) { return 16 * c + 4 * q + kb; }

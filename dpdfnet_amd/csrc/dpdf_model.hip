@@ -448,7 +448,7 @@ struct dpdf_model {
     long dbg_nspec = 0, dbg_nframes = 0;
     int dft2 = 1;                      // big launches: STFT / iSTFT as two small matrix stages (0: one [win x 2F] GEMM; A/B)
     size_t dft64_tw1 = 0, dft64_twm = 0, dft64_tw2 = 0;   // operands of the float64 analysis DFT (dft64.h; doubles stored in the float arena)
-    int gru64_limbs = 1;               // the GRU-64 throughput kernels on bf16 limbs (gru_limb.h: every fp32 product from three bf16 limbs per operand, six
+    int gru64_limbs = 3;               // (bit 0: intra-band pair, bit 1: inter-band scan) the GRU-64 throughput kernels on bf16 limbs (gru_limb.h: every fp32 product from three bf16 limbs per operand, six
                                        // bf16 MFMAs per term, fp32 accumulation -- fp32-exact products at 2.67 x the fp32 matrix rate); 0 = the fp32-MFMA kernels of gru_scan.h
     int dft64 = 2;                     // analysis STFT in float64 on every call path (dft64.h): 1 = 48 kHz models only (per-bin log-magnitude features), 2 = 16 kHz too (default: one analysis everywhere), 0 = the fp32 forms (A/B)
     bool use_dft64() const { return (d.win == 960 && dft64 >= 1) || (d.win == 320 && dft64 >= 2); }
@@ -1183,7 +1183,7 @@ struct DprnnWalk {
         ai.x = x; ai.wfrag = m->C(w.intra.wfrag); ai.bias = m->C(w.intra.bias); ai.hstate = nullptr;
         ai.nrows = B * Tc; ai.nsteps = Fp; ai.rdiv = 1;
         ai.x_hi = (long)Fp * 64; ai.x_lo = 0; ai.x_step = 64;
-        if (fuse_intra && m->gru64_limbs) {
+        if (fuse_intra && (m->gru64_limbs & 1)) {
             // bf16-limb kernels (gru_limb.h): the forward scan leaves pf = W_fc[:, 0:64] hf in `hin`, the backward scan adds its own half
             ai.out = hin; ai.ndirs = 1; ai.o_hi = (long)Fp * 64; ai.o_lo = 0; ai.o_step = 64; ai.o_dir_off = 0;
             {
@@ -1267,7 +1267,7 @@ struct DprnnWalk {
         ae.x_hi = (long)Tc * Fp * 64; ae.x_lo = 64; ae.x_step = (long)Fp * 64;
         ae.o_hi = ae.x_hi; ae.o_lo = 64; ae.o_step = ae.x_step; ae.o_dir_off = 0;
         ae.h_hi = S; ae.h_lo = 64;
-        if (fuse_inter && m->gru64_limbs) {
+        if (fuse_inter && (m->gru64_limbs & 2)) {
             ProfScope ps(m, df ? "gru64_l3_kernel<1>/inter_df" : "gru64_l3_kernel<1>/inter_erb");
             ae.out = nullptr;
             Gru64LArgs la{ae, (const uint4*)m->C(w.inter.wl), (const uint4*)m->C(w.fce_l), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b), nullptr, y};

@@ -58,9 +58,10 @@ __device__ __forceinline__ void split3(const float4 v, uint2& hi, uint2& mid, ui
 //           backward kernel's fc shrinks to its own half (one fc matrix per kernel: the 24 VGPRs that still fit beside the GRU's 144);
 //   MODE 2  intra-band BACKWARD scan: y(p) = x(p) + LN(pf(p) + W_fc[:, 64:128] hb(p) + b);
 //   MODE 1  inter-band scan (state carried): y(s) = x(s) + LN(W_fc h'(s) + b).
-// The fc product of step s - 1 rides on the h operand of step s (the same limb registers); MODE 0 stores it from the D layout (a float4 of
-// four consecutive channels per lane), MODES 1 / 2 pass it through an LDS tile to the row-contiguous lanes, which hold the residual x and
-// normalise one step later (16 lanes x 4 values = one 64-channel row: statistics are two DPP butterflies) -- output lags by two steps.
+// The fc product of step s - 1 rides on the h operand of step s (the same limb registers) and passes through an LDS tile to the
+// row-contiguous lanes, which store it (MODE 0; laid out like x) or, holding the residual x, normalise it first (MODES 1 / 2: 16 lanes x
+// 4 values = one 64-channel row, statistics are two DPP butterflies) -- one 16-byte store per lane and step, whole 256-byte rows per 16
+// lanes; output lags by two steps.
 struct Gru64LArgs {
     Gru64Args g;            // MODE 0: g.out = pf; MODES 1, 2: g.out unused
     const uint4* wl;        // GRU limb fragments [dir][wave 4][mat 6][chunk 2][limb 3][lane 64]
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
     __shared__ __attribute__((aligned(16))) unsigned short Hp[2][3][16][72];
     __shared__ __attribute__((aligned(16))) unsigned short Xp[2][3][16][72];
     __shared__ __attribute__((aligned(16))) float Xs[EPI ? 4 : 1][EPI ? 16 : 1][EPI ? 68 : 4];     // residual x, fp32: x(s - 2) must outlive x(s + 1)'s staging
-    __shared__ __attribute__((aligned(16))) float Ys[EPI ? 2 : 1][EPI ? 16 : 1][EPI ? 68 : 4];
+    __shared__ __attribute__((aligned(16))) float Ys[2][16][68];
     __shared__ __attribute__((aligned(16))) float Lp[7][64];                                       // fc bias | ln gamma | ln beta | GRU biases r, z, in, hn
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int dir = MODE == 2 ? 1 : 0;
@@ -110,14 +111,13 @@ __global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
     const float* xbase = a.x + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
     const float* ebase = MODE == 2 ? ea.extra + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo : nullptr;
     float* ybase = EPI ? ea.y + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo : nullptr;
-    float* obase = MODE == 0 ? a.out + (long)hi0 * a.o_hi + (long)lo0 * a.o_lo : nullptr;
+    float* obase = MODE == 0 ? a.out + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo : nullptr;            // pf is laid out (and addressed) like x
     const int srow = 4 * w + q, scol = 4 * cl;
-    unsigned sx_off, o_off = 0; bool s_ok, o_ok;
+    unsigned sx_off; bool s_ok, o_ok;
     {
         int rs = row0 + srow; s_ok = rs < a.nrows; if (!s_ok) rs = a.nrows - 1;
         sx_off = (unsigned)((long)(rs / a.rdiv - hi0) * a.x_hi + (long)(rs % a.rdiv - lo0) * a.x_lo) + scol;
         int rc = row0 + cl; o_ok = rc < a.nrows; if (!o_ok) rc = a.nrows - 1;
-        if (MODE == 0) o_off = (unsigned)((long)(rc / a.rdiv - hi0) * a.o_hi + (long)(rc % a.rdiv - lo0) * a.o_lo) + u0;
     }
     float* hp = nullptr;
     float4 h_own = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
     float4 e_prev = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    constexpr int LAG = EPI ? 2 : 1;
+    constexpr int LAG = 2;
     for (int s = 0; s < n + LAG; ++s) {
         const int buf = s & 1;
         // ---- finalize step s - 2: LayerNorm + residual on the row-contiguous pieces, one 16-byte store per lane
@@ -159,6 +159,10 @@ __global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
             o.x = rv.x + d0 * inv * gg.x + bb.x; o.y = rv.y + d1 * inv * gg.y + bb.y;
             o.z = rv.z + d2 * inv * gg.z + bb.z; o.w = rv.w + d3 * inv * gg.w + bb.w;
             if (s_ok) *(float4*)((ybase + (long)pos_of(s - 2) * a.x_step) + sx_off) = o;
+        }
+        if (MODE == 0 && s >= 2) {        // pf(s - 2) out of the exchange tile: whole 256-byte rows per 16 lanes
+            const float4 yv = *(const float4*)&Ys[buf ^ 1][srow][scol];
+            if (s_ok) *(float4*)((obase + (long)pos_of(s - 2) * a.x_step) + sx_off) = yv;
         }
         // ---- loads for step s + 1 (and the pf tile of step s - 1: consumed by the finalize of the next iteration)
         const float4 xnext = *(const float4*)((xbase + (long)pos_of(s + 1) * a.x_step) + sx_off);
@@ -192,11 +196,7 @@ __global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
         uint2 l0, l1, l2;
         split3(hn, l0, l1, l2);
         *(uint2*)&Hp[buf][0][cl][u0] = l0; *(uint2*)&Hp[buf][1][cl][u0] = l1; *(uint2*)&Hp[buf][2][cl][u0] = l2;
-        if (MODE == 0) {
-            if (s >= 1 && o_ok) *(float4*)((obase + (long)pos_of(s - 1) * a.o_step) + o_off) = make_float4(ay[0], ay[1], ay[2], ay[3]);
-        } else {
-            *(float4*)&Ys[buf][cl][u0] = make_float4(ay[0], ay[1], ay[2], ay[3]);     // fc(h'(s - 1)): read by the finalize of iteration s + 1
-        }
+        *(float4*)&Ys[buf][cl][u0] = make_float4(ay[0], ay[1], ay[2], ay[3]);         // fc(h'(s - 1)): read by the finalize / store of iteration s + 1
         __builtin_amdgcn_sched_barrier(0);
         split3(xnext, l0, l1, l2);
         *(uint2*)&Xp[buf ^ 1][0][srow][scol] = l0; *(uint2*)&Xp[buf ^ 1][1][srow][scol] = l1; *(uint2*)&Xp[buf ^ 1][2][srow][scol] = l2;

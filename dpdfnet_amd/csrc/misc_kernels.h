@@ -339,7 +339,7 @@ __global__ void df_apply_kernel(DfApplyArgs a) {
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
             float2 s = *(const float2*)(xb + n * fs);
-            float cr = c[2 * n], ci = c[2 * n + 1];
+            const float cr = ld_agent(c + 2 * n), ci = ld_agent(c + 2 * n + 1);
             rr += s.x * cr; ii += s.y * ci; ri += s.x * ci; ir += s.y * cr;
         }
         re = rr - ii; im = ri + ir;
@@ -409,7 +409,7 @@ __global__ void mask_df_kernel(MaskDfArgs a) {
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
             const float2 s = tap(n);
-            const float cr = c[2 * n], ci = c[2 * n + 1];
+            const float cr = ld_agent(c + 2 * n), ci = ld_agent(c + 2 * n + 1);
             rr += s.x * cr; ii += s.y * ci; ri += s.x * ci; ir += s.y * cr;
         }
         re = rr - ii; im = ri + ir;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
             for (long i = tid; i < fsz; i += 256) {
                 int n = (int)(i / (2 * a.D)); int rem = (int)(i - (long)n * 2 * a.D);
                 int f = rem >> 1, p = rem & 1;                               // state index = (n*D + f)*2 + p
-                if (a.do_export) sp[i] = tp[(long)f * 10 + 2 * n + p]; else tp[(long)f * 10 + 2 * n + p] = sp[i];
+                if (a.do_export) sp[i] = ld_agent(tp + (long)f * 10 + 2 * n + p); else tp[(long)f * 10 + 2 * n + p] = sp[i];
             }
         }
     }

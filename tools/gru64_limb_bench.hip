@@ -17,6 +17,17 @@
 #include "../dpdfnet_amd/csrc/gru_scan.h"
 #include "../dpdfnet_amd/csrc/gru_limb.h"
 
+__global__ __launch_bounds__(256, 1) void cotenant_kernel(float* junk, int iters) {
+    __shared__ float big[33000];                        // 132 KB: one workgroup per CU, nothing beside it
+    for (int i = threadIdx.x; i < 33000; i += 256) big[i] = i;
+    __syncthreads();
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        acc += big[(threadIdx.x * 17 + it * 31) % 33000] + __hip_atomic_load(junk + (blockIdx.x * 256 + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
+    junk[blockIdx.x * 256 + threadIdx.x] = acc * 1e-30f;
+}
 static unsigned short bf16_rne(float x) {
     unsigned u; memcpy(&u, &x, 4);
     u += 0x7fffu + ((u >> 16) & 1u);
@@ -126,6 +137,27 @@ int main() {
         if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
         printf("intra forward : fp32 %.3f ms   limbs %.3f ms   %.2f x\nintra backward: fp32 %.3f ms   limbs %.3f ms   %.2f x\n", t_f, u_f, t_f / u_f, t_b, u_b, t_b / u_b);
         cmp("intra block output y", y1, y2, (size_t)4096 * Fp * 64);
+        // the same pair beside a co-tenant on another stream (64 workgroups that take a whole CU each: 132 KB of LDS, spinning on memory):
+        // results must be bit-identical to the run alone
+        std::vector<float> ref(nx), got(nx);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(ref.data(), y2, nx * 4, hipMemcpyDeviceToHost);
+        hipStream_t s1, s2; (void)hipStreamCreate(&s1); (void)hipStreamCreate(&s2);
+        float* junk; (void)hipMalloc(&junk, 64 * 256 * 4);
+        int nbad_total = 0;
+        for (int rep = 0; rep < 20; ++rep) {
+            (void)hipMemsetAsync(y2, 0, nx * 4, s1); (void)hipMemsetAsync(pf, 0, nx * 4, s1);
+            hipLaunchKernelGGL(cotenant_kernel, dim3(64), dim3(256), 0, s2, junk, 3000 + 500 * rep);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_l3_kernel<0>), dim3(rows / 16), dim3(256), 0, s1, l0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gru64_l3_kernel<2>), dim3(rows / 16), dim3(256), 0, s1, l2);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(got.data(), y2, nx * 4, hipMemcpyDeviceToHost);
+            size_t nbad = 0, first = 0;
+            for (size_t i = 0; i < nx; ++i) if (got[i] != ref[i]) { if (!nbad) first = i; ++nbad; }
+            if (nbad) printf("  rep %d beside a co-tenant: %zu values differ from the run alone (first at row %zu pos %zu ch %zu)\n", rep, nbad, first / (Fp * 64), first / 64 % Fp, first % 64);
+            nbad_total += nbad != 0;
+        }
+        printf("  intra pair beside a co-tenant: %d of 20 runs differ from the run alone\n", nbad_total);
     }
     // ---- inter-band: rows = (clip, band position), steps = frames, carried state
     {
