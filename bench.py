@@ -40,6 +40,8 @@ MODEL, SR, NB = "dpdfnet4", 16000, 4
 CLIP_SECONDS = 10.0
 WEIGHT_SEED = 20260417
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # ... dense bf16 peak (~2.5 PF; the guide measured >= 2382): what the limb kernels' MFMAs are priced against
+LIMB_TERMS = 6                         # bf16 MFMAs per fp32 product term in gru_limb.h (3 x 3 limbs, the three products below 2^-24 dropped)
 GRU64_FLOP_PER_ROW_STEP = 2 * 3 * 64 * (64 + 64)   # r,z,n gates x 64 units x (W_ih x + W_hh h), MAC = 2 FLOP
 FLOP_PER_FRAME = 45.18e6               # algorithmic FLOP / frame, dpdfnet4
 # SURVEY.md 8(d), measured with forward hooks on the reference modules: algorithmic MFLOP / frame of every registry model
@@ -444,7 +446,7 @@ def other_configs(only=None) -> dict:
     if only in ("offline2", "offline8"):
         nb = int(only[-1])
         fps, ms, rec = offline(nb, 256, 3)
-        return {"frames_per_s": round(fps), "ms_per_step": round(ms, 2), "whole_path_frac": mfma(fps, SR, nb), "recovery_count": rec}
+        return {"frames_per_s": round(fps), "ms_per_step": round(ms, 2), "whole_path_over_fp32_peak": mfma(fps, SR, nb), "recovery_count": rec}
     if only == "offline48_2":                                                  # dpdfnet2_48khz_hr, 256 clips x 10 s (the 48 kHz family offline)
         n48 = int(CLIP_SECONDS * 48000)
         m = backend.HipModel(48000, 2, synth_blob(backend.manifest(48000, 2), WEIGHT_SEED), device=torch.cuda.current_device())
@@ -458,7 +460,7 @@ def other_configs(only=None) -> dict:
         dt = (time.perf_counter() - t0) / 3
         fps = 256 * m.num_frames(n48) / dt
         rec = m.recovery_count; m.close()
-        return {"frames_per_s": round(fps), "ms_per_step": round(1e3 * dt, 2), "whole_path_frac": mfma(fps, 48000, 2), "recovery_count": rec}
+        return {"frames_per_s": round(fps), "ms_per_step": round(1e3 * dt, 2), "whole_path_over_fp32_peak": mfma(fps, 48000, 2), "recovery_count": rec}
     if only == "public_streams48":
         return public_streams("dpdfnet8_48khz_hr", 48000, 64)
     if only is not None:
@@ -1038,6 +1040,17 @@ def main() -> None:
         iso_prof = model.profile_report()
         model.profile(False)
         model.set_overlap(args.overlap if args.overlap >= 0 else 27)
+    # the same pipelined step with the fp32-MFMA GRU-64 kernels of gru_scan.h (the round-4 engine) instead of the limb kernels: A/B on the line
+    fp32_kernels = None
+    if rank == 0 and not args.no_isolated:
+        model.set_option("gru64_limbs", 0)
+        step(); sync()
+        t1 = time.perf_counter()
+        for i in range(2):
+            step(i)
+        sync(); ms32 = 1e3 * (time.perf_counter() - t1) / 2
+        model.set_option("gru64_limbs", 3)
+        fp32_kernels = {"ms_per_step": ms32, "value": B * T / (ms32 * 1e-3)}
 
     mark("per_kernel_event_passes")
     # ---- SURVEY 8(d)'s full metric: the same steps INCLUDING H2D of the noisy PCM and D2H of the enhanced PCM ----
@@ -1082,12 +1095,23 @@ def main() -> None:
         #   gru64_epi_kernel<1>    inter-band + fc_inter + LN              49 152 + 2*64*64 FLOP
         # rows*steps per step of the bench: NB blocks x B*T frames x (48 DF + 8 ERB) band positions.
         rs = NB * (B * T) * (48 + 8)
+        # Round 5: the same three launches run on bf16 LIMBS by default (gru_limb.h, option gru64_limbs): every fp32 product is formed from
+        # 3 x 3 bf16 limbs, six v_mfma_f32_16x16x32_bf16 per term, fp32 accumulation -- same algorithmic (fp32) FLOPs, six times as
+        # many matrix FLOPs issued, on a pipe with 16 x the fp32 rate.  `flop` below is the ALGORITHMIC fp32 count per (row, step);
+        # `issued` = flop x 6 is what the bf16 pipe executes and what the roofline prices against the bf16 peak.
+        #   gru64_l3_kernel<0>     intra-band forward + its half of fc_intra        49 152 + 2*64*64
+        #   gru64_l3_kernel<2>     intra-band backward + its half of fc_intra + LN  49 152 + 2*64*64
+        #   gru64_l3_kernel<1>     inter-band + fc_inter + LN                       49 152 + 2*64*64
         fam = {
             "gru64_scan_kernel": GRU64_FLOP_PER_ROW_STEP * (1 if fused else 3),
             "gru64_epi_kernel<2>": GRU64_FLOP_PER_ROW_STEP + 2 * 64 * 128,
             "gru64_epi_kernel<1>": GRU64_FLOP_PER_ROW_STEP + 2 * 64 * 64,
             "gru64_scan_gi_kernel": GRU64_FLOP_PER_ROW_STEP,      # small --clips only: hoisted input GEMM + h-part scan
+            "gru64_l3_kernel<0>": GRU64_FLOP_PER_ROW_STEP + 2 * 64 * 64,
+            "gru64_l3_kernel<2>": GRU64_FLOP_PER_ROW_STEP + 2 * 64 * 64,
+            "gru64_l3_kernel<1>": GRU64_FLOP_PER_ROW_STEP + 2 * 64 * 64,
         }
+        is_limb = lambda k: k.startswith("gru64_l3_kernel")
 
         def kernel_stats(p, nsteps):
             out_ = {}
@@ -1096,14 +1120,21 @@ def main() -> None:
                 ms_ = sum(v[0] for v in sel.values()); n_ = sum(v[1] for v in sel.values())
                 if n_:
                     fl = flop_rs * rs * nsteps
+                    mult = LIMB_TERMS if is_limb(kname) else 1
                     out_[kname] = {"ms_total": ms_, "launches": n_, "avg_launch_ms": ms_ / n_,
-                                   "flop_per_launch": fl / n_, "tflops": fl / (ms_ * 1e-3) / 1e12}
+                                   "flop_per_launch": fl / n_, "tflops": fl / (ms_ * 1e-3) / 1e12,
+                                   "issued_flop_per_launch": mult * fl / n_, "issued_tflops": mult * fl / (ms_ * 1e-3) / 1e12,
+                                   "peak": BF16_MFMA_PEAK_TFLOPS if is_limb(kname) else FP32_MFMA_PEAK_TFLOPS}
             return out_
 
         line = {
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 values, fp32 accumulation everywhere.  The GRU-64 recurrences (85 % of the FLOPs) form each fp32 product from three bf16 limbs "
+                          "per operand -- an exact split, v = hi + mid + lo -- as six bf16 MFMAs with fp32 accumulate (gru_limb.h): fp32-exact products, closer to a "
+                          "float64 recurrence than the fp32-MFMA kernels (tools/gru64_limb_bench.hip); `value_fp32_mfma_kernels` is the same step with those "
+                          "kernels instead (option gru64_limbs = 0)",
             "config": {"workload": f"{MODEL} @16 kHz, {B} clips x {CLIP_SECONDS:g} s per GPU (T={T} frames/clip), "
                                    "seeded synthetic weights + clips, inputs/outputs resident in HBM",
                        "clips_per_gpu": B, "frames_per_clip": T, "chunk_frames": args.chunk,
@@ -1114,6 +1145,9 @@ def main() -> None:
         # words the metric with the H2D / D2H of the PCM inside: that figure is `value_incl_pcie` (measured below in the
         # same run); `value_hbm_resident` repeats `value` under an explicit name.
         line["value_hbm_resident"] = value
+        if fp32_kernels:
+            line["value_fp32_mfma_kernels"] = fp32_kernels["value"]
+            line["ms_per_step_fp32_mfma_kernels"] = fp32_kernels["ms_per_step"]
         if not args.no_parity and timed_out_host:
             line["parity"] = parity_vs_oracle(blob, wav_host, timed_out_host, parity_slots)
             mark("parity_vs_oracle")
@@ -1130,12 +1164,13 @@ def main() -> None:
                                  "collective_error": collective_error, "gathered_matches_rank_outputs": gather_check,
                                  "gathered_shape": list(gathered.shape) if gathered is not None else None}
         ks = kernel_stats(prof, psteps) if prof else {}
-        dom = next((k for k in ("gru64_epi_kernel<2>", "gru64_scan_kernel", "gru64_scan_gi_kernel") if k in ks), None)
+        dom = next((k for k in ("gru64_l3_kernel<2>", "gru64_epi_kernel<2>", "gru64_scan_kernel", "gru64_scan_gi_kernel") if k in ks), None)
         if dom is not None:
             if iso_prof is not None:
                 kernel_stats_iso = kernel_stats(iso_prof, 1)
             ms, calls = ks[dom]["ms_total"], ks[dom]["launches"]
-            achieved = ks[dom]["tflops"]
+            achieved = ks[dom]["issued_tflops"]
+            peak = ks[dom]["peak"]
             fam_ms = sum(v["ms_total"] for v in ks.values())
             fam_flop = sum(v["flop_per_launch"] * v["launches"] for v in ks.values())
             # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
@@ -1150,12 +1185,16 @@ def main() -> None:
                 pass
             # algorithmic bytes: x row in, (hf row in,) y row out = 256 B each per (row, step)
             alg_bytes = {"gru64_scan_kernel": 2 * 256, "gru64_epi_kernel<2>": 3 * 256, "gru64_epi_kernel<1>": 2 * 256,
-                         "gru64_scan_gi_kernel": 256 + 768 + 256}[dom]
+                         "gru64_scan_gi_kernel": 256 + 768 + 256, "gru64_l3_kernel<2>": 3 * 256}[dom]
             serial_mode = args.overlap == 0
             roofline = {
                 "bound": "mfma", "kernel": dom + " (all launches, DF + ERB branch)",
-                "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
+                "accounting": (f"limb kernel: achieved = {LIMB_TERMS} x the algorithmic fp32 FLOPs per launch (the bf16 MFMAs actually issued) / launch duration, "
+                               f"against the dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:g}; `useful_fp32_tflops` is the algorithmic rate, which the fp32 pipe "
+                               f"({FP32_MFMA_PEAK_TFLOPS} peak) could not reach" if is_limb(dom) else "fp32 MFMA kernel against the fp32 MFMA peak"),
+                "useful_fp32_tflops": ks[dom]["tflops"],
                 "algorithmic_bytes_per_launch": alg_bytes * rs * psteps / calls,
                 "avg_launch_ms": ms / calls, "launches": calls, "flop_per_launch": ks[dom]["flop_per_launch"],
                 "timing": f"HIP events on the launching stream around every launch of {psteps} steps run right after the timed "
@@ -1166,27 +1205,31 @@ def main() -> None:
                                "--no-pcie" + (" --overlap 0`" if serial_mode else "`") + " -- every launch of that run has this execution "
                                "shape, so the CSV's AverageNs for the kernel is this avg_launch_ms (profiles/README.md)",
                 "gru64_family": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "launches": v["launches"],
-                                     "tflops": round(v["tflops"], 1)} for k, v in ks.items()},
+                                     "useful_fp32_tflops": round(v["tflops"], 1), "issued_tflops": round(v["issued_tflops"], 1),
+                                     "frac_of_its_pipe_peak": round(v["issued_tflops"] / v["peak"], 3)} for k, v in ks.items()},
                 "gru64_family_tflops": fam_flop / (fam_ms * 1e-3) / 1e12 if fam_ms else None,
-                "whole_path_frac": value * FLOP_PER_FRAME / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
+                "whole_path_fp32_equiv_tflops": value * FLOP_PER_FRAME / 1e12 / world,
+                "whole_path_over_fp32_peak": value * FLOP_PER_FRAME / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
+                "whole_path_note": "frames/s x algorithmic fp32 FLOP per frame (SURVEY 8(d)) over the fp32 MFMA peak -- north_star's yardstick; with the "
+                                   "GRU-64 products on the bf16 pipe it is no longer an upper bound of 1",
                 # the three GRU-64 kernels' algorithmic FLOPs over the WALL time of a step: a lower bound on what
                 # they achieve while sharing the chip (unlike per-launch durations it only goes up when throughput goes up)
-                "gru64_family_wallclock_frac": fam_flop / psteps / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                "gru64_family_wallclock_over_fp32_peak": fam_flop / psteps / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                 "per_class_ms_per_step": {k: round(v[0] / psteps, 3) for k, v in sorted(prof.items())},
             }
             if kernel_stats_iso is not None:
                 ki = kernel_stats_iso
-                roofline["frac_isolated"] = round(ki[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4) if dom in ki else None
+                roofline["frac_isolated"] = round(ki[dom]["issued_tflops"] / ki[dom]["peak"], 4) if dom in ki else None
                 roofline["frac_note"] = ("`frac` divides by the launch duration seen INSIDE the 4-stream pipeline, where the kernel "
                                          "shares the CUs with three other streams (faster pipeline => longer individual launches); "
                                          "`frac_isolated` is the same kernel, same launches, run back to back in the extra serial "
-                                         f"step (= {banked_trace('serial')}, the --overlap 0 run); `whole_path_frac` is "
+                                         f"step (= {banked_trace('serial')}, the --overlap 0 run); `whole_path_over_fp32_peak` is "
                                          "frames/s x FLOP/frame over the fp32 MFMA peak")
                 roofline["roofline_isolated"] = {
                     "note": "one extra step AFTER the timed region with the stream pipeline switched off (kernels back to back)",
                     "ms_per_step": iso_ms,
-                    "kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "tflops": round(v["tflops"], 1),
-                                    "frac": round(v["tflops"] / FP32_MFMA_PEAK_TFLOPS, 3)} for k, v in ki.items()},
+                    "kernels": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "useful_fp32_tflops": round(v["tflops"], 1),
+                                    "issued_tflops": round(v["issued_tflops"], 1), "frac": round(v["issued_tflops"] / v["peak"], 3)} for k, v in ki.items()},
                     "per_class_ms_per_step": {k: round(v[0], 3) for k, v in sorted(iso_prof.items())},
                 }
             line["roofline"] = roofline
