@@ -256,7 +256,7 @@ def public_api_worker(B: int, steps: int, ref_path: str) -> None:
     res = {"value_public_api": B * T / dt, "ms_per_call": 1e3 * dt, "calls": steps,
            "call": f'dpdfnet_amd.enhance_batch(<list of {B} float32 arrays x {N} samples>, {SR}, model="{MODEL}")',
            "process": "own process (bench.py --public-api-only): a second engine handle in the bench process shares hardware queues "
-                      "with the first one's streams and measures 4-5 % slower (DESIGN.md section 3b)",
+                      "with the first one's streams and measures 4-5 % slower (docs/HISTORY.md section 3b)",
            "finite_output": bool(all(np.isfinite(o).all() for o in outs)),
            "max_abs_diff_vs_hbm_resident_output": (max(float(np.abs(outs[int(b)] - ref[b]).max()) for b in ref) if ref else None)}
     print("PUBLIC_API " + json.dumps(res), flush=True)
@@ -415,7 +415,7 @@ def other_configs(only=None) -> dict:
         rec = m.recovery_count
         st.close(); m.close()
         d = backend.query_dims(sr_, nb_)
-        # Latency model of a hop: the two branches run side by side, each a chain of nb x (F' dependent
+        # Latency model of a hop (docs/HISTORY.md section 4): the two branches run side by side, each a chain of nb x (F' dependent
         # GRU-64 steps + one glue launch); the DF branch (F' = 48) is the longer one.  Measured minima on this chip
         # (tools/scan4_bench.hip, rocprofv3 traces of single hops, profiles/r*_stream_hop_*): 0.41 us per 4-row scan step (64 x
         # 8.4-cycle v_mfma_f32_4x4x1 + one LDS round trip + the gate chain; 0.55 until round 4), ~1.5 us per dependent kernel boundary.
@@ -434,7 +434,7 @@ def other_configs(only=None) -> dict:
                 **({"parity_sparse": sparse} if sparse else {})}
 
     # Every side configuration is measured in a process of its own (`bench.py --side-config <name>`): engine handles created
-    # one after the other in ONE process end up sharing hardware queues (section 3b of DESIGN.md) -- the fifth handle of the bench
+    # one after the other in ONE process end up sharing hardware queues (docs/HISTORY.md section 3b) -- the fifth handle of the bench
     # process measured dpdfnet8 at 194.7 ms per step, a fresh process 187.0.
     if only == "one_clip":
         fps, ms, rec = offline(NB, 1, 5)

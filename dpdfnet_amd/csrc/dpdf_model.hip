@@ -375,7 +375,7 @@ struct dpdf_model {
     // bit 0: stage 2 on its own stream; bit 1: ERB encoder branch on its own stream; bit 3: DF decoder beside the ERB decoder
     // inside stage 2 (needs bit 0); bit 4: GRU-256 scans on 8 / 16 workgroups per tile for launches of few tiles.
     // 0 = everything serial on the main stream (A/B timing).  (Bits 2 and 5 -- two lanes, five-stream sub-stage pipeline --
-    // were measured slower and removed: DESIGN.md section 7; they are ignored.)
+    // were measured slower and removed: docs/HISTORY.md section 7; they are ignored.)
     int overlap = 27;
     int inter_fuse_rows = 1024;        // inter-band scan: fused form (fc + LN inside the scan) from this many (stream, band) rows on, hoisted-input form below
     int scan4_max_wgs = 512;           // hoisted-input GRU-64 scans on 4-row tiles (gru_scan4.h) while the launch has at most this many workgroups (0 = never)
@@ -644,7 +644,7 @@ GruW64 build_gru64(Arena& A, const Blob& B, const std::vector<std::pair<std::str
     // The exponent scales of the gate non-linearities are folded into the packed weights, so that the accumulators
     // come out of the MFMAs ready for v_exp_f32 (2^x): sigma(a) = 1/(1 + 2^(-a log2 e)) for r and z, and
     // tanh(t) = 2/(1 + 2^(-2 t log2 e)) - 1 for the candidate (common.h gru64_cell).  VALU instructions and fp32 MFMAs
-    // share the SIMD datapath, so the four multiplies per hidden unit this removes are MFMA time.
+    // share the SIMD datapath (docs/HISTORY.md section 3), so the four multiplies per hidden unit this removes are MFMA time.
     const float gate_scale[3] = {-1.4426950408889634f, -1.4426950408889634f, -2.8853900817779268f};
     std::vector<float> frag((size_t)g.ndirs * 4 * 2 * 3 * 16 * 64), bias((size_t)g.ndirs * 256);
     for (int d = 0; d < g.ndirs; ++d) {
@@ -1834,7 +1834,7 @@ std::vector<int> chunk_schedule(const dpdf_model* m, int B, int T) {
     }
     // (Measured and dropped: ending on a quarter-size chunk to shorten the pipeline drain -- 115.0 vs 114.6 ms/step; splitting
     // the batch over two independent lanes -- 180 vs 120 ms/step; stage 2 as a five-stream pipeline of sub-stages across
-    // chunks for small batches -- 13.3 vs 10.3 ms for one clip: DESIGN.md section 7.)
+    // chunks for small batches -- 13.3 vs 10.3 ms for one clip: docs/HISTORY.md section 7.)
     std::vector<int> sizes;
     for (int rem = T; rem > 0; rem -= std::min(chunk, rem)) sizes.push_back(std::min(chunk, rem));
     // Pipeline drain: stage 2 of the LAST chunk has no stage 1 to run under -- its latency-bound GRU-256 scans (three deep,

@@ -8,7 +8,7 @@
 // workgroup per 16-row tile does them back to back: A tile [16][K1] -> fc on the matrix cores -> bias -> LayerNorm in the
 // row-contiguous layout (DPP row reductions) -> + residual -> y (stored, and kept in LDS as the next A operand) ->
 // gi = y . W_ih^T + b for NG groups of 64 columns (3: inter-band cell, 6: both directions of the intra-band GRU).
-// Two launches per block fewer on the critical chain (64 streams x 48 kHz dpdfnet8, one hop: 1.34 -> see DESIGN.md).
+// Two launches per block fewer on the critical chain (64 streams x 48 kHz dpdfnet8, one hop: 1.34 -> docs/HISTORY.md).
 // Operand packings are the ones gemm_rows uses (pack_frag: [k-chunk][col tile][kb][lane]); results equal the two-launch
 // form to rounding (the same MFMA order per output).
 #pragma once

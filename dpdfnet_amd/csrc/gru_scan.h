@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256, (EPI == 1 && EPI1_WF_LDS) ? 3 : 2) void gru64_
     float* ybase = ea.y + (long)hi0 * a.x_hi + (long)lo0 * a.x_lo;
     const int srow = 4 * w + q, scol = 4 * cl;
     // non-negative 32-bit lane offset: every global address is (wave-uniform base advanced on the scalar unit) + sx_off,
-    // so the step costs no 64-bit VALU address arithmetic -- VALU cycles come straight out of the MFMA budget
+    // so the step costs no 64-bit VALU address arithmetic -- VALU cycles come straight out of the MFMA budget (docs/HISTORY.md 3)
     unsigned sx_off; bool so_ok;
     {
         int rs = row0 + srow;

@@ -218,7 +218,7 @@ int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
  * host-pointer batch calls pipelined over time slices), "host_copy_threads" (4), "host_prefault" (1: a helper thread populates
  * the caller's output rows while the first chunk computes), "chunk_io" (default 0; 1: per-chunk STFT / iSTFT also for
  * device-pointer calls -- measured, no gain).  Unknown name -> DPDF_E_INVALID.  (Removed after measurement, see
- * DESIGN.md section 7 and tools/experimental/: "gru64_bf16x3", "gru256_pair", "gru256_chain", "pipe_chunk".) */
+ * docs/HISTORY.md section 7 and tools/experimental/: "gru64_bf16x3", "gru256_pair", "gru256_chain", "pipe_chunk".) */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);
 
 /* Rational polyphase resampler on the device, for `ensure_sample_rate` when the caller's rate differs from the

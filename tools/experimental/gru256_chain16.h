@@ -1,4 +1,4 @@
-// Measured and NOT shipped: kept out of the library build.  Was part of csrc/gru_stack.h up to round 2
+// Measured and NOT shipped (docs/HISTORY.md section 7): kept out of the library build.  Was part of csrc/gru_stack.h up to round 2
 // (launch code: git history of dpdf_model.hip, run_gru256_chain / "gru256_chain").
 // ---------------------------------------------------------------------------------------------
 // gru256_chain16_kernel: ALL FIVE GRUCell(256) layers of stage 2 as one wavefront launch (<= 2 tiles).

@@ -1,4 +1,4 @@
-// Measured and NOT shipped: kept out of the library build.  Was part of csrc/gru_scan.h up to round 2;
+// Measured and NOT shipped (docs/HISTORY.md section 7): kept out of the library build.  Was part of csrc/gru_scan.h up to round 2;
 // include it behind gru_scan.h to rebuild the experiment (launch code: git history of dpdf_model.hip, run_gru256 / "gru256_pair").
 // ---------------------------------------------------------------------------------------------
 // gru256_ring_kernel<NT>: the 4-workgroup cluster scan with NT 16-row tiles per cluster, round-robin -- the form for

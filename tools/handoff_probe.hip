@@ -6,7 +6,7 @@
 // (c) the same with the payload published as {epoch, value} granules (sc1 write-through stores, relaxed agent-scope polling loads: the
 //     GRU-256 cluster scans' protocol) from every workgroup to its ring neighbour -- no fences, no counter: us per phase
 // (d) see flagged_kernel.
-// The decision they inform: a persistent DPRNN-branch kernel replaces 2 nb kernel boundaries + entry phases
+// The decision they inform (docs/HISTORY.md section 7): a persistent DPRNN-branch kernel replaces 2 nb kernel boundaries + entry phases
 // by 2 nb in-kernel hand-offs of (b) or (c).
 #include <hip/hip_runtime.h>
 #include <cstdio>
