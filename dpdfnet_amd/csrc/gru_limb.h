@@ -48,6 +48,9 @@ __device__ __forceinline__ void split3(const float4 v, uint2& hi, uint2& mid, ui
     lo.x = pk_bf16(r0, r1); lo.y = pk_bf16(r2, r3);
 }
 
+#ifndef GRU64L_VAR
+#define GRU64L_VAR 0      // tools/gru64_limb_bench.hip A/B switches
+#endif
 // the six limb pairs of a product, smallest first: (weight limb, activation limb)
 #define GRU64L_TERMS(F) F(2, 0) F(0, 2) F(1, 1) F(1, 0) F(0, 1) F(0, 0)
 
@@ -168,7 +171,9 @@ __global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
         const float4 xnext = *(const float4*)((xbase + (long)pos_of(s + 1) * a.x_step) + sx_off);
         float4 e_ld = xnext;
         if (MODE == 2) e_ld = *(const float4*)((ebase + (long)pos_of(s - 1) * a.x_step) + sx_off);
+#if !(GRU64L_VAR & 1)
         __builtin_amdgcn_sched_barrier(0);
+#endif
         uint4 xb[2][3], hb[2][3];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -197,7 +202,9 @@ __global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
         split3(hn, l0, l1, l2);
         *(uint2*)&Hp[buf][0][cl][u0] = l0; *(uint2*)&Hp[buf][1][cl][u0] = l1; *(uint2*)&Hp[buf][2][cl][u0] = l2;
         *(float4*)&Ys[buf][cl][u0] = make_float4(ay[0], ay[1], ay[2], ay[3]);         // fc(h'(s - 1)): read by the finalize / store of iteration s + 1
+#if !(GRU64L_VAR & 2)
         __builtin_amdgcn_sched_barrier(0);
+#endif
         split3(xnext, l0, l1, l2);
         *(uint2*)&Xp[buf ^ 1][0][srow][scol] = l0; *(uint2*)&Xp[buf ^ 1][1][srow][scol] = l1; *(uint2*)&Xp[buf ^ 1][2][srow][scol] = l2;
         if (EPI) *(float4*)&Xs[(s + 1) & 3][srow][scol] = xnext;

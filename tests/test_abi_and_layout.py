@@ -141,3 +141,18 @@ def test_banked_profiles_are_of_this_build():
         # DPDF_STRICT_PROFILES=1 after banking, where a mismatch is an error
         pytest.skip(f"profiles/ is of an earlier build; changed since: {changed}")
     assert not changed, f"sources changed since profiles/ was collected (re-run tools/profile_round.sh + tools/bank_profiles.sh): {changed}"
+
+
+def test_limb_kernel_microbenchmark_builds_for_gfx950(tmp_path):
+    """tools/gru64_limb_bench.hip (the limb GRU-64 kernels against the fp32-MFMA kernels and a float64 recurrence) and the bf16 MFMA /
+    VALU overlap probe stay buildable: DESIGN.md section 3a quotes their output."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("no hipcc")
+    for src in ("tools/gru64_limb_bench.hip", "tools/mfma_bf16_valu_overlap.hip"):
+        out = tmp_path / (Path(src).stem + ".o")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", str(ROOT / src), "-o", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert out.stat().st_size > 10000
