@@ -38,11 +38,12 @@ __device__ __forceinline__ float gru64_cell(float ar, float az, float axn, float
     return __builtin_fmaf(z, h - n, n);
 }
 
-// A load that is coherent across the chip's eight XCDs (agent scope: not served from a stale line of this XCD's L2).  For tensors whose
-// 128-byte lines are written piecewise by workgroups on DIFFERENT XCDs -- the deep-filter taps: df_out's groups write 240-byte pieces of a
-// coefs row from one workgroup each -- a writer's L2 fills the rest of such a line with the OLD contents and keeps that copy; a reader on
-// the same XCD in the next kernel gets the neighbour's bytes stale (seen as single wrong low-band frames, a few per thousand, in
-// multi-chunk batches once the stage-1 kernels got faster; same-process A/B: 19-59 clips of 256 per run -> 0).
+// An agent-scope (device-coherent, L1-bypassing) load.  Used for the deep-filter taps in df_apply / mask_df / the FIFO export: with the
+// faster stage 1 of round 5, multi-chunk batches showed single wrong low-band frames in a few clips per run (never the same twice; taps,
+// their inputs and every other stage-2 tensor correct in per-row checksums taken at the end of the chunk's stage 2, the deep-filtered rows
+// wrong).  Reading the taps this way removed them in same-box A/Bs (19-59 bad clips of 256 per run -> 0 in every run since) -- the MECHANISM
+// is not established: tools/xcd_line_sharing_probe.hip (two XCDs writing one line piecewise, read by the next kernel) shows no stale
+// value, nor did a debug build comparing plain and agent-scope loads of the same tap inside df_apply.  DESIGN.md section 6.
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // K index supplied by lane-quad q (= lane>>4) for MFMA kb (0..3) of 16-wide K chunk c.
