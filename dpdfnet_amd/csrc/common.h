@@ -38,12 +38,14 @@ __device__ __forceinline__ float gru64_cell(float ar, float az, float axn, float
     return __builtin_fmaf(z, h - n, n);
 }
 
-// An agent-scope (device-coherent, L1-bypassing) load.  Used for the deep-filter taps in df_apply / mask_df / the FIFO export: with the
-// faster stage 1 of round 5, multi-chunk batches showed single wrong low-band frames in a few clips per run (never the same twice; taps,
-// their inputs and every other stage-2 tensor correct in per-row checksums taken at the end of the chunk's stage 2, the deep-filtered rows
-// wrong).  Reading the taps this way removed them in same-box A/Bs (19-59 bad clips of 256 per run -> 0 in every run since) -- the MECHANISM
-// is not established: tools/xcd_line_sharing_probe.hip (two XCDs writing one line piecewise, read by the next kernel) shows no stale
-// value, nor did a debug build comparing plain and agent-scope loads of the same tap inside df_apply.  DESIGN.md section 6.
+// An agent-scope, single-dword load.  Used for the deep-filter taps in df_apply / mask_df / the FIFO export: with the faster stage 1 of
+// round 5, multi-chunk batches showed single wrong low-band frames in a few clips per run (never the same twice) whenever df_apply read
+// its ten taps through the loads the compiler merges them into -- two UNDER-ALIGNED global_load_dwordx4 + one dwordx2 (records of 40 bytes:
+// 8-byte aligned): 23-36 bad clips of 256 per run; with ten single-dword loads (volatile or agent-scope) none, in every run since.  What
+// it is not: stamps written behind df_out's rows show df_apply never ran ahead of them; per-row checksums at the end of the chunk's stage 2
+// show taps, their inputs and every other tensor correct; probes of under-aligned vector loads on static buffers and on lines freshly
+// written piecewise from two XCDs (tools/misaligned_load_probe.hip, tools/xcd_line_sharing_probe.hip) return the right bytes.  The
+// mechanism is NOT established; DESIGN.md section 6.
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // K index supplied by lane-quad q (= lane>>4) for MFMA kb (0..3) of 16-wide K chunk c.

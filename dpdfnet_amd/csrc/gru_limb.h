@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
     if (a.hstate) {
         int rc = row0 + cl; if (rc >= a.nrows) rc = a.nrows - 1;
         hp = a.hstate + (long)(rc / a.rdiv) * a.h_hi + (long)(rc % a.rdiv) * a.h_lo + u0;
-        h_own = *(const float4*)hp;
+        h_own = make_float4(ld_agent(hp), ld_agent(hp + 1), ld_agent(hp + 2), ld_agent(hp + 3));      // (the state stride need not be a multiple of 16 bytes: no vector access)
     }
     const int n = a.nsteps;
     auto pos_of = [&](int s) { s = s < 0 ? 0 : (s < n ? s : n - 1); return dir ? n - 1 - s : s; };    // clamped: head and tail re-read a valid tile
@@ -211,5 +211,8 @@ __global__ __launch_bounds__(256, 2) void gru64_l3_kernel(Gru64LArgs ea) {
         e_prev = e_ld;
         __syncthreads();
     }
-    if (hp && o_ok) *(float4*)hp = h_own;
+    if (hp && o_ok) {
+        __hip_atomic_store(hp, h_own.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(hp + 1, h_own.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hp + 2, h_own.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(hp + 3, h_own.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
