@@ -1040,17 +1040,28 @@ def main() -> None:
         iso_prof = model.profile_report()
         model.profile(False)
         model.set_overlap(args.overlap if args.overlap >= 0 else 27)
-    # the same pipelined step with the fp32-MFMA GRU-64 kernels of gru_scan.h (the round-4 engine) instead of the limb kernels: A/B on the line
-    fp32_kernels = None
-    if rank == 0 and not args.no_isolated:
-        model.set_option("gru64_limbs", 0)
-        step(); sync()
-        t1 = time.perf_counter()
-        for i in range(2):
-            step(i)
-        sync(); ms32 = 1e3 * (time.perf_counter() - t1) / 2
+    # OPT-IN mode beside the headline (never `value`): the same pipelined steps with the GRU-64 throughput kernels on bf16 limbs
+    # (gru_limb.h, dpdf_set_option gru64_limbs = 3) -- its own timing, its own per-kernel pass, its own parity block
+    limb = None
+    if rank == 0 and not args.no_isolated and not args.no_fuse:
         model.set_option("gru64_limbs", 3)
-        fp32_kernels = {"ms_per_step": ms32, "value": B * T / (ms32 * 1e-3)}
+        step(); sync()
+        nl = max(1, min(args.steps, 3))
+        t1 = time.perf_counter()
+        for i in range(nl):
+            step(i)
+        sync(); ms_l = 1e3 * (time.perf_counter() - t1) / nl
+        limb_out = {b: outs[(nl - 1) & 1][b].cpu().numpy() for b in sorted({0, B // 2, B - 1})}
+        model.profile(True)
+        step(); sync()
+        limb_prof = model.profile_report()
+        model.profile(False)
+        model.set_overlap(0); model.profile(True)
+        step(); sync()
+        limb_iso = model.profile_report()
+        model.profile(False); model.set_overlap(args.overlap if args.overlap >= 0 else 27)
+        model.set_option("gru64_limbs", 0)
+        limb = {"ms_per_step": ms_l, "value": B * T / (ms_l * 1e-3), "out": limb_out, "prof": limb_prof, "iso": limb_iso}
 
     mark("per_kernel_event_passes")
     # ---- SURVEY 8(d)'s full metric: the same steps INCLUDING H2D of the noisy PCM and D2H of the enhanced PCM ----
@@ -1095,7 +1106,7 @@ def main() -> None:
         #   gru64_epi_kernel<1>    inter-band + fc_inter + LN              49 152 + 2*64*64 FLOP
         # rows*steps per step of the bench: NB blocks x B*T frames x (48 DF + 8 ERB) band positions.
         rs = NB * (B * T) * (48 + 8)
-        # Round 5: the same three launches run on bf16 LIMBS by default (gru_limb.h, option gru64_limbs): every fp32 product is formed from
+        # Round 5, OPT-IN (limb_kernels_opt_in below): the same three launches on bf16 LIMBS (gru_limb.h, option gru64_limbs): every fp32 product is formed from
         # 3 x 3 bf16 limbs, six v_mfma_f32_16x16x32_bf16 per term, fp32 accumulation -- same algorithmic (fp32) FLOPs, six times as
         # many matrix FLOPs issued, on a pipe with 16 x the fp32 rate.  `flop` below is the ALGORITHMIC fp32 count per (row, step);
         # `issued` = flop x 6 is what the bf16 pipe executes and what the roofline prices against the bf16 peak.
@@ -1131,10 +1142,6 @@ def main() -> None:
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 values, fp32 accumulation everywhere.  The GRU-64 recurrences (85 % of the FLOPs) form each fp32 product from three bf16 limbs "
-                          "per operand -- an exact split, v = hi + mid + lo -- as six bf16 MFMAs with fp32 accumulate (gru_limb.h): fp32-exact products, closer to a "
-                          "float64 recurrence than the fp32-MFMA kernels (tools/gru64_limb_bench.hip); `value_fp32_mfma_kernels` is the same step with those "
-                          "kernels instead (option gru64_limbs = 0)",
             "config": {"workload": f"{MODEL} @16 kHz, {B} clips x {CLIP_SECONDS:g} s per GPU (T={T} frames/clip), "
                                    "seeded synthetic weights + clips, inputs/outputs resident in HBM",
                        "clips_per_gpu": B, "frames_per_clip": T, "chunk_frames": args.chunk,
@@ -1145,9 +1152,6 @@ def main() -> None:
         # words the metric with the H2D / D2H of the PCM inside: that figure is `value_incl_pcie` (measured below in the
         # same run); `value_hbm_resident` repeats `value` under an explicit name.
         line["value_hbm_resident"] = value
-        if fp32_kernels:
-            line["value_fp32_mfma_kernels"] = fp32_kernels["value"]
-            line["ms_per_step_fp32_mfma_kernels"] = fp32_kernels["ms_per_step"]
         if not args.no_parity and timed_out_host:
             line["parity"] = parity_vs_oracle(blob, wav_host, timed_out_host, parity_slots)
             mark("parity_vs_oracle")
@@ -1233,6 +1237,29 @@ def main() -> None:
                     "per_class_ms_per_step": {k: round(v[0], 3) for k, v in sorted(iso_prof.items())},
                 }
             line["roofline"] = roofline
+            if limb is not None:
+                lk, li = kernel_stats(limb["prof"], 1), kernel_stats(limb["iso"], 1)
+                ld = "gru64_l3_kernel<2>"
+                lpar = parity_vs_oracle(blob, wav_host, limb["out"], sorted(limb["out"])) if (not args.no_parity and timed_out_host) else None
+                line["limb_kernels_opt_in"] = {
+                    "what": "NOT the headline: the same step with dpdf_set_option(gru64_limbs, 3) -- the three GRU-64 throughput launches of a DPRNN block form every "
+                            "fp32 product from three bf16 limbs per operand (v = hi + mid + lo exactly; six v_mfma_f32_16x16x32_bf16 per term, fp32 accumulate): gru_limb.h. "
+                            "fp32-exact products (closer to a float64 recurrence than the fp32-MFMA kernels: tools/gru64_limb_bench.hip), but another instruction mix than "
+                            "the reference's fp32 -- the headline `value`, `dtype` and `roofline` above are the fp32-MFMA kernels'",
+                    "value": limb["value"], "ms_per_step": limb["ms_per_step"], "speedup_over_headline": (dt / args.steps) / (limb["ms_per_step"] * 1e-3),
+                    "parity": lpar,
+                    "roofline": None if ld not in lk else {
+                        "bound": "mfma", "kernel": ld, "achieved": lk[ld]["issued_tflops"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": lk[ld]["issued_tflops"] / BF16_MFMA_PEAK_TFLOPS,
+                        "frac_isolated": (li[ld]["issued_tflops"] / BF16_MFMA_PEAK_TFLOPS) if ld in li else None,
+                        "useful_fp32_tflops": lk[ld]["tflops"], "useful_fp32_tflops_isolated": li[ld]["tflops"] if ld in li else None,
+                        "avg_launch_ms": lk[ld]["avg_launch_ms"], "launches": lk[ld]["launches"],
+                        "accounting": f"achieved = {LIMB_TERMS} x the algorithmic fp32 FLOPs per launch (the bf16 MFMAs issued) / launch duration, against the dense bf16 peak",
+                        "family": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "avg_launch_ms_isolated": round(li[k]["avg_launch_ms"], 4) if k in li else None,
+                                       "useful_fp32_tflops": round(v["tflops"], 1), "issued_tflops": round(v["issued_tflops"], 1)} for k, v in lk.items()}},
+                }
+                if lpar is not None and not lpar["ok"]:
+                    print(f"[bench.py] PARITY FAILURE of the opt-in limb kernels: {lpar}", file=sys.stderr, flush=True)
         else:
             line["roofline"] = None
             print("[bench.py] no GRU-64 kernel launches were profiled (--profile-steps 0?): the roofline block is empty", file=sys.stderr)

@@ -448,7 +448,7 @@ struct dpdf_model {
     long dbg_nspec = 0, dbg_nframes = 0;
     int dft2 = 1;                      // big launches: STFT / iSTFT as two small matrix stages (0: one [win x 2F] GEMM; A/B)
     size_t dft64_tw1 = 0, dft64_twm = 0, dft64_tw2 = 0;   // operands of the float64 analysis DFT (dft64.h; doubles stored in the float arena)
-    int gru64_limbs = 3;               // (bit 0: intra-band pair, bit 1: inter-band scan) the GRU-64 throughput kernels on bf16 limbs (gru_limb.h: every fp32 product from three bf16 limbs per operand, six
+    int gru64_limbs = 0;               // OPT-IN (default off: the headline arithmetic is fp32 MFMA, reviews of rounds 1 and 2); bit 0: intra-band pair, bit 1: inter-band scan: the GRU-64 throughput kernels on bf16 limbs (gru_limb.h: every fp32 product from three bf16 limbs per operand, six
                                        // bf16 MFMAs per term, fp32 accumulation -- fp32-exact products at 2.67 x the fp32 matrix rate); 0 = the fp32-MFMA kernels of gru_scan.h
     int dft64 = 2;                     // analysis STFT in float64 on every call path (dft64.h): 1 = 48 kHz models only (per-bin log-magnitude features), 2 = 16 kHz too (default: one analysis everywhere), 0 = the fp32 forms (A/B)
     bool use_dft64() const { return (d.win == 960 && dft64 >= 1) || (d.win == 320 && dft64 >= 2); }

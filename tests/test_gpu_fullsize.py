@@ -182,12 +182,12 @@ def test_config5_64_streams_48khz_dpdfnet8(be):
 
 
 def test_limb_and_fp32_gru64_kernels_agree_on_every_clip_of_a_pipelined_batch(be):
-    """The GRU-64 throughput kernels on bf16 limbs (gru_limb.h, default) against the fp32-MFMA kernels of gru_scan.h, 256 clips through
+    """The opt-in GRU-64 throughput kernels on bf16 limbs (gru_limb.h, gru64_limbs = 3) against the default fp32-MFMA kernels of gru_scan.h, 256 clips through
     the multi-chunk pipeline (stage 2 of a chunk under stage 1 of the next), several times over: every clip within fp32 rounding of the
     other path, and each path bit-identical to itself run to run.  (Round 5: with the faster stage 1 the deep-filter kernel read taps
     whose 128-byte lines two XCDs had written piecewise -- single wrong low-band frames in a few clips per run; the taps are read with
     agent-scope loads since: common.h ld_agent.)"""
-    m, _ = _model(be, 16000, 4)
+    m, blob = _model(be, 16000, 4)
     rng = np.random.default_rng(3)
     B, n = 256, 160 * 64 * 8
     wav = (0.05 * rng.standard_normal((B, n))).astype(np.float32)
@@ -208,4 +208,8 @@ def test_limb_and_fp32_gru64_kernels_agree_on_every_clip_of_a_pipelined_batch(be
     m.set_chunk_frames(0)
     y2 = m.enhance_batch(wav, None)                     # the automatic schedule
     assert np.sqrt(np.mean((y2.astype(np.float64) - y0) ** 2, axis=1)).max() < 5e-7
+    # and against the oracle, at the default path's tolerance
+    from oracle import oracle as orc
+    for b in (0, 131, 255):
+        assert rms(y2[b] - orc.Oracle(16000, 4, blob).enhance(wav[b])) < WAVE_TOL, b
     m.close()
