@@ -761,6 +761,7 @@ def main() -> None:
                     help="time-chunk length in frames (0 = engine default)")
     ap.add_argument("--overlap", type=int, default=-1, help="overlap bit mask (1 stage-2 stream, 2 ERB stream, 8 decoder fork, 16 8-/16-WG GRU-256 clusters; 0 serial; -1 engine default)")
     ap.add_argument("--no-fuse", action="store_true", help="run fc+LN of the DPRNN blocks as separate kernels")
+    ap.add_argument("--limbs", action="store_true", help="A/B and traces only: time the OPT-IN limb kernels (gru64_limbs = 3) as this run's mode; the line says so")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -903,6 +904,8 @@ def main() -> None:
         model.set_chunk_frames(args.chunk)
     if args.overlap >= 0:
         model.set_overlap(args.overlap)
+    if args.limbs:
+        model.set_option("gru64_limbs", 3)
     if args.no_fuse:
         model.set_fuse_dprnn(False)
     for kv in args.opt:
@@ -1043,7 +1046,7 @@ def main() -> None:
     # OPT-IN mode beside the headline (never `value`): the same pipelined steps with the GRU-64 throughput kernels on bf16 limbs
     # (gru_limb.h, dpdf_set_option gru64_limbs = 3) -- its own timing, its own per-kernel pass, its own parity block
     limb = None
-    if rank == 0 and not args.no_isolated and not args.no_fuse:
+    if rank == 0 and not args.no_isolated and not args.no_fuse and not args.limbs:
         model.set_option("gru64_limbs", 3)
         step(); sync()
         nl = max(1, min(args.steps, 3))
@@ -1152,6 +1155,9 @@ def main() -> None:
         # words the metric with the H2D / D2H of the PCM inside: that figure is `value_incl_pcie` (measured below in the
         # same run); `value_hbm_resident` repeats `value` under an explicit name.
         line["value_hbm_resident"] = value
+        if args.limbs:
+            line["opt_in_mode"] = "--limbs: THIS RUN times the opt-in limb kernels (dpdf_set_option gru64_limbs = 3), not the default engine"
+            line["dtype"] = "f32 values; GRU-64 products as 3 x 3 bf16 limbs on the bf16 MFMA pipe, fp32 accumulate (opt-in mode)"
         if not args.no_parity and timed_out_host:
             line["parity"] = parity_vs_oracle(blob, wav_host, timed_out_host, parity_slots)
             mark("parity_vs_oracle")
