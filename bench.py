@@ -122,17 +122,33 @@ def cpu_baseline(blob: np.ndarray, seconds_per_clip: float, clips_per_thread: in
     }
 
 
-def parity_vs_oracle(blob: np.ndarray, wav_host: np.ndarray, out_host: np.ndarray, slots) -> dict:
+def parity_vs_oracle(blob: np.ndarray, wav_host: np.ndarray, out_host: np.ndarray, slots, clip_seed0=None) -> dict:
     """The timed step's OWN output (automatic chunk schedule, the execution shape `value` is measured on) against the CPU
     oracle on the same clips: a few slots of the batch, one oracle clip per thread, OUTSIDE the timed region.  The oracle is
     the checker here, never the thing measured (reference package/src/dpdfnet/api.py:51-113 is what both restate)."""
     from oracle import oracle as orc
     errs, sig = {}, {}
 
+    stoi, sisnr = {}, {}
+
     def work(b: int) -> None:
         ref = orc.Oracle(SR, NB, blob).enhance(wav_host[b])
         errs[b] = float(np.sqrt(np.mean((out_host[b].astype(np.float64) - ref) ** 2)))
         sig[b] = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+        # north_star: "PESQ/STOI identical to 3 d.p."  pesq / pystoi are absent here; evalkit.stoi_np restates STOI from its paper (unpinned
+        # against pystoi, and says so) -- the SAME function on both outputs against the clip's clean component, plus SI-SNR of ours vs the oracle
+        try:
+            from dpdfnet_amd.evalkit import si_snr, stoi_np
+            rng = np.random.default_rng(clip_seed0 + b) if clip_seed0 is not None else None
+            if rng is not None:
+                n = wav_host.shape[1]
+                t = np.arange(n, dtype=np.float32) / np.float32(SR)
+                f0 = np.float32(rng.uniform(100.0, 1000.0))
+                clean = np.float32(0.1) * np.sin(np.float32(2 * np.pi) * f0 * t) * (1.0 + np.sin(np.float32(2 * np.pi * 3.0) * t))
+                stoi[b] = (round(float(stoi_np(clean, out_host[b], SR)), 4), round(float(stoi_np(clean, ref, SR)), 4))
+            sisnr[b] = round(float(si_snr(ref, out_host[b])), 1)
+        except Exception as e:          # (metrics are a courtesy here; the RMS check above is the gate)
+            stoi[b] = f"{type(e).__name__}: {e}"
 
     ths = [threading.Thread(target=work, args=(int(b),)) for b in slots]
     for th in ths:
@@ -142,6 +158,9 @@ def parity_vs_oracle(blob: np.ndarray, wav_host: np.ndarray, out_host: np.ndarra
     tol = 2e-6
     return {"rms_max": max(errs.values()), "clips": [int(b) for b in slots], "rms_per_clip": [errs[int(b)] for b in slots],
             "signal_rms": [sig[int(b)] for b in slots], "tol": tol, "ok": bool(max(errs.values()) < tol),
+            "stoi_np_ours_vs_oracle_output": [stoi.get(int(b)) for b in slots], "si_snr_db_ours_against_oracle": [sisnr.get(int(b)) for b in slots],
+            "metrics_note": "STOI of our output and of the oracle's output against the clip's clean component with evalkit.stoi_np (a restatement of the STOI paper, "
+                            "NOT pinned against pystoi, which like pesq is absent here): the pair must agree to 3 d.p.; SI-SNR as the reference's script computes it",
             "against": "oracle/dpdf_oracle.c (pinned to the reference's goldens) on the same clips; output of the LAST timed step"}
 
 
@@ -1159,7 +1178,7 @@ def main() -> None:
             line["opt_in_mode"] = "--limbs: THIS RUN times the opt-in limb kernels (dpdf_set_option gru64_limbs = 3), not the default engine"
             line["dtype"] = "f32 values; GRU-64 products as 3 x 3 bf16 limbs on the bf16 MFMA pipe, fp32 accumulate (opt-in mode)"
         if not args.no_parity and timed_out_host:
-            line["parity"] = parity_vs_oracle(blob, wav_host, timed_out_host, parity_slots)
+            line["parity"] = parity_vs_oracle(blob, wav_host, timed_out_host, parity_slots, WEIGHT_SEED + lo)
             mark("parity_vs_oracle")
             if not line["parity"]["ok"]:
                 print(f"[bench.py] PARITY FAILURE on the timed shape: {line['parity']}", file=sys.stderr, flush=True)
@@ -1246,7 +1265,7 @@ def main() -> None:
             if limb is not None:
                 lk, li = kernel_stats(limb["prof"], 1), kernel_stats(limb["iso"], 1)
                 ld = "gru64_l3_kernel<2>"
-                lpar = parity_vs_oracle(blob, wav_host, limb["out"], sorted(limb["out"])) if (not args.no_parity and timed_out_host) else None
+                lpar = parity_vs_oracle(blob, wav_host, limb["out"], sorted(limb["out"]), WEIGHT_SEED + lo) if (not args.no_parity and timed_out_host) else None
                 line["limb_kernels_opt_in"] = {
                     "what": "NOT the headline: the same step with dpdf_set_option(gru64_limbs, 3) -- the three GRU-64 throughput launches of a DPRNN block form every "
                             "fp32 product from three bf16 limbs per operand (v = hi + mid + lo exactly; six v_mfma_f32_16x16x32_bf16 per term, fp32 accumulate): gru_limb.h. "
