@@ -244,8 +244,9 @@ class _HostBlockPool:
     Blocks are therefore leased: `take(n)` hands out a flat float32 array of n elements on a block from the free list (or a new
     one); the results of a call are row views of it; when the LAST view of a lease is garbage collected the block returns to the
     free list (a ctypes array is the views' common base object; its weakref finaliser gives the block back).  Consequence: one
-    kept result keeps its whole block alive.  DPDFNET_OUTPUT_POOL_MB (default 2048) bounds the idle memory kept; 0 turns leasing
-    off (every result its own fresh array)."""
+    kept result keeps its whole block alive (copy what you keep beyond the next call if that matters).  DPDFNET_OUTPUT_POOL_MB
+    (default 512: three result blocks of a 256 x 10 s call) bounds the idle memory kept, and a request that no idle block fits evicts idle
+    blocks of other sizes down to that bound before it allocates; 0 turns leasing off (every result its own fresh array)."""
 
     def __init__(self) -> None:
         self._lock = threading.Lock()
@@ -254,7 +255,7 @@ class _HostBlockPool:
         # holds `_lock` (cyclic GC) -- so it must never take the lock: it only appends here (deque.append is atomic), and take()
         # moves the blocks to the free list under the lock.
         self._returned: "collections.deque[np.ndarray]" = collections.deque()
-        self.limit_bytes = int(float(os.environ.get("DPDFNET_OUTPUT_POOL_MB", "2048")) * (1 << 20))
+        self.limit_bytes = int(float(os.environ.get("DPDFNET_OUTPUT_POOL_MB", "512")) * (1 << 20))
         self.leases = 0          # statistics (tests)
         self.reused = 0
 
@@ -294,6 +295,11 @@ class _HostBlockPool:
             if best >= 0:
                 raw = self._free.pop(best)
                 self.reused += 1
+            else:
+                # a new size class: idle blocks of other sizes do not pile up beside it (largest first)
+                self._free.sort(key=lambda b: b.nbytes)
+                while self._free and sum(b.nbytes for b in self._free) + n * 4 > self.limit_bytes:
+                    self._free.pop()
         if raw is None:
             raw = np.empty(n, dtype=np.float32)
         lease = (ctypes.c_float * raw.size).from_buffer(raw)          # shares raw's memory and keeps raw alive
