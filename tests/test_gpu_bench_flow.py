@@ -57,11 +57,18 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["public_api"]["max_abs_diff_vs_hbm_resident_output"] == 0.0
     # RCCL has executed on this box: one-rank process group (backend nccl) in a child process, the collectives of the N > 1 path
     st = d["rccl_selftest"]
-    # (the child runs under a 180 s cap: on a box whose host is slow enough to hit it -- first import of torch included -- the line
-    # says so, and that is not a failure of the collectives)
-    if not (st.get("rccl_init_ok") is False and "timed out" in str(st.get("error", ""))):
-        assert d["rccl_init_ok"] is True, st
-        assert st["all_reduce_ok"] and st["barrier_ok"] and st["all_gather_object_ok"], st
+    # the child streams stage stamps and runs under a 60 s cap: a run that did not finish must SAY where it stopped (round-4 review:
+    # a time-out may not simply pass)
+    if st.get("rccl_init_ok") is False:
+        assert st.get("hung_at") and isinstance(st.get("stages"), list), st
+        pytest.fail(f"RCCL self-test did not finish on this box: hung at {st['hung_at']!r}; stages {st['stages']}")
+    assert d["rccl_init_ok"] is True, st
+    assert st["all_reduce_ok"] and st["barrier_ok"] and st["all_gather_object_ok"], st
+    # the headline arithmetic is fp32 MFMA; the limb kernels ride beside it as an opt-in block with its own parity (16 clips: the
+    # fused launches they replace are not selected at this size, so the block reports the timing and the parity only)
+    assert d["dtype"] == "f32" and "opt_in_mode" not in d
+    lk = d["limb_kernels_opt_in"]
+    assert lk["value"] > 0 and lk["parity"]["ok"] is True and "NOT the headline" in lk["what"]
 
 
 def test_two_ranks_control_flow_over_gloo():
