@@ -67,7 +67,7 @@ def banked_trace(kind: str) -> str:
     import re
     best, best_n = f"profiles/rN_{kind}_kernel_stats.csv (none banked)", -1
     for f in (ROOT / "profiles").glob(f"r*_{kind}_kernel_stats.csv"):
-        mt = re.match(r"r(\d+)_", f.name)
+        mt = re.fullmatch(rf"r(\d+)_{kind}_kernel_stats\.csv", f.name)          # (not r5_limbs_pipelined_... for "pipelined")
         if mt and int(mt.group(1)) > best_n:
             best, best_n = f"profiles/{f.name}", int(mt.group(1))
     return best
@@ -1229,7 +1229,7 @@ def main() -> None:
                 "timing": f"HIP events on the launching stream around every launch of {psteps} steps run right after the timed "
                           "region in the same execution shape (the timed region itself runs with these events off: "
                           f"{1e3 * dt / args.steps:.2f} ms/step timed vs {prof_ms:.2f} ms/step with events)",
-                "reproduce": (banked_trace("serial") if serial_mode else banked_trace("pipelined"))
+                "reproduce": (banked_trace(("limbs_" if args.limbs else "") + "serial") if serial_mode else banked_trace(("limbs_" if args.limbs else "") + "pipelined"))
                              + ": rocprofv3 --kernel-trace --stats of `python bench.py --no-isolated --no-other-configs --no-cpu-baseline "
                                "--no-pcie" + (" --overlap 0`" if serial_mode else "`") + " -- every launch of that run has this execution "
                                "shape, so the CSV's AverageNs for the kernel is this avg_launch_ms (profiles/README.md)",
