@@ -105,3 +105,21 @@ def test_plain_invocation_with_gpus_2_launches_its_own_ranks():
     mg = d["multi_gpu"]
     assert [q["rank"] for q in mg["rccl_ranks"]] == [0, 1] and mg["collective_ok"] is True and mg["gathered_matches_rank_outputs"] is True
     assert "starting 2 ranks" in r.stderr
+
+
+def test_rccl_that_never_answers_falls_back_to_gloo_and_the_line_says_so():
+    """Round-4 review item 2: at N > 1 `init_process_group("nccl")` runs under a watchdog; when it does not return (test hook
+    DPDF_BENCH_FAKE_RCCL_HANG=1: the init sleeps instead) every rank re-executes itself on gloo with a host-staged gather -- rc 0, ONE line,
+    the compute figure kept, `collective: FALLBACK gloo: <reason naming the stage>`."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update({"DPDF_BENCH_FAKE_RCCL_HANG": "1", "DPDF_BENCH_RCCL_WATCHDOG_S": "6"})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "8", "--no-other-configs"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stderr[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["finite_output"] is True and d["value"] > 0
+    assert "FALLBACK gloo" in d["config"]["sharding"] and "init_process_group" in d["config"]["sharding"]
+    mg = d["multi_gpu"]
+    assert "FALLBACK" in mg["backend"] and mg["fallback_reason"] and mg["gathered_matches_rank_outputs"] is True
