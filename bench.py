@@ -771,6 +771,9 @@ class CollectiveWatchdog:
 
 
 def main() -> None:
+    if os.environ.get("DPDF_BENCH_TRACE_HANG"):          # debugging aid: every thread's Python stack on stderr after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["DPDF_BENCH_TRACE_HANG"]), repeat=False, exit=False)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -891,8 +894,11 @@ def main() -> None:
                 wd.disarm()
                 reexec_with_gloo_fallback(f"{type(exc).__name__} at stage `{wd._stage}`: {exc}")
         elif args.fallback_reason:
-            dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{os.environ['DPDF_BENCH_FALLBACK_PORT']}",
-                                    rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+            # an explicit store: under torch.distributed.run (TORCHELASTIC_USE_AGENT_STORE) a tcp:// init_method makes EVERY rank a
+            # client of a store nobody hosts -- both ranks sat in the rendezvous for good (found by the fake-hang GPU test)
+            store = dist.TCPStore("127.0.0.1", int(os.environ["DPDF_BENCH_FALLBACK_PORT"]), world, rank == 0,
+                                  timeout=datetime.timedelta(seconds=120), wait_for_workers=True)
+            dist.init_process_group(backend="gloo", store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         else:
             dist.init_process_group(backend=args.backend)
         # pre-flight: the process group really has N ranks and (under RCCL) every rank sits on its own GPU
