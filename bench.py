@@ -920,7 +920,7 @@ def main() -> None:
         # RCCL executed on this box (one rank): communicator init on the device + the collectives the N > 1 path uses.  FIRST, on an
         # idle GPU and with torch's files already paged in by the import above (a fresh box takes a minute for the first import: that
         # is not RCCL's time), in a process of its own under a 60 s deadline.
-        rccl_selftest = dist_selftest()
+        rccl_selftest = dist_selftest(float(os.environ.get("DPDF_BENCH_SELFTEST_CAP_S", "60")))
         mark("rccl_selftest_child")
 
     blob = synth_blob(backend.manifest(SR, NB), WEIGHT_SEED)

@@ -123,3 +123,18 @@ def test_rccl_that_never_answers_falls_back_to_gloo_and_the_line_says_so():
     assert "FALLBACK gloo" in d["config"]["sharding"] and "init_process_group" in d["config"]["sharding"]
     mg = d["multi_gpu"]
     assert "FALLBACK" in mg["backend"] and mg["fallback_reason"] and mg["gathered_matches_rank_outputs"] is True
+
+
+def test_one_rank_rccl_self_test_that_hangs_names_its_stage_and_costs_only_its_cap():
+    """N = 1: the RCCL self-test child "hangs" in its communicator init (DPDF_BENCH_FAKE_RCCL_HANG=1), the parent kills it at the cap
+    (8 s here, 60 s by default) and the line carries `rccl_init_ok: false`, `hung_at` naming that stage and the stamps that did
+    arrive -- the headline is measured all the same (round-4 review item 2a)."""
+    env = dict(os.environ, DPDF_BENCH_FAKE_RCCL_HANG="1", DPDF_BENCH_SELFTEST_CAP_S="8")
+    r = subprocess.run([sys.executable, "bench.py", "--clips", "16", "--steps", "1", "--warmup", "1", "--no-other-configs", "--no-cpu-baseline",
+                        "--no-pcie", "--no-isolated"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_lines(r.stdout)[0]
+    st = d["rccl_selftest"]
+    assert d["rccl_init_ok"] is False and "timed out after 8 s" in st["error"], st
+    assert "init_process_group" in st["hung_at"] and any("import torch" in x for x in st["stages"]), st
+    assert d["value"] > 0 and d["parity"]["ok"] is True and 7.0 < st["wall_s"] < 30.0
