@@ -42,6 +42,7 @@
 #include "resample.h"
 #include "df_ring.h"
 #include "dec_last.h"
+#include "dec_seg2.h"
 #include "gru_stack.h"
 #include "fcln_gi.h"
 #include "gru_scan4.h"
@@ -391,7 +392,8 @@ struct dpdf_model {
     int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
     int gru256_c16_tiles = 2;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
     int df_ring = 2;                   // big batches: 1 = df_conv1 + DF pathway conv as one time-walking pass over c0 (df_ring.h), 2 = df_conv0 in it too
-    int dec_seg = 1;                   // 48 kHz decoder stages as band-segment tiles with inputs read once (dec_last.h: dec_seg_kernel; 0: gemm_rows producers, A/B)
+    int dec_seg = 2;                   // 48 kHz decoder stages as band-segment tiles with inputs read once: 2 = tile-pipelined (dec_seg2.h), 1 = dec_last.h: dec_seg_kernel, 0 = gemm_rows producers (A/B)
+    int dec_seg_grid = 256;            // dec_seg2 workgroups (512 threads, 110 / 149 KB of LDS: one per CU)
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
                                        // 1 auto (only when B*Tc fills the chip; measured crossover ~3k frame rows), 2 always
@@ -1559,16 +1561,21 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
     }
     if (geo48) {    // 48 kHz geometry: tiles of 80 / 80 / 96 output bands of one frame, inputs loaded once (dec_last.h: dec_seg_kernel)
         const long cap = 256 * 2 * 4;
+        const bool pipe = m->dec_seg == 2;
+        auto grid = [&](long tiles) { return dim3((unsigned)std::min<long>(tiles, pipe ? m->dec_seg_grid : cap)); };
         DecSegArgs a3{x.e3.p, dembp, w.d3.p, m->C(m->conv3p.ps), m->C(m->conv3p.pb), m->C(m->convt3.dw), m->C(m->convt3.pwfrag), m->C(m->convt3.bias),
                       nullptr, nullptr, nullptr, nullptr, nullptr, BT, d.F2};
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), dim3((unsigned)std::min<long>((long)BT * (d.F2 / 80), cap)), dim3(256), 0, st, a3);
+        if (pipe) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<2, 80, false>), grid((long)BT * (d.F2 / 80)), dim3(512), 0, st, a3);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), grid((long)BT * (d.F2 / 80)), dim3(256), 0, st, a3);
         DecSegArgs a2{x.e2.p, w.d3.p, w.d2.p, m->C(m->conv2p.ps), m->C(m->conv2p.pb), m->C(m->convt2.dw), m->C(m->convt2.pwfrag), m->C(m->convt2.bias),
                       nullptr, nullptr, nullptr, nullptr, nullptr, BT, d.F1};
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), dim3((unsigned)std::min<long>((long)BT * (d.F1 / 80), cap)), dim3(256), 0, st, a2);
+        if (pipe) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<2, 80, false>), grid((long)BT * (d.F1 / 80)), dim3(512), 0, st, a2);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), grid((long)BT * (d.F1 / 80)), dim3(256), 0, st, a2);
         // convt1 + mask head: w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
         DecSegArgs a1{x.e1.p, w.d2.p, nullptr, m->C(m->conv1p.ps), m->C(m->conv1p.pb), m->C(m->convt1.dw), m->C(m->convt1.pwfrag), m->C(m->convt1.bias),
                       x.e0.p, w.d1.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), BT, d.Ec};
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<3, 96, true>), dim3((unsigned)std::min<long>((long)BT * (d.Ec / 96), cap)), dim3(256), 0, st, a1);
+        if (pipe) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<3, 96, true>), grid((long)BT * (d.Ec / 96)), dim3(512), 0, st, a1);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<3, 96, true>), grid((long)BT * (d.Ec / 96)), dim3(256), 0, st, a1);
         MaskFinArgs mf{w.d1.p, w.m.p, m->c0out_bias, BT * d.Ec, d.Ec, d.E, d.is48};
         hipLaunchKernelGGL(mask_fin_kernel, dim3((BT * d.Ec + 255) / 256), dim3(256), 0, st, mf);
         return;
@@ -2224,7 +2231,8 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     for (int g = 0; g < 1; ++g) m->lanes[g].sync_all();
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
-    else if (n == "dec_seg") m->dec_seg = value != 0;
+    else if (n == "dec_seg") m->dec_seg = value;
+    else if (n == "dec_seg_grid") m->dec_seg_grid = value > 0 ? value : 256;
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
     else if (n == "scan4_max_wgs") m->scan4_max_wgs = value < 0 ? 0 : value;
