@@ -70,29 +70,30 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
     // A tile's input run starts one band below its first output's source band; the halo band is outside the frame for the first / last
     // segment of a frame (its u stays zero: the pathway term too) -- those threads read their neighbour row instead, p1 drops it.
     // Addresses are a wave-uniform base + a per-thread byte offset fixed for the whole launch.
+    // No control flow around the loads: behind a branch that may skip them the compiler can no longer count the loads in flight and waits
+    // for ALL of them where a tile's registers are first used -- i.e. for the loads it has just issued (measured: +0.95 ms on the 3.15 ms of
+    // the mask-head stage).  Rows past the run read the last row again, tiles past the workgroup's last read the last tile again.
     unsigned in_off[NP];
     bool in_lo[NP], in_hi[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int row = r32 + 32 * i;
+        const int row = r32 + 32 * i < NIN ? r32 + 32 * i : NIN - 1;
         in_off[i] = (unsigned)(row * 64 + c4) * 4u;              // against the halo band below the tile
         in_lo[i] = row == 0; in_hi[i] = row == NIN - 1;
     }
     auto load_tile = [&](int j, float4 (&ve)[NP], float4 (&vp)[NP]) __attribute__((always_inline)) {
-        if (j >= cnt || (DS2_VAR == 3 && j > 1)) return;
-        const int tile = b0 + j * G, bt = tile / nseg, seg = tile - bt * nseg;
+        if (DS2_VAR == 3 && j > 1) return;
+        const int tile = b0 + (j < cnt ? j : cnt - 1) * G, bt = tile / nseg, seg = tile - bt * nseg;
         const char* ep = (const char*)(a.e + ((size_t)bt * FI + (size_t)seg * RI) * 64) - 256;
         const char* pp = (const char*)(a.prev + ((size_t)bt * FI + (size_t)seg * RI) * 64) - 256;
         const bool first = seg == 0, last = seg == nseg - 1;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (r32 + 32 * i < NIN) {
-                unsigned off = in_off[i];
-                if (first && in_lo[i]) off += 256u;
-                if (last && in_hi[i]) off -= 256u;
-                ve[i] = *(const float4*)(ep + off);
-                vp[i] = *(const float4*)(pp + off);
-            }
+            unsigned off = in_off[i];
+            off = first && in_lo[i] ? off + 256u : off;
+            off = last && in_hi[i] ? off - 256u : off;
+            ve[i] = *(const float4*)(ep + off);
+            vp[i] = *(const float4*)(pp + off);
         }
     };
     auto p1 = [&](int j, int ub, const float4 (&ve)[NP], const float4 (&vp)[NP]) __attribute__((always_inline)) {
@@ -171,13 +172,13 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
         }
     };
     auto load_e0 = [&](int j, float4 (&ve0)[NO]) __attribute__((always_inline)) {
-        if (j >= cnt || (DS2_VAR == 3 && j > 1)) return;
-        const int tile = b0 + j * G, bt = tile / nseg, seg = tile - bt * nseg;
+        if (DS2_VAR == 3 && j > 1) return;
+        const int tile = b0 + (j < cnt ? j : cnt - 1) * G, bt = tile / nseg, seg = tile - bt * nseg;
         const char* e0p = (const char*)(a.e0 + ((size_t)bt * a.FO + (size_t)seg * R) * 64);
 #pragma unroll
         for (int i = 0; i < NO; ++i) {
-            const int row = r32 + 32 * i;
-            if (row < R) ve0[i] = *(const float4*)(e0p + (unsigned)(row * 64 + c4) * 4u);
+            const int row = r32 + 32 * i < R ? r32 + 32 * i : R - 1;
+            ve0[i] = *(const float4*)(e0p + (unsigned)(row * 64 + c4) * 4u);
         }
     };
     // LAST: the three tap sums of conv0_out per row from the finished u0 rows: four threads per row, sixteen channels each, summed over
@@ -220,9 +221,15 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
     };
 
     float4 ve[2][NP], vp[2][NP], ve0[2][NO];
+    // (in the order of the steady state, pinned: the wait in front of a tile's first use counts the loads issued behind it)
     load_tile(0, ve[0], vp[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (LAST) load_e0(0, ve0[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (LAST) load_e0(1, ve0[1]);
+    __builtin_amdgcn_sched_barrier(0);
     load_tile(1, ve[1], vp[1]);
-    if (LAST) { load_e0(0, ve0[0]); load_e0(1, ve0[1]); }
+    __builtin_amdgcn_sched_barrier(0);
     int k3 = 1;                                                          // (n + 3) % 3: tile n's E0 ring slot
     auto tick = [&](auto par, int n) __attribute__((always_inline)) {
         constexpr int P = decltype(par)::value;
