@@ -378,6 +378,38 @@ def test_throughput_regime_chunk_schedule_matches_whole_sequence_and_oracle(be):
     m.close()
 
 
+def test_48khz_decoder_stage_forms_agree_and_match_the_oracle(be):
+    """The 48 kHz decoder stages (40 -> 80 -> 160 -> 480 bands + the mask head's tap sums) exist three times: gemm_rows launches with
+    sub-pixel producers (dec_seg = 0), band-segment tiles with inputs read once (1: dec_last.h dec_seg_kernel) and the tile pipeline of
+    dec_seg2.h (2, the default from 1024 frames per chunk on).  97 clips x 11-frame chunks (1067 frames: 1067 / 2134 / 5335 tiles over 256
+    workgroups -- uneven shares, a ragged last chunk of 4 frames falls back to the small forms), stage tensors and waveforms against
+    each other, three clips against the oracle."""
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import synth_blob
+    sr, nb = 48000, 1
+    blob = synth_blob(be.manifest(sr, nb), 4242)
+    m = be.HipModel(sr, nb, blob, 0)
+    B, n = 97, int(0.37 * sr) + 5
+    wav = np.stack([synth_clip(n, sr, 5100 + i) * (0.4 + (i % 5) / 5.0) for i in range(B)]).astype(np.float32)
+    m.set_chunk_frames(11)
+    outs, masks = {}, {}
+    for form in (2, 1, 0, 2):
+        m.set_option("dec_seg", form)
+        out = m.enhance_batch(wav, 6.0)
+        if form in outs:
+            np.testing.assert_array_equal(out, outs[form])          # run to run
+        outs[form], masks[form] = out, m.debug_fetch("m")
+    for form in (1, 0):
+        assert rms(outs[2] - outs[form]) < 1e-6, form
+        assert np.abs(masks[2] - masks[form]).max() < 2e-5, form
+    o = orc.Oracle(sr, nb, blob)
+    for b in (0, 50, 96):
+        assert rms(outs[2][b] - o.enhance(wav[b], 6.0)) < WAVE_TOL, b
+    m.set_option("dec_seg_grid", 7)                                   # many tiles per workgroup, odd shares
+    np.testing.assert_array_equal(m.enhance_batch(wav, 6.0), outs[2])
+    m.close()
+
+
 @pytest.mark.parametrize("sr,nb", [(16000, 2), (48000, 1)])
 def test_big_batch_kernel_forms_match_small_batch_forms_and_oracle(be, sr, nb):
     """Launch shapes that only big batches select -- the time-walking DF pass over c0 (df_ring_kernel: df_conv1 + pathway
