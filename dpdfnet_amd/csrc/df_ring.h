@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 3) void df_ring_kernel(DfRingArgs a) {
                     c0acc[mt] = mfma16(x0, c0w[c * 4 + 0], c0acc[mt]);
                     c0acc[mt] = mfma16(x1, c0w[c * 4 + 1], c0acc[mt]);
                     c0acc[mt] = mfma16(x2, c0w[c * 4 + 2], c0acc[mt]);
-                    c0acc[mt] = mfma16(0.f, c0w[c * 4 + 3], c0acc[mt]);
+                    // (kb = 3 is the zero padding of the three band taps to four: its product is skipped, not issued)
                 }
             }
             const bool keep = t + 5 >= a.Tc;                            // the state FIFO exports the chunk's last five frames
