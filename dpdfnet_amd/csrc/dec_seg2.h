@@ -19,16 +19,21 @@
 #endif
 
 template <int S, int R, bool LAST>
-__global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
+constexpr int dec_seg2_lds_floats() { return (2 * (R / S + 2) + 2 * R + (LAST ? 3 * R : 2 * R)) * 68; }
+
+// One stage over this workgroup's frames (b0, b0 + G, ...: every tile of a frame belongs to the frame's workgroup, so a stage's input frame is
+// the same workgroup's output of the stage before -- dec_seg2_all_kernel runs the three stages back to back without leaving its CU).
+template <int S, int R, bool LAST>
+__device__ __forceinline__ void dec_seg2_body(const DecSegArgs& a, float* lds) {
     constexpr int RI = R / S, NRT = R / 16, NIN = RI + 2;
     constexpr int NP = (NIN * 16 + 511) / 512;                           // float4 pieces per thread of e / prev (incl. the halo bands)
     constexpr int NO = (R * 16 + 511) / 512;                             // ... of the depthwise panel / the output tile / e0 (LAST)
     constexpr int RT_SPLIT = (NRT + 1) / 2;
     static_assert(R % 16 == 0 && R % S == 0, "tile = whole MFMA row tiles and whole input bands");
-    __shared__ __attribute__((aligned(16))) float U1[2][NIN][68];
-    __shared__ __attribute__((aligned(16))) float As[2][R][68];
-    __shared__ __attribute__((aligned(16))) float Os[LAST ? 1 : 2][LAST ? 1 : R][68];
-    __shared__ __attribute__((aligned(16))) float E0[LAST ? 3 : 1][LAST ? R : 1][68];    // relu(ps0 e0 + pb0), then u0 in place; a tile's buffer lives three ticks
+    float (*U1)[NIN][68] = reinterpret_cast<float (*)[NIN][68]>(lds);                                    // [2]
+    float (*As)[R][68] = reinterpret_cast<float (*)[R][68]>(lds + 2 * NIN * 68);                         // [2]
+    float (*Os)[R][68] = reinterpret_cast<float (*)[R][68]>(lds + (2 * NIN + 2 * R) * 68);               // [2] (!LAST)
+    float (*E0)[R][68] = Os;                                                                             // [3] (LAST): relu(ps0 e0 + pb0), then u0 in place; a tile's buffer lives three ticks
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, q = lane >> 4;
@@ -63,9 +68,9 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
             for (int t = 0; t < 3; ++t) dwr[i][j][t] = a.dw[((size_t)k * 64 + c4 + j) * 3 + t];
     }
     const int FI = a.FO / S, nseg = a.FO / R;
-    const int ntiles = a.BT * nseg, G = gridDim.x, b0 = blockIdx.x;
-    if (b0 >= ntiles) return;
-    const int cnt = (ntiles - b0 + G - 1) / G;                           // this workgroup's tiles: b0 + j G, j < cnt
+    const int G = gridDim.x, b0 = blockIdx.x;
+    if (b0 >= a.BT) return;
+    const int cnt = (a.BT - b0 + G - 1) / G * nseg;                      // this workgroup's tiles: segment j % nseg of frame b0 + (j / nseg) G, j < cnt
 
     // A tile's input run starts one band below its first output's source band; the halo band is outside the frame for the first / last
     // segment of a frame (its u stays zero: the pathway term too) -- those threads read their neighbour row instead, p1 drops it.
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
     }
     auto load_tile = [&](int j, float4 (&ve)[NP], float4 (&vp)[NP]) __attribute__((always_inline)) {
         if (DS2_VAR == 3 && j > 1) return;
-        const int tile = b0 + (j < cnt ? j : cnt - 1) * G, bt = tile / nseg, seg = tile - bt * nseg;
+        const int jc = j < cnt ? j : cnt - 1, fr = jc / nseg, bt = b0 + fr * G, seg = jc - fr * nseg;
         const char* ep = (const char*)(a.e + ((size_t)bt * FI + (size_t)seg * RI) * 64) - 256;
         const char* pp = (const char*)(a.prev + ((size_t)bt * FI + (size_t)seg * RI) * 64) - 256;
         const bool first = seg == 0, last = seg == nseg - 1;
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
     };
     auto p1 = [&](int j, int ub, const float4 (&ve)[NP], const float4 (&vp)[NP]) __attribute__((always_inline)) {
         if (j < 0 || j >= cnt) return;
-        const int tile = b0 + j * G, seg = tile % nseg;
+        const int seg = j % nseg;
         const bool first = seg == 0, last = seg == nseg - 1;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
     };
     auto load_e0 = [&](int j, float4 (&ve0)[NO]) __attribute__((always_inline)) {
         if (DS2_VAR == 3 && j > 1) return;
-        const int tile = b0 + (j < cnt ? j : cnt - 1) * G, bt = tile / nseg, seg = tile - bt * nseg;
+        const int jc = j < cnt ? j : cnt - 1, fr = jc / nseg, bt = b0 + fr * G, seg = jc - fr * nseg;
         const char* e0p = (const char*)(a.e0 + ((size_t)bt * a.FO + (size_t)seg * R) * 64);
 #pragma unroll
         for (int i = 0; i < NO; ++i) {
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
     // the quad by two DPP steps; thread 0 of the quad stores [t0 t1 t2 0] (dec_seg_kernel sums in another order: equal to rounding)
     auto taps = [&](int j, int eb) __attribute__((always_inline)) {
         if (j < 0 || j >= cnt || DS2_VAR == 4 || DS2_VAR == 5) return;
-        const int tile = b0 + j * G, bt = tile / nseg, seg = tile - bt * nseg;
+        const int fr = j / nseg, bt = b0 + fr * G, seg = j - fr * nseg;
         char* sp = (char*)(a.ssum + ((size_t)bt * a.FO + (size_t)seg * R) * 4);
         const int r = tid >> 2, pq = tid & 3;
         if (r < R) {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
     };
     auto p4 = [&](int j, int ob) __attribute__((always_inline)) {
         if (LAST || j < 0 || j >= cnt || DS2_VAR == 4) return;
-        const int tile = b0 + j * G, bt = tile / nseg, seg = tile - bt * nseg;
+        const int fr = j / nseg, bt = b0 + fr * G, seg = j - fr * nseg;
         char* op = (char*)(a.out + ((size_t)bt * a.FO + (size_t)seg * R) * 64);
 #pragma unroll
         for (int i = 0; i < NO; ++i) {
@@ -248,4 +253,26 @@ __global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
         tick(std::integral_constant<int, 0>{}, n);
         tick(std::integral_constant<int, 1>{}, n + 1);
     }
+}
+
+template <int S, int R, bool LAST>
+__global__ __launch_bounds__(512) void dec_seg2_kernel(DecSegArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[dec_seg2_lds_floats<S, R, LAST>()];
+    dec_seg2_body<S, R, LAST>(a, lds);
+}
+
+// The three stages of the 48 kHz decoder in ONE launch (option dec_seg = 3; NOT the default).  Stage 2 of the pipeline runs beside the next
+// chunk's stage 1, whose GRU-64 workgroups hold their CUs for a millisecond or two, and each of the three launches waits for CUs again (traced:
+// 2.35 ms per launch for stages that take 0.49 / 0.87 ms alone).  With frames dealt to workgroups, a stage reads what the same workgroup
+// wrote: nothing crosses workgroups, the stages follow each other behind a drained store queue and a barrier.  Bit-identical to the three
+// launches, 3.92 against 4.00 ms alone -- and 3 ms per step SLOWER in the pipeline (dpdfnet2_48khz_hr 131.0 -> 134.1): holding all 256 CUs for
+// the whole decoder costs stage 1 more than the two re-acquisitions cost stage 2.
+__global__ __launch_bounds__(512) void dec_seg2_all_kernel(DecSegArgs a3, DecSegArgs a2, DecSegArgs a1) {
+    constexpr int NF = dec_seg2_lds_floats<3, 96, true>() > dec_seg2_lds_floats<2, 80, false>() ? dec_seg2_lds_floats<3, 96, true>() : dec_seg2_lds_floats<2, 80, false>();
+    __shared__ __attribute__((aligned(16))) float lds[NF];
+    dec_seg2_body<2, 80, false>(a3, lds);
+    __threadfence(); __syncthreads();
+    dec_seg2_body<2, 80, false>(a2, lds);
+    __threadfence(); __syncthreads();
+    dec_seg2_body<3, 96, true>(a1, lds);
 }

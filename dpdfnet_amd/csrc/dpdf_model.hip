@@ -392,7 +392,10 @@ struct dpdf_model {
     int gru256_c8_tiles = 4;           // launches of <= this many tiles use eight workgroups per tile (gru256_cluster8_kernel)
     int gru256_c16_tiles = 2;          // launches of <= this many 16-row tiles use sixteen workgroups per tile (gru256_cluster16_kernel)
     int df_ring = 2;                   // big batches: 1 = df_conv1 + DF pathway conv as one time-walking pass over c0 (df_ring.h), 2 = df_conv0 in it too
-    int dec_seg = 2;                   // 48 kHz decoder stages as band-segment tiles with inputs read once: 2 = tile-pipelined (dec_seg2.h), 1 = dec_last.h: dec_seg_kernel, 0 = gemm_rows producers (A/B)
+    int dec_seg = 2;                   // 48 kHz decoder stages as band-segment tiles with inputs read once: 2 = tile-pipelined (dec_seg2.h), three launches; 3 = the same in ONE launch
+                                       // (dec_seg2_all_kernel; A/B: holding every CU for the whole decoder costs stage 1 more than the two re-acquisitions cost stage 2: 131.0 -> 134.1 ms/step);
+                                       // 1 = dec_last.h: dec_seg_kernel, 0 = gemm_rows producers
+    int dec_seg_all_frames = 8192;     // ... one launch from this many frames per chunk on
     int conv0_frames = 256;            // erb_conv0 as a workgroup per frame (conv0_erb_frames_kernel) from this many frames per chunk on (0: conv0_erb_kernel)
     int dec_seg_grid = 256;            // dec_seg2 workgroups (512 threads, 110 / 149 KB of LDS: one per CU)
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
@@ -1563,21 +1566,26 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
     }
     if (geo48) {    // 48 kHz geometry: tiles of 80 / 80 / 96 output bands of one frame, inputs loaded once (dec_last.h: dec_seg_kernel)
         const long cap = 256 * 2 * 4;
-        const bool pipe = m->dec_seg == 2;
-        auto grid = [&](long tiles) { return dim3((unsigned)std::min<long>(tiles, pipe ? m->dec_seg_grid : cap)); };
+        const bool pipe = m->dec_seg >= 2;
+        const bool one = m->dec_seg >= 3 && BT >= m->dec_seg_all_frames;   // (few frames per workgroup: three launches fill and drain faster)
+        auto grid = [&](long tiles) { return dim3((unsigned)std::min<long>(pipe ? BT : tiles, pipe ? m->dec_seg_grid : cap)); };
         DecSegArgs a3{x.e3.p, dembp, w.d3.p, m->C(m->conv3p.ps), m->C(m->conv3p.pb), m->C(m->convt3.dw), m->C(m->convt3.pwfrag), m->C(m->convt3.bias),
                       nullptr, nullptr, nullptr, nullptr, nullptr, BT, d.F2};
-        if (pipe) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<2, 80, false>), grid((long)BT * (d.F2 / 80)), dim3(512), 0, st, a3);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), grid((long)BT * (d.F2 / 80)), dim3(256), 0, st, a3);
         DecSegArgs a2{x.e2.p, w.d3.p, w.d2.p, m->C(m->conv2p.ps), m->C(m->conv2p.pb), m->C(m->convt2.dw), m->C(m->convt2.pwfrag), m->C(m->convt2.bias),
                       nullptr, nullptr, nullptr, nullptr, nullptr, BT, d.F1};
-        if (pipe) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<2, 80, false>), grid((long)BT * (d.F1 / 80)), dim3(512), 0, st, a2);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), grid((long)BT * (d.F1 / 80)), dim3(256), 0, st, a2);
         // convt1 + mask head: w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
         DecSegArgs a1{x.e1.p, w.d2.p, nullptr, m->C(m->conv1p.ps), m->C(m->conv1p.pb), m->C(m->convt1.dw), m->C(m->convt1.pwfrag), m->C(m->convt1.bias),
                       x.e0.p, w.d1.p, m->C(m->conv0p.ps), m->C(m->conv0p.pb), m->C(m->c0out_w), BT, d.Ec};
-        if (pipe) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<3, 96, true>), grid((long)BT * (d.Ec / 96)), dim3(512), 0, st, a1);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<3, 96, true>), grid((long)BT * (d.Ec / 96)), dim3(256), 0, st, a1);
+        if (one && d.F2 == 80 && d.F1 == 160 && d.Ec == 480) {
+            hipLaunchKernelGGL(dec_seg2_all_kernel, grid(BT), dim3(512), 0, st, a3, a2, a1);
+        } else {
+            if (pipe) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<2, 80, false>), grid((long)BT * (d.F2 / 80)), dim3(512), 0, st, a3);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), grid((long)BT * (d.F2 / 80)), dim3(256), 0, st, a3);
+            if (pipe) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<2, 80, false>), grid((long)BT * (d.F1 / 80)), dim3(512), 0, st, a2);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), grid((long)BT * (d.F1 / 80)), dim3(256), 0, st, a2);
+            if (pipe) hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<3, 96, true>), grid((long)BT * (d.Ec / 96)), dim3(512), 0, st, a1);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<3, 96, true>), grid((long)BT * (d.Ec / 96)), dim3(256), 0, st, a1);
+        }
         MaskFinArgs mf{w.d1.p, w.m.p, m->c0out_bias, BT * d.Ec, d.Ec, d.E, d.is48};
         hipLaunchKernelGGL(mask_fin_kernel, dim3((BT * d.Ec + 255) / 256), dim3(256), 0, st, mf);
         return;
@@ -2236,6 +2244,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "dec_seg") m->dec_seg = value;
     else if (n == "conv0_frames") m->conv0_frames = value;
     else if (n == "dec_seg_grid") m->dec_seg_grid = value > 0 ? value : 256;
+    else if (n == "dec_seg_all_frames") m->dec_seg_all_frames = value;
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "hoist_gi") m->hoist_gi = value != 0;
     else if (n == "scan4_max_wgs") m->scan4_max_wgs = value < 0 ? 0 : value;

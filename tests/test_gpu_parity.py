@@ -381,7 +381,7 @@ def test_throughput_regime_chunk_schedule_matches_whole_sequence_and_oracle(be):
 def test_48khz_decoder_stage_forms_agree_and_match_the_oracle(be):
     """The 48 kHz decoder stages (40 -> 80 -> 160 -> 480 bands + the mask head's tap sums) exist three times: gemm_rows launches with
     sub-pixel producers (dec_seg = 0), band-segment tiles with inputs read once (1: dec_last.h dec_seg_kernel) and the tile pipeline of
-    dec_seg2.h (2, the default from 1024 frames per chunk on).  97 clips x 11-frame chunks (1067 frames: 1067 / 2134 / 5335 tiles over 256
+    dec_seg2.h (2, the default from 1024 frames per chunk on; 3: its three stages in one launch).  97 clips x 11-frame chunks (1067 frames: 1067 / 2134 / 5335 tiles over 256
     workgroups -- uneven shares, a ragged last chunk of 4 frames falls back to the small forms), stage tensors and waveforms against
     each other, three clips against the oracle."""
     from oracle import oracle as orc
@@ -393,12 +393,14 @@ def test_48khz_decoder_stage_forms_agree_and_match_the_oracle(be):
     wav = np.stack([synth_clip(n, sr, 5100 + i) * (0.4 + (i % 5) / 5.0) for i in range(B)]).astype(np.float32)
     m.set_chunk_frames(11)
     outs, masks = {}, {}
-    for form in (2, 1, 0, 2):
+    m.set_option("dec_seg_all_frames", 0)
+    for form in (2, 1, 0, 2, 3):
         m.set_option("dec_seg", form)
         out = m.enhance_batch(wav, 6.0)
         if form in outs:
             np.testing.assert_array_equal(out, outs[form])          # run to run
         outs[form], masks[form] = out, m.debug_fetch("m")
+    np.testing.assert_array_equal(outs[3], outs[2])                  # the one-launch form runs the same code on the same tiles
     for form in (1, 0):
         assert rms(outs[2] - outs[form]) < 1e-6, form
         assert np.abs(masks[2] - masks[form]).max() < 2e-5, form

@@ -1,5 +1,5 @@
 """A/B of the 48 kHz decoder stage kernels inside the pipeline: dec_seg = 1 (dec_last.h: dec_seg_kernel) against 2 (dec_seg2.h, tile-
-pipelined), same process, interleaved; 256 x 10 s clips.  python tools/dec_seg_ab.py [nb]"""
+pipelined, three launches) and 3 (one launch), same process, interleaved; 256 x 10 s clips.  python tools/dec_seg_ab.py [nb]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
@@ -11,7 +11,7 @@ N = 10 * sr
 wav = torch.from_numpy((0.05 * np.random.default_rng(1).standard_normal((B, N))).astype(np.float32)).cuda()
 out = torch.empty_like(wav)
 ref = None
-settings = [(1, 256), (2, 256), (2, 512), (2, 128), (1, 256), (2, 256)]
+settings = [(1, 256), (2, 256), (3, 256), (3, 512), (1, 256), (2, 256), (3, 256)]
 for seg, grid in settings:
     m.set_option("dec_seg", seg); m.set_option("dec_seg_grid", grid)
     m.enhance_batch_device(wav.data_ptr(), B, N, out.data_ptr(), None); m.sync()

@@ -45,7 +45,7 @@ static void run(int BT, int FO) {
     const float t0 = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<S, R, LAST>), dim3((unsigned)std::min<long>(ntiles, 2048)), dim3(256), 0, 0, a); }, 5);
     printf("S %d R %d FO %3d  %ld tiles  %.2f GB   dec_seg_kernel       %7.3f ms  %6.0f GB/s\n", S, R, FO, ntiles, gb, t0, gb / t0 * 1e3);
     for (int grid : {256, 1024, 2048}) {
-        const float t1 = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<S, R, LAST>), dim3((unsigned)std::min<long>(ntiles, grid)), dim3(512), 0, 0, b); }, 5);
+        const float t1 = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<S, R, LAST>), dim3((unsigned)std::min<long>(BT, grid)), dim3(512), 0, 0, b); }, 5);
         printf("                                 dec_seg2 grid %4d   %7.3f ms  %6.0f GB/s  (var %d)\n", grid, t1, gb / t1 * 1e3, DS2_VAR);
     }
     std::vector<float> h0(nout), h1(nout);
@@ -59,8 +59,42 @@ static void run(int BT, int FO) {
     (void)hipFree(e); (void)hipFree(prev); (void)hipFree(out0); (void)hipFree(out1); (void)hipFree(e0);
 }
 
+// the three stages chained as in the engine (d3 -> d2 -> tap sums): three dec_seg_kernel launches, three dec_seg2_kernel launches, one dec_seg2_all_kernel
+static void run_chain(int BT) {
+    const size_t n3 = (size_t)BT * 40 * 64, n2 = (size_t)BT * 80 * 64, n1 = (size_t)BT * 160 * 64, n0 = (size_t)BT * 480 * 64, ns = (size_t)BT * 480 * 4;
+    float *e3, *emb, *e2, *e1, *e0, *d3[3], *d2[3], *ss[3];
+    (void)hipMalloc(&e3, n3 * 4); (void)hipMalloc(&emb, n3 * 4); (void)hipMalloc(&e2, n2 * 4); (void)hipMalloc(&e1, n1 * 4); (void)hipMalloc(&e0, n0 * 4);
+    for (int k = 0; k < 3; ++k) { (void)hipMalloc(&d3[k], n2 * 4); (void)hipMalloc(&d2[k], n1 * 4); (void)hipMalloc(&ss[k], ns * 4); (void)hipMemset(ss[k], 0xff, ns * 4); }
+    fill_kernel<<<2048, 256>>>(e3, n3, 1u); fill_kernel<<<2048, 256>>>(emb, n3, 2u); fill_kernel<<<2048, 256>>>(e2, n2, 3u);
+    fill_kernel<<<2048, 256>>>(e1, n1, 4u); fill_kernel<<<2048, 256>>>(e0, n0, 5u);
+    const float *ps = dev_rand(64, 1.f), *pb = dev_rand(64, 0.3f), *dw2 = dev_rand(2 * 64 * 3, 0.5f), *dw3 = dev_rand(3 * 64 * 3, 0.5f), *pw = dev_rand(64 * 64, 0.15f), *bi = dev_rand(64, 0.2f), *w0 = dev_rand(64 * 3, 0.3f);
+    auto A3 = [&](int k) { return DecSegArgs{e3, emb, d3[k], ps, pb, dw2, pw, bi, nullptr, nullptr, nullptr, nullptr, nullptr, BT, 80}; };
+    auto A2 = [&](int k) { return DecSegArgs{e2, d3[k], d2[k], ps, pb, dw2, pw, bi, nullptr, nullptr, nullptr, nullptr, nullptr, BT, 160}; };
+    auto A1 = [&](int k) { return DecSegArgs{e1, d2[k], nullptr, ps, pb, dw3, pw, bi, e0, ss[k], ps, pb, w0, BT, 480}; };
+    const float t0 = time_ms([&] {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), dim3((unsigned)std::min<long>(BT, 2048)), dim3(256), 0, 0, A3(0));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<2, 80, false>), dim3((unsigned)std::min<long>(2L * BT, 2048)), dim3(256), 0, 0, A2(0));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg_kernel<3, 96, true>), dim3((unsigned)std::min<long>(5L * BT, 2048)), dim3(256), 0, 0, A1(0)); }, 5);
+    const float t1 = time_ms([&] {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<2, 80, false>), dim3((unsigned)std::min(BT, 256)), dim3(512), 0, 0, A3(1));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<2, 80, false>), dim3((unsigned)std::min(BT, 256)), dim3(512), 0, 0, A2(1));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dec_seg2_kernel<3, 96, true>), dim3((unsigned)std::min(BT, 256)), dim3(512), 0, 0, A1(1)); }, 5);
+    const float t2 = time_ms([&] { hipLaunchKernelGGL(dec_seg2_all_kernel, dim3((unsigned)std::min(BT, 256)), dim3(512), 0, 0, A3(2), A2(2), A1(2)); }, 5);
+    printf("chain, %d frames: dec_seg_kernel x 3 %.3f ms | dec_seg2_kernel x 3 %.3f ms | dec_seg2_all_kernel %.3f ms\n", BT, t0, t1, t2);
+    std::vector<float> h0(ns), h1(ns), h2(ns), g1(n1), g2(n1);
+    (void)hipMemcpy(h0.data(), ss[0], ns * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(h1.data(), ss[1], ns * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(h2.data(), ss[2], ns * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(g1.data(), d2[1], n1 * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(g2.data(), d2[2], n1 * 4, hipMemcpyDeviceToHost);
+    size_t bad12 = 0, badd = 0; double dmax = 0;
+    for (size_t i = 0; i < ns; ++i) { bad12 += memcmp(&h1[i], &h2[i], 4) != 0; const double d = fabs((double)h0[i] - h2[i]); if (d > dmax) dmax = d; }
+    for (size_t i = 0; i < n1; ++i) badd += memcmp(&g1[i], &g2[i], 4) != 0;
+    printf("        one launch vs three dec_seg2 launches: %zu tap-sum words and %zu d2 words differ; max |tap sum - dec_seg_kernel's| %.3g\n", bad12, badd, dmax);
+    (void)hipFree(e3); (void)hipFree(emb); (void)hipFree(e2); (void)hipFree(e1); (void)hipFree(e0);
+    for (int k = 0; k < 3; ++k) { (void)hipFree(d3[k]); (void)hipFree(d2[k]); (void)hipFree(ss[k]); }
+}
+
 int main(int argc, char** argv) {
     const int BT = argc > 1 ? atoi(argv[1]) : 49152;          // 256 clips x a 192-frame chunk
+    run_chain(BT); run_chain(1067);
     const bool quick = argc > 2;                              // timing builds: the two big shapes only
     if (!quick) run<2, 80, false>(BT, 80);
     run<2, 80, false>(BT, 160);
