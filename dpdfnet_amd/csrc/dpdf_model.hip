@@ -396,7 +396,6 @@ struct dpdf_model {
                                        // (dec_seg2_all_kernel; A/B: holding every CU for the whole decoder costs stage 1 more than the two re-acquisitions cost stage 2: 131.0 -> 134.1 ms/step);
                                        // 1 = dec_last.h: dec_seg_kernel, 0 = gemm_rows producers
     int dec_seg_all_frames = 8192;     // ... one launch from this many frames per chunk on
-    int conv0_frames = 256;            // erb_conv0 as a workgroup per frame (conv0_erb_frames_kernel) from this many frames per chunk on (0: conv0_erb_kernel)
     int dec_seg_grid = 256;            // dec_seg2 workgroups (512 threads, 110 / 149 KB of LDS: one per CU)
     int fuse_mask = 1;                 // mask head's 64->1 contraction in the convt1 epilogue (0: stand-alone mask_out_kernel, A/B)
     int fuse_dprnn = 1;                // fc + LayerNorm + residual fused into the GRU-64 scans: 0 never (separate GEMM kernels),
@@ -1497,8 +1496,7 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
         } else {
             Conv0ErbArgs ca{w.feat_erb.p, x.e0.p, m->C(m->conv0_w), m->C(m->conv0_b), B, Tc, d.E, d.Ec};
             size_t rows16 = ((size_t)BT * d.Ec + 15) / 16;
-            if (m->conv0_frames && d.Ec <= CONV0_MAX_EC && BT >= m->conv0_frames) hipLaunchKernelGGL(conv0_erb_frames_kernel, dim3((unsigned)std::min<long>(BT, 2048)), dim3(256), 0, sC, ca);
-            else hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)std::min<size_t>(rows16, 8192)), dim3(256), 0, sC, ca);
+            hipLaunchKernelGGL(conv0_erb_kernel, dim3((unsigned)std::min<size_t>(rows16, 8192)), dim3(256), 0, sC, ca);
             run_dwconv_s(m, m->erb_conv1, e0v, e1v, B, Tc, d.s1);
             run_dwconv_s(m, m->erb_conv2, e1v, e2v, B, Tc, d.s2);
             run_dwconv_s(m, m->erb_conv3, e2v, e3v, B, Tc, d.s3);
@@ -2242,7 +2240,6 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     const std::string n(name);
     if (n == "fuse_mask") m->fuse_mask = value != 0;
     else if (n == "dec_seg") m->dec_seg = value;
-    else if (n == "conv0_frames") m->conv0_frames = value;
     else if (n == "dec_seg_grid") m->dec_seg_grid = value > 0 ? value : 256;
     else if (n == "dec_seg_all_frames") m->dec_seg_all_frames = value;
     else if (n == "df_ring") m->df_ring = value < 0 ? 0 : (value > 2 ? 2 : value);

@@ -229,48 +229,6 @@ __global__ __launch_bounds__(256) void conv0_erb_kernel(Conv0ErbArgs a) {
     }
 }
 
-// The same convolution, a workgroup per FRAME: conv0_erb_kernel derives (clip, frame, band) of every row from a 64-bit row index -- two
-// 64-bit divisions per thread and row, ~200 integer instructions around 36 FMAs, which holds it at 2.4 TB/s of e0 written (48 kHz: 31.5 GB
-// per 256 x 10 s step).  Here the frame is fixed per workgroup pass (one 32-bit division, scalar), its three feature rows go through LDS
-// once (zero-padded at both ends, double-buffered: one barrier per frame), a thread walks the bands in steps of 16.  Same FMA order per
-// output (the out-of-range taps add w x 0 as there): bit-identical.
-constexpr int CONV0_MAX_EC = 512;
-__global__ __launch_bounds__(256) void conv0_erb_frames_kernel(Conv0ErbArgs a) {
-    __shared__ float X[2][3][CONV0_MAX_EC + 2];
-    const int c4 = (threadIdx.x & 15) * 4, r16 = threadIdx.x >> 4;
-    float w[4][9];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) w[j][k] = a.w[(c4 + j) * 9 + k];
-    const float4 bias = *(const float4*)(a.bias + c4);
-    const int frames = a.B * a.Tc;
-    int buf = 0;
-    for (int bt = blockIdx.x; bt < frames; bt += gridDim.x, buf ^= 1) {
-        const int b = bt / a.Tc, t = bt - b * a.Tc;
-        const float* src = a.feat + ((size_t)b * (a.Tc + 2) + t) * a.E;
-        for (int i = threadIdx.x; i < 3 * (a.Ec + 2); i += 256) {
-            const int kt = i / (a.Ec + 2), fi = i - kt * (a.Ec + 2) - 1;
-            X[buf][kt][fi + 1] = (fi >= 0 && fi < a.Ec) ? src[(size_t)kt * a.E + fi] : 0.f;
-        }
-        __syncthreads();
-        float* dst = a.e0 + (size_t)bt * a.Ec * 64 + c4;
-        for (int f = r16; f < a.Ec; f += 16) {
-            float4 acc = bias;
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                for (int kf = 0; kf < 3; ++kf) {
-                    const float x = X[buf][kt][f + kf];
-                    acc.x += w[0][kt * 3 + kf] * x; acc.y += w[1][kt * 3 + kf] * x;
-                    acc.z += w[2][kt * 3 + kf] * x; acc.w += w[3][kt * 3 + kf] * x;
-                }
-            acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-            *(float4*)(dst + (size_t)f * 64) = acc;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // mask-decoder tail: u = relu(ps*e0 + pb) + d1 ; m = sigmoid(bias + sum_{c,k} w[c][k] u[f+k-1][c])
 // (conv0p pathway + conv0_out dense 64->1 k(1,3) + BN + Sigmoid, reference

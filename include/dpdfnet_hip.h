@@ -193,8 +193,7 @@ int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
 /* Further A/B switches by name (measurement only; results equal to rounding): "fuse_mask" (1: the mask head's 64->1
  * contraction runs in the last decoder stage's epilogue, 0: stand-alone kernel), "dec_seg" (the 48 kHz decoder stages: 2 =
  * band-segment tiles pipelined inside one workgroup, dec_seg2_kernel, on "dec_seg_grid" workgroups; 3 = the same in one launch
- * (slower in the pipeline); 1 = band-segment tiles, dec_seg_kernel; 0 = gemm_rows producers), "conv0_frames" (erb_conv0 as a workgroup per frame from this many frames per chunk on,
- * default 256; 0: one thread group per row, conv0_erb_kernel), "df_ring" (df_conv0 + df_conv1 + DF pathway conv as one
+ * (slower in the pipeline); 1 = band-segment tiles, dec_seg_kernel; 0 = gemm_rows producers), "df_ring" (df_conv0 + df_conv1 + DF pathway conv as one
  * time-walking pass for big batches; 0: time-parallel GEMM launches), "hoist_gi" (small-batch GRU-64 input GEMM hoisting),
  * "scan4_max_wgs" (default 512: hoisted-input GRU-64 scans run on 4-row tiles, gru64_scan4_gi_kernel, while the launch has at
  * most this many workgroups; 0 never), "gru256_cluster" (0: single-workgroup GRU-256 scan, the form without cross-workgroup
