@@ -11,7 +11,7 @@ from dpdfnet_amd import backend as be
 from dpdfnet_amd.weights import synth_blob
 
 
-def run(budget: float = 60.0, seed: int = 1) -> dict:
+def run(budget: float = 60.0, seed: int = 1, min_cases: int = 0) -> dict:
     rng = np.random.default_rng(seed)
     models = {}
 
@@ -22,7 +22,7 @@ def run(budget: float = 60.0, seed: int = 1) -> dict:
 
     t_end = time.time() + budget
     n = piped_cases = 0
-    while time.time() < t_end:
+    while time.time() < t_end or n < min_cases:       # (min_cases: a fixed floor of cases however slow the box)
         sr, nb = [(16000, 2), (16000, 4), (48000, 2), (16000, 0)][rng.integers(4)]
         m = model(sr, nb)
         hop = m.hop

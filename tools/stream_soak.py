@@ -13,11 +13,11 @@ PLAIN = {"single_chunk_inline": 0, "hop_prologue": 0, "late_export": 0, "dual_st
 
 def rms(x): return float(np.sqrt(np.mean(np.square(x.astype(np.float64)))))
 
-def run(seconds: float, seed: int) -> dict:
+def run(seconds: float, seed: int, min_cases: int = 0) -> dict:
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
     cases = calls = 0; worst = 0.0
-    while time.time() < t_end:
+    while time.time() < t_end or cases < min_cases:   # (min_cases: a fixed floor of cases however slow the box)
         sr, nb = [(16000, 2), (16000, 4), (48000, 1), (48000, 2)][int(rng.integers(4))]
         S = int(rng.choice([1, 2, 3, 4, 5, 8, 17, 64, 70]))
         blob = synth_blob(be.manifest(sr, nb), int(rng.integers(1 << 30)))

@@ -11,7 +11,7 @@ from dpdfnet_amd import backend as be
 from dpdfnet_amd.weights import synth_blob
 
 
-def run(budget: float = 60.0, seed: int = 1) -> dict:
+def run(budget: float = 60.0, seed: int = 1, min_cases: int = 0) -> dict:
     rng = np.random.default_rng(seed)
     models = {}
     def model(sr, nb):
@@ -24,7 +24,7 @@ def run(budget: float = 60.0, seed: int = 1) -> dict:
 
     t_end = time.time() + budget
     n = 0; worst = 0.0; worst_case = None
-    while time.time() < t_end:
+    while time.time() < t_end or n < min_cases:       # (min_cases: a fixed floor of cases however slow the box)
         sr, nb = [(16000, 2), (16000, 4), (16000, 8), (48000, 2), (48000, 8)][rng.integers(5)]
         m = model(sr, nb)
         B = int(rng.choice([1, 2, 3, 7, 16, 17, 33, 64, 65, 130, 257]))
@@ -33,9 +33,9 @@ def run(budget: float = 60.0, seed: int = 1) -> dict:
         F = m.freq_bins
         spec = (rng.standard_normal((B, T, F, 2)) * 3.0).astype(np.float32)
         st0 = np.tile(m.initial_state()[None, :], (B, 1))
-        m.set_overlap(0); m.set_fuse_dprnn("never"); m.set_chunk_frames(-1); m.set_option("gru256_fused_x", 0)
+        m.set_overlap(0); m.set_fuse_dprnn("never"); m.set_chunk_frames(-1); m.set_option("gru256_fused_x", 0); m.set_option("dec_seg", 0)
         ref, sref = m.run_frames(spec, st0.copy())
-        m.set_overlap(27); m.set_fuse_dprnn("auto"); m.set_chunk_frames(int(rng.choice([0, 0, 1, 2, 7, 64]))); m.set_option("gru256_fused_x", 1)
+        m.set_overlap(27); m.set_fuse_dprnn("auto"); m.set_chunk_frames(int(rng.choice([0, 0, 1, 2, 7, 64]))); m.set_option("gru256_fused_x", 1); m.set_option("dec_seg", 2)
         out, s1 = m.run_frames(spec, st0.copy())
         out2, s2 = m.run_frames(spec, st0.copy())
         scale = float(np.abs(ref).max()) + 1e-12
