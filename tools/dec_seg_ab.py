@@ -11,7 +11,7 @@ N = 10 * sr
 wav = torch.from_numpy((0.05 * np.random.default_rng(1).standard_normal((B, N))).astype(np.float32)).cuda()
 out = torch.empty_like(wav)
 ref = None
-settings = [(1, 256), (2, 256), (3, 256), (3, 512), (1, 256), (2, 256), (3, 256)]
+settings = [(2, 256), (2, 224), (2, 192), (2, 320), (2, 384), (2, 256), (2, 224)] if len(sys.argv) > 2 else [(1, 256), (2, 256), (3, 256), (3, 512), (1, 256), (2, 256), (3, 256)]
 for seg, grid in settings:
     m.set_option("dec_seg", seg); m.set_option("dec_seg_grid", grid)
     m.enhance_batch_device(wav.data_ptr(), B, N, out.data_ptr(), None); m.sync()
