@@ -9,7 +9,12 @@
 // The pointwise is split by (row tile, 16 output columns): wave w owns columns [16 (w & 3), + 16) -- 16 B fragments instead of 64 -- and
 // the first (w < 4) or second half of the row tiles, so the two waves of a SIMD together issue a quarter of the tile's matrix
 // instructions whatever the number of row tiles; waves 0-3 start a tick with their matrix work, waves 4-7 end with it.  Every output
-// element is accumulated in the order dec_seg_kernel uses: results are bit-identical.
+// element of the pointwise is accumulated in the order dec_seg_kernel uses: stages 3 and 2 (LAST = false) are bit-identical to it.
+// LAST (convt1 + the mask head): e0 passes through a ring of THREE LDS buffers -- relu(ps0 e0 + pb0) written a tick ahead, u0 = relu(d1) + that
+// formed in place by the lane that owns the element, the three tap sums of conv0_out taken a tick later by four threads per row (sixteen
+// channels each, two quad DPP steps) instead of dec_seg_kernel's DPP row reductions on the accumulators: equal to rounding (4e-8 RMS).
+// Frames are dealt to workgroups (frame b0 + k G: all its tiles), 110 KB (LAST: 149 KB) of LDS, one workgroup per CU.
+// Measured: DESIGN.md section 3b, tools/dec_seg_bench.hip, docs/HISTORY.md (round-5 ledger: what was tried around it).
 #pragma once
 #include "common.h"
 #include "dec_last.h"
