@@ -770,6 +770,20 @@ class CollectiveWatchdog:
         reexec_with_gloo_fallback(f"no answer within {seconds:g} s at stage `{self._stage}`")
 
 
+def multi_gpu_summary(per_rank: list) -> dict:
+    """What a first hardware scaling curve needs to be read without a re-run: the spread of the ranks' own step times and what the
+    gather to rank 0 costs (device-side duration of the grouped receive on rank 0 -- it overlaps the next step's compute -- and as a
+    fraction of the slowest rank's step)."""
+    ms = [r["ms_per_step"] for r in per_rank if isinstance(r, dict)]
+    if not ms:
+        return {}
+    root = next((r for r in per_rank if isinstance(r, dict) and r.get("rank") == 0), None)
+    g = root.get("gather_device_ms_per_step") if root else None
+    return {"per_rank_ms_min": min(ms), "per_rank_ms_max": max(ms), "per_rank_ms_spread": (max(ms) - min(ms)) / max(ms),
+            "gather_ms_per_step_root_device": g, "gather_frac_of_step": (g / max(ms)) if g is not None else None,
+            "gather_host_ms_per_step_max": max(r.get("gather_host_ms_per_step", 0.0) for r in per_rank if isinstance(r, dict))}
+
+
 def main() -> None:
     if os.environ.get("DPDF_BENCH_TRACE_HANG"):          # debugging aid: every thread's Python stack on stderr after that many seconds
         import faulthandler
@@ -1002,14 +1016,17 @@ def main() -> None:
         dist.barrier()
     sync()
     gather_ms = 0.0
+    gather_events = []                 # (start, end) on torch's current stream around every timed gather: its device-side duration
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
         if gather_in_timed:
             model.sync()          # host waits for this rank's step i; the gather below is asynchronous (RCCL's stream),
             tg = time.perf_counter()
+            ev0 = torch.cuda.Event(enable_timing=True); ev0.record()
             gathered = gather_to_root(outs[i & 1], world, rank, gathered)   # so it runs under the compute of step i+1
-            ev = torch.cuda.Event(); ev.record(); gather_done[i & 1] = ev
+            ev = torch.cuda.Event(enable_timing=True); ev.record(); gather_done[i & 1] = ev
+            gather_events.append((ev0, ev))
             gather_ms += 1e3 * (time.perf_counter() - tg)
     sync()
     if world > 1:
@@ -1025,7 +1042,9 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         allms = [None] * world
-        dist.all_gather_object(allms, {"rank": rank, "ms_per_step": 1e3 * dt_local / args.steps, "gather_host_ms_per_step": gather_ms / args.steps})
+        gather_dev_ms = (sum(a.elapsed_time(b) for a, b in gather_events) / len(gather_events)) if gather_events else None
+        dist.all_gather_object(allms, {"rank": rank, "ms_per_step": 1e3 * dt_local / args.steps, "gather_host_ms_per_step": gather_ms / args.steps,
+                                       "gather_device_ms_per_step": gather_dev_ms})
         per_rank_ms = sorted(allms, key=lambda r: r["rank"])
     # the LAST timed step's output, copied out before anything else touches the buffers (parity block below)
     parity_slots = sorted({0, B // 2, B - 1})
@@ -1195,7 +1214,7 @@ def main() -> None:
             line["multi_gpu"] = {"backend": "rccl" if args.backend == "nccl" else (args.backend + (" (FALLBACK: RCCL did not answer)" if fallback else "")),
                                  "fallback_reason": args.fallback_reason or None, "fallback_gather_ms_once_outside_timed_region": fallback_gather_ms,
                                  "gather_inside_timed_region": bool(gather_in_timed), "rccl_ranks": rccl_ranks,
-                                 "per_rank": per_rank_ms, "collective_ok": bool(do_gather) if not args.no_gather else None,
+                                 "per_rank": per_rank_ms, **multi_gpu_summary(per_rank_ms), "collective_ok": bool(do_gather) if not args.no_gather else None,
                                  "collective_error": collective_error, "gathered_matches_rank_outputs": gather_check,
                                  "gathered_shape": list(gathered.shape) if gathered is not None else None}
         ks = kernel_stats(prof, psteps) if prof else {}

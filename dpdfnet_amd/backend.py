@@ -612,17 +612,33 @@ class HipStreams:
         _check(self.model._L.dpdf_streams_pool_timing(self._h, a))
         return float(a[0]), float(a[1]), float(a[2])
 
+    def _hops(self, pcm, k: int, what: str) -> np.ndarray:
+        """float32, contiguous, exactly k whole hops: the library reads k * hop floats from the pointer, whatever the array holds."""
+        k = int(k)
+        if k <= 0:
+            raise ValueError(f"{what}: hop count must be positive, got {k}")
+        a = np.ascontiguousarray(pcm, dtype=np.float32).reshape(-1)
+        if a.size != k * self.model.hop:
+            raise ValueError(f"{what}: expected {k} x {self.model.hop} = {k * self.model.hop} samples, got {a.size}")
+        return a
+
     def submit_wait(self, slot: int, pcm: np.ndarray, k: int, no_window: bool = False) -> np.ndarray:
-        """k whole hops (float32, contiguous) for one slot -> its k * hop enhanced samples; rides in the round other threads' submissions
-        for this stream set are in (ONE masked device call per round)."""
-        out = np.empty(k * self.model.hop, dtype=np.float32)
+        """k whole hops for one slot -> its k * hop enhanced samples; rides in the round other threads' submissions for this stream
+        set are in (ONE masked device call per round)."""
+        pcm = self._hops(pcm, k, "submit_wait")
+        out = np.empty(int(k) * self.model.hop, dtype=np.float32)
         _check(self.model._L.dpdf_streams_submit_wait(self._h, int(slot), pcm.ctypes.data, int(k), out.ctypes.data, 1 if no_window else 0))
         return out
 
     def submit_block(self, slots: np.ndarray, block: np.ndarray, k: int, no_window: bool = False) -> np.ndarray:
-        """n = len(slots) requests of k hops each, rows of `block` [n, k * hop] (float32, contiguous) -> [n, k * hop]."""
+        """n = len(slots) requests of k hops each, rows of `block` [n, k * hop] -> [n, k * hop]."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32).reshape(-1)
+        n = int(slots.shape[0])
+        block = self._hops(block, int(k) * n, "submit_block").reshape(n, int(k) * self.model.hop) if n else np.zeros((0, int(k) * self.model.hop), np.float32)
         out = np.empty(block.shape, dtype=np.float32)
-        rc = self.model._L.dpdf_streams_submit_block(self._h, slots.shape[0], slots.ctypes.data, block.ctypes.data, k, out.ctypes.data,
+        if n == 0:
+            return out
+        rc = self.model._L.dpdf_streams_submit_block(self._h, n, slots.ctypes.data, block.ctypes.data, int(k), out.ctypes.data,
                                                      1 if no_window else 0)
         if rc:
             _check(rc)
@@ -631,7 +647,10 @@ class HipStreams:
     def submit_many(self, slots: Sequence[int], rows: Sequence[np.ndarray], ks: Sequence[int], no_window: bool = False) -> List[np.ndarray]:
         """Requests with different hop counts: rows[i] holds ks[i] whole hops for slots[i]."""
         n = len(slots)
+        if len(rows) != n or len(ks) != n:
+            raise ValueError(f"submit_many: {n} slots, {len(rows)} rows, {len(ks)} hop counts")
         hop = self.model.hop
+        rows = [self._hops(r, k, f"submit_many[{i}]") for i, (r, k) in enumerate(zip(rows, ks))]
         outs = [np.empty(int(k) * hop, dtype=np.float32) for k in ks]
         sl = (ctypes.c_int * n)(*[int(x) for x in slots]); kk = (ctypes.c_int * n)(*[int(k) for k in ks])
         ip = (ctypes.c_void_p * n)(*[r.ctypes.data for r in rows]); op = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])

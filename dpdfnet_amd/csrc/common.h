@@ -38,23 +38,21 @@ __device__ __forceinline__ float gru64_cell(float ar, float az, float axn, float
     return __builtin_fmaf(z, h - n, n);
 }
 
-// An agent-scope, single-dword load.  Used for the deep-filter taps in df_apply / mask_df / the FIFO export: with the faster stage 1 of
-// round 5, multi-chunk batches showed single wrong low-band frames in a few clips per run (never the same twice) whenever df_apply read
-// its ten taps through the loads the compiler merges them into -- two UNDER-ALIGNED global_load_dwordx4 + one dwordx2 (records of 40 bytes:
-// 8-byte aligned): 23-36 bad clips of 256 per run; with ten single-dword loads (volatile or agent-scope) none, in every run since.  What
-// it is not: stamps written behind df_out's rows show df_apply never ran ahead of them; per-row checksums at the end of the chunk's stage 2
-// show taps, their inputs and every other tensor correct; probes of under-aligned vector loads on static buffers and on lines freshly
-// written piecewise from two XCDs (tools/misaligned_load_probe.hip, tools/xcd_line_sharing_probe.hip) return the right bytes.  The
-// mechanism is NOT established; DESIGN.md section 6.
+// An agent-scope, single-dword load: for values another workgroup of a RUNNING launch (or a kernel of another stream that is still
+// running) has written.  (Round 5 read the deep-filter taps of df_apply / mask_df through it as a guard against a corruption whose cause
+// was not known; round 6 found the cause -- packed FP32 arithmetic, not memory: DESIGN.md section 6 -- and those kernels read plain again.)
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // K index supplied by lane-quad q (= lane>>4) for MFMA kb (0..3) of 16-wide K chunk c.
 // All A fragments (4 contiguous floats per lane per chunk) and all packed B fragments use it.
 __host__ __device__ inline int kperm(int c, int q, int kb) { return 16 * c + 4 * q + kb; }
 
+// ReLU that keeps a NaN (torch.relu(NaN) = NaN: the reference's frame function carries a NaN that has entered a clip through every layer and
+// state of that clip -- tests/golden/nonfinite_*.npz); fmaxf / v_max_f32 return the other operand.  v_cmp + v_cndmask instead of one v_max.
+__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
 __device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_RELU) return relu_f(v);
     if (act == ACT_TANH) return tanh_f(v);
     if (act == ACT_SIGMOID) return sigmoid_f(v);
     return v;

@@ -88,18 +88,18 @@ __global__ __launch_bounds__(256, 2) void dec_last_kernel(DecLastArgs a) {
         for (int i = 0; i < 2; ++i) {
             const int band = tid >> 4;                               // piece i: frame i, band tid>>4
             float4 u;
-            u.x = fmaxf(__builtin_fmaf(s1.x, ve1[i].x, b1.x), 0.f) + vd2[i].x;
-            u.y = fmaxf(__builtin_fmaf(s1.y, ve1[i].y, b1.y), 0.f) + vd2[i].y;
-            u.z = fmaxf(__builtin_fmaf(s1.z, ve1[i].z, b1.z), 0.f) + vd2[i].z;
-            u.w = fmaxf(__builtin_fmaf(s1.w, ve1[i].w, b1.w), 0.f) + vd2[i].w;
+            u.x = relu_f(__builtin_fmaf(s1.x, ve1[i].x, b1.x)) + vd2[i].x;
+            u.y = relu_f(__builtin_fmaf(s1.y, ve1[i].y, b1.y)) + vd2[i].y;
+            u.z = relu_f(__builtin_fmaf(s1.z, ve1[i].z, b1.z)) + vd2[i].z;
+            u.w = relu_f(__builtin_fmaf(s1.w, ve1[i].w, b1.w)) + vd2[i].w;
             *(float4*)&U1[i][1 + band][c4] = u;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (tid >> 4) + 16 * i;
             float4 u;
-            u.x = fmaxf(__builtin_fmaf(s0.x, ve0[i].x, b0.x), 0.f); u.y = fmaxf(__builtin_fmaf(s0.y, ve0[i].y, b0.y), 0.f);
-            u.z = fmaxf(__builtin_fmaf(s0.z, ve0[i].z, b0.z), 0.f); u.w = fmaxf(__builtin_fmaf(s0.w, ve0[i].w, b0.w), 0.f);
+            u.x = relu_f(__builtin_fmaf(s0.x, ve0[i].x, b0.x)); u.y = relu_f(__builtin_fmaf(s0.y, ve0[i].y, b0.y));
+            u.z = relu_f(__builtin_fmaf(s0.z, ve0[i].z, b0.z)); u.w = relu_f(__builtin_fmaf(s0.w, ve0[i].w, b0.w));
             *(float4*)&E0[row][c4] = u;
         }
         const int next = tile + gridDim.x;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void dec_last_kernel(DecLastArgs a) {
             float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const float u = fmaxf(acc[nt][i] + bv[nt], 0.f) + E0[row][nt * 16 + cl];
+                const float u = relu_f(acc[nt][i] + bv[nt]) + E0[row][nt * 16 + cl];
                 t0 = __builtin_fmaf(w0v[nt][0], u, t0); t1 = __builtin_fmaf(w0v[nt][1], u, t1); t2 = __builtin_fmaf(w0v[nt][2], u, t2);
             }
             t0 = row16_allreduce_sum(t0); t1 = row16_allreduce_sum(t1); t2 = row16_allreduce_sum(t2);
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(256, 2) void dec_stage_kernel(DecStageArgs a) {
         for (int i = 0; i < NL; ++i) {
             const int row = (tid >> 4) + 16 * i, fr = row / FI, band = row - fr * FI;
             float4 u;
-            u.x = fmaxf(__builtin_fmaf(s1.x, ve[i].x, b1.x), 0.f) + vp[i].x; u.y = fmaxf(__builtin_fmaf(s1.y, ve[i].y, b1.y), 0.f) + vp[i].y;
-            u.z = fmaxf(__builtin_fmaf(s1.z, ve[i].z, b1.z), 0.f) + vp[i].z; u.w = fmaxf(__builtin_fmaf(s1.w, ve[i].w, b1.w), 0.f) + vp[i].w;
+            u.x = relu_f(__builtin_fmaf(s1.x, ve[i].x, b1.x)) + vp[i].x; u.y = relu_f(__builtin_fmaf(s1.y, ve[i].y, b1.y)) + vp[i].y;
+            u.z = relu_f(__builtin_fmaf(s1.z, ve[i].z, b1.z)) + vp[i].z; u.w = relu_f(__builtin_fmaf(s1.w, ve[i].w, b1.w)) + vp[i].w;
             *(float4*)&U1[fr][1 + band][c4] = u;
         }
         const int next = tile + gridDim.x;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void dec_stage_kernel(DecStageArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) As[16 * w + 4 * q + i][nt * 16 + cl] = fmaxf(acc[nt][i] + bv[nt], 0.f);
+            for (int nt = 0; nt < 4; ++nt) As[16 * w + 4 * q + i][nt * 16 + cl] = relu_f(acc[nt][i] + bv[nt]);
         __syncthreads();
         {
             const size_t orow0 = (size_t)tile * 64, nrows = (size_t)a.BT * FO;
@@ -378,8 +378,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (row < RI + 2) {
                 float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (fi >= 0 && fi < FI) {
-                    u.x = fmaxf(__builtin_fmaf(s1.x, ve[i].x, b1.x), 0.f) + vp[i].x; u.y = fmaxf(__builtin_fmaf(s1.y, ve[i].y, b1.y), 0.f) + vp[i].y;
-                    u.z = fmaxf(__builtin_fmaf(s1.z, ve[i].z, b1.z), 0.f) + vp[i].z; u.w = fmaxf(__builtin_fmaf(s1.w, ve[i].w, b1.w), 0.f) + vp[i].w;
+                    u.x = relu_f(__builtin_fmaf(s1.x, ve[i].x, b1.x)) + vp[i].x; u.y = relu_f(__builtin_fmaf(s1.y, ve[i].y, b1.y)) + vp[i].y;
+                    u.z = relu_f(__builtin_fmaf(s1.z, ve[i].z, b1.z)) + vp[i].z; u.w = relu_f(__builtin_fmaf(s1.w, ve[i].w, b1.w)) + vp[i].w;
                 }
                 *(float4*)&U1[row][c4] = u;
             }
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int row = r16 + 16 * i;
                 if (row < R) {
                     float4 u;
-                    u.x = fmaxf(__builtin_fmaf(s0.x, ve0[i].x, b0.x), 0.f); u.y = fmaxf(__builtin_fmaf(s0.y, ve0[i].y, b0.y), 0.f);
-                    u.z = fmaxf(__builtin_fmaf(s0.z, ve0[i].z, b0.z), 0.f); u.w = fmaxf(__builtin_fmaf(s0.w, ve0[i].w, b0.w), 0.f);
+                    u.x = relu_f(__builtin_fmaf(s0.x, ve0[i].x, b0.x)); u.y = relu_f(__builtin_fmaf(s0.y, ve0[i].y, b0.y));
+                    u.z = relu_f(__builtin_fmaf(s0.z, ve0[i].z, b0.z)); u.w = relu_f(__builtin_fmaf(s0.w, ve0[i].w, b0.w));
                     *(float4*)&E0[row][c4] = u;
                 }
             }
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) As[16 * rt + 4 * q + i][nt * 16 + cl] = fmaxf(acc[nt][i] + bv[nt], 0.f);
+                    for (int nt = 0; nt < 4; ++nt) As[16 * rt + 4 * q + i][nt * 16 + cl] = relu_f(acc[nt][i] + bv[nt]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        const float u = fmaxf(acc[nt][i] + bv[nt], 0.f) + E0[lr][nt * 16 + cl];
+                        const float u = relu_f(acc[nt][i] + bv[nt]) + E0[lr][nt * 16 + cl];
                         t0 = __builtin_fmaf(w0v[nt][0], u, t0); t1 = __builtin_fmaf(w0v[nt][1], u, t1); t2 = __builtin_fmaf(w0v[nt][2], u, t2);
                     }
                     t0 = row16_allreduce_sum(t0); t1 = row16_allreduce_sum(t1); t2 = row16_allreduce_sum(t2);

@@ -84,7 +84,7 @@ __device__ __forceinline__ void dec_pyr_stage(const float (*U)[68], const float 
             const int row = rt * 16 + 4 * q + i, g = fo0 + row, su = row - OFF;
             if (row < NROW && su >= 0 && su < NNEXT) {
                 float v = 0.f;
-                if (g >= 0 && g < Fout) v = fmaxf(acc[i] + bv, 0.f) + fmaxf(__builtin_fmaf(sn, skip.v[rt][i], bn), 0.f);
+                if (g >= 0 && g < Fout) v = relu_f(acc[i] + bv) + relu_f(__builtin_fmaf(sn, skip.v[rt][i], bn));
                 Unext[su][16 * w + cl] = v;
             }
         }
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void dec_pyr_kernel(DecPyrArgs a) {
             float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f >= 0 && f < a.F3) {
                 const float4 e = *(const float4*)(e3 + (size_t)f * 64 + c4), p = *(const float4*)(de + (size_t)f * 64 + c4);
-                u.x = fmaxf(__builtin_fmaf(s4.x, e.x, b4.x), 0.f) + p.x; u.y = fmaxf(__builtin_fmaf(s4.y, e.y, b4.y), 0.f) + p.y;
-                u.z = fmaxf(__builtin_fmaf(s4.z, e.z, b4.z), 0.f) + p.z; u.w = fmaxf(__builtin_fmaf(s4.w, e.w, b4.w), 0.f) + p.w;
+                u.x = relu_f(__builtin_fmaf(s4.x, e.x, b4.x)) + p.x; u.y = relu_f(__builtin_fmaf(s4.y, e.y, b4.y)) + p.y;
+                u.z = relu_f(__builtin_fmaf(s4.z, e.z, b4.z)) + p.z; u.w = relu_f(__builtin_fmaf(s4.w, e.w, b4.w)) + p.w;
             }
             *(float4*)&U3[r][c4] = u;
         }

@@ -115,8 +115,8 @@ __device__ __forceinline__ void dec_seg2_body(const DecSegArgs& a, float* lds) {
             const int row = r32 + 32 * i;
             if (row < NIN) {
                 float4 u;
-                u.x = fmaxf(__builtin_fmaf(s1.x, ve[i].x, b1.x), 0.f) + vp[i].x; u.y = fmaxf(__builtin_fmaf(s1.y, ve[i].y, b1.y), 0.f) + vp[i].y;
-                u.z = fmaxf(__builtin_fmaf(s1.z, ve[i].z, b1.z), 0.f) + vp[i].z; u.w = fmaxf(__builtin_fmaf(s1.w, ve[i].w, b1.w), 0.f) + vp[i].w;
+                u.x = relu_f(__builtin_fmaf(s1.x, ve[i].x, b1.x)) + vp[i].x; u.y = relu_f(__builtin_fmaf(s1.y, ve[i].y, b1.y)) + vp[i].y;
+                u.z = relu_f(__builtin_fmaf(s1.z, ve[i].z, b1.z)) + vp[i].z; u.w = relu_f(__builtin_fmaf(s1.w, ve[i].w, b1.w)) + vp[i].w;
                 if ((first && in_lo[i]) || (last && in_hi[i])) u = make_float4(0.f, 0.f, 0.f, 0.f);
                 *(float4*)&U1[ub][row][c4] = u;
             }
@@ -157,12 +157,12 @@ __device__ __forceinline__ void dec_seg2_body(const DecSegArgs& a, float* lds) {
             }
             if (!LAST) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) Os[ab][16 * rt + 4 * q + i][nt * 16 + cl] = fmaxf(acc[i] + bvn, 0.f);
+                for (int i = 0; i < 4; ++i) Os[ab][16 * rt + 4 * q + i][nt * 16 + cl] = relu_f(acc[i] + bvn);
             } else {            // u0 = relu(d1) + relu(ps0 e0 + pb0), in place (this lane is the element's only reader and writer)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float* ep = &E0[eb][16 * rt + 4 * q + i][nt * 16 + cl];
-                    *ep = fmaxf(acc[i] + bvn, 0.f) + *ep;
+                    *ep = relu_f(acc[i] + bvn) + *ep;
                 }
             }
         }
@@ -175,8 +175,8 @@ __device__ __forceinline__ void dec_seg2_body(const DecSegArgs& a, float* lds) {
             const int row = r32 + 32 * i;
             if (row < R) {
                 float4 u;
-                u.x = fmaxf(__builtin_fmaf(s0.x, ve0[i].x, b0v.x), 0.f); u.y = fmaxf(__builtin_fmaf(s0.y, ve0[i].y, b0v.y), 0.f);
-                u.z = fmaxf(__builtin_fmaf(s0.z, ve0[i].z, b0v.z), 0.f); u.w = fmaxf(__builtin_fmaf(s0.w, ve0[i].w, b0v.w), 0.f);
+                u.x = relu_f(__builtin_fmaf(s0.x, ve0[i].x, b0v.x)); u.y = relu_f(__builtin_fmaf(s0.y, ve0[i].y, b0v.y));
+                u.z = relu_f(__builtin_fmaf(s0.z, ve0[i].z, b0v.z)); u.w = relu_f(__builtin_fmaf(s0.w, ve0[i].w, b0v.w));
                 *(float4*)&E0[eb][row][c4] = u;
             }
         }

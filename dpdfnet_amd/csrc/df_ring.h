@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 3) void df_ring_kernel(DfRingArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     const int r = mt * 16 + q * 4 + i;
                     if (r < 33) {
-                        const float v = (r == 0 && f0 == 0) ? 0.f : fmaxf(c0acc[mt][i] + c0b, 0.f);
+                        const float v = (r == 0 && f0 == 0) ? 0.f : relu_f(c0acc[mt][i] + c0b);
                         R[slot][r][16 * w + cl] = v;
                         if (keep && r >= 1) a.c0[(((size_t)b * (a.Tc + 4) + 4 + t) * D + f0 + r - 1) * 64 + 16 * w + cl] = v;
                     }
@@ -195,12 +195,12 @@ __global__ __launch_bounds__(256, 3) void df_ring_kernel(DfRingArgs a) {
         {
             float* dst = a.c1 + (bt * FD + fo0 + q * 4) * 64 + 16 * w + cl;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dst[(size_t)i * 64] = fmaxf(a1[i] + pwb, 0.f);
+            for (int i = 0; i < 4; ++i) dst[(size_t)i * 64] = relu_f(a1[i] + pwb);
         }
         if (kh == 0 && cl < 10) {
             float* dst = a.p + (bt * D + f0 + mt * 16 + q * 4) * 10 + cl;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dst[(size_t)i * 10] = fmaxf(acc[i] + Pz[mt][i][lane] + cpb, 0.f);
+            for (int i = 0; i < 4; ++i) dst[(size_t)i * 10] = relu_f(acc[i] + Pz[mt][i][lane] + cpb);
         }
         slot = slot == 4 ? 0 : slot + 1;
     }

@@ -47,6 +47,7 @@
 #include "fcln_gi.h"
 #include "gru_scan4.h"
 #include "dprnn_hop_block.h"
+#include "dprnn_hop_stack.h"
 #include "small_fused_mfma.h"
 #include "enc_seg.h"
 #include "dec_pyr.h"
@@ -239,12 +240,19 @@ struct DevBuf {
         if (need <= n) return DPDF_OK;
         if (p) (void)hipFree(p);
         p = nullptr; n = 0;
+#ifdef DPDF_HAZARD_PROBE
+        hipError_t e = uncached ? hipExtMallocWithFlags((void**)&p, need * sizeof(float), hipDeviceMallocUncached) : hipMalloc((void**)&p, need * sizeof(float));
+#else
         hipError_t e = hipMalloc((void**)&p, need * sizeof(float));
+#endif
         if (e != hipSuccess) return set_err(DPDF_E_RUNTIME, "hipMalloc(%zu floats) failed: %s", need, hipGetErrorString(e));
         n = need;
         return DPDF_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+#ifdef DPDF_HAZARD_PROBE
+    bool uncached = false;
+#endif
 };
 
 // Tensors that cross from stage 1 (features, encoder convs, DPRNNs) to stage 2 (embedding GRUs,
@@ -307,6 +315,10 @@ struct Lane {
     unsigned long long* gru_xbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int gru_xbuf_tiles[5] = {0, 0, 0, 0, 0}; unsigned gru_epoch[5] = {0, 0, 0, 0, 0};
     // stacked decoder pairs (gru256_stack16_kernel): per pair [tiles][Tcap + 2][16][256] granules = cell A's per-frame ring + cell B's two slots
     unsigned* join_ctr = nullptr; unsigned join_total = 0; bool join_want = false, join_armed = false;   // streaming hop: stage 2's first kernel waits for the ERB stack's last block by counter, not by event
+    // dprnn_hop_stack_kernel (a whole stack as one persistent launch): per branch the scans' granules [2][M][128], the later blocks' input projections
+    // [2][M][384], the glue tiles' flags [S][4] and the epoch of the next launch's first block
+    unsigned long long* hs_hcat[2] = {nullptr, nullptr}; float* hs_gi[2] = {nullptr, nullptr}; unsigned* hs_flags[2] = {nullptr, nullptr};
+    int hs_M[2] = {0, 0}, hs_S[2] = {0, 0}; unsigned hs_epoch[2] = {1, 1};
     unsigned* hop_flags[2] = {nullptr, nullptr}; int hop_flags_n[2] = {0, 0}; unsigned hop_epoch[2] = {0, 0};   // dprnn_hop_block_kernel: [0] DF stack, [1] ERB stack (they run side by side)
     unsigned* arrive[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int arrive_tiles[5] = {0, 0, 0, 0, 0}; unsigned arrive_count[5] = {0, 0, 0, 0, 0};   // gru256_step_kernel
     unsigned long long* gru_sbuf[2] = {nullptr, nullptr}; int gru_sbuf_tiles[2] = {0, 0}, gru_sbuf_T[2] = {0, 0}; unsigned gru_sepoch[2] = {0, 0};
@@ -377,6 +389,9 @@ struct dpdf_model {
     // inside stage 2 (needs bit 0); bit 4: GRU-256 scans on 8 / 16 workgroups per tile for launches of few tiles.
     // 0 = everything serial on the main stream (A/B timing).  (Bits 2 and 5 -- two lanes, five-stream sub-stage pipeline --
     // were measured slower and removed: docs/HISTORY.md section 7; they are ignored.)
+#ifdef DPDF_HAZARD_PROBE
+    int probe_taps = -1, probe_wait = 0, probe_late = 0; bool probe_dump_on = false; unsigned* probe_dump = nullptr; int probe_dump_T = 0; size_t probe_dump_n = 0;
+#endif
     int overlap = 27;
     int inter_fuse_rows = 1024;        // inter-band scan: fused form (fc + LN inside the scan) from this many (stream, band) rows on, hoisted-input form below
     int scan4_max_wgs = 512;           // hoisted-input GRU-64 scans on 4-row tiles (gru_scan4.h) while the launch has at most this many workgroups (0 = never)
@@ -386,6 +401,8 @@ struct dpdf_model {
     int gru256_step = 1;               // single-hop streaming: input projection + GRUCell(256) step as one launch per cell
     bool counted = false;              // this handle is in g_live_models
     int hop_spin_join = 1;             // ... and stage 2's emb_in waits for the ERB stack's last block by a counter instead of a cross-stream event (~10 us)
+    int n_cus = 256;                   // compute units of the device (co-residency checks of the persistent launches)
+    int hop_stack = 1;                 // a whole DPRNN stack of a hop as ONE persistent launch (dprnn_hop_stack.h) while its workgroups fit the chip
     int hop_fused = 1;                 // ... and that glue in the SAME launch as the scan in front of it (dprnn_hop_block.h): one launch per block
     int hop_glue = 1;                  // single-hop streaming: one glue launch per DPRNN block between the intra-band scans (fcln_gi.h)
     int fcln_gi = 1;                   // small batches: fc + LayerNorm GEMMs of the DPRNN also produce the next recurrence's input projection (fcln_gi.h)
@@ -1181,6 +1198,69 @@ struct DprnnWalk {
         after_glue(bi);
         return true;
     }
+    // single-hop streaming: ALL blocks of this stack as one persistent launch (dprnn_hop_stack.h); false: not available here
+    bool stack_ok() const {
+        if (!(m->hop_stack && hop_glue && m->glue8 && m->hop_fused && m->use_gru256_cluster)) return false;
+        if (blocks.empty() || blocks.size() > (size_t)HOP_STACK_MAX_BLOCKS || Fp > 48 || Fp % 8 || Tc != 1) return false;
+        // every workgroup of BOTH stacks of the hop must be resident at once (one 512-thread workgroup per CU)
+        const int wgs = 2 * ((B + 3) / 4) + B;
+        return 2 * wgs <= m->n_cus && (size_t)M * 384 < (1u << 30);
+    }
+    bool stack() {
+        Lane& L = *m->ln;
+        const int br = df ? 0 : 1, S_ = B, nbk = (int)blocks.size();
+        if (!m->d_err) {
+            if (hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess) return false;
+            (void)hipMemsetAsync(m->d_err, 0, sizeof(int), m->cur);
+        }
+        if (L.hs_M[br] < M || L.hs_S[br] < S_ || L.hs_epoch[br] > 0xF0000000u) {
+            L.sync_all();
+            if (L.hs_hcat[br]) (void)hipFree(L.hs_hcat[br]);
+            if (L.hs_gi[br]) (void)hipFree(L.hs_gi[br]);
+            if (L.hs_flags[br]) (void)hipFree(L.hs_flags[br]);
+            L.hs_hcat[br] = nullptr; L.hs_gi[br] = nullptr; L.hs_flags[br] = nullptr; L.hs_M[br] = L.hs_S[br] = 0;
+            const int Mc = std::max(M, L.hs_M[br]), Sc = std::max(S_, L.hs_S[br]);
+            if (hipMalloc((void**)&L.hs_hcat[br], (size_t)2 * Mc * 128 * sizeof(unsigned long long)) != hipSuccess ||
+                hipMalloc((void**)&L.hs_gi[br], (size_t)2 * Mc * 384 * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&L.hs_flags[br], (size_t)Sc * 4 * sizeof(unsigned)) != hipSuccess) return false;
+            // epochs start at 1: zeroed granules and flags are "never written"
+            if (hipMemset(L.hs_hcat[br], 0, (size_t)2 * Mc * 128 * sizeof(unsigned long long)) != hipSuccess ||
+                hipMemset(L.hs_flags[br], 0, (size_t)Sc * 4 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+            L.hs_M[br] = Mc; L.hs_S[br] = Sc; L.hs_epoch[br] = 1;
+        }
+        if (!intra_gi_ready) {        // block 0's input projection (the encoder launch did not bring it along)
+            const DprnnW& w0 = blocks[0];
+            PlainA<64> ap{x, 64, 0, 64};
+            BiasActStore<4> ep{gibuf.p, 384, 64, m->C(w0.intra.ih_bias), 64, 64, ACT_NONE};
+            launch_gemm_rows<4, 64, true>(m->cur, ap, m->C(w0.intra.ih_frag), ep, M, 64, 6);
+        }
+        ProfScope ps(m, "dprnn_hop_stack");
+        HopStackArgs ha{};
+        for (int bi = 0; bi < nbk; ++bi) {
+            const DprnnW& w = blocks[bi];
+            const bool next = bi + 1 < nbk;
+            ha.blk[bi] = HopStackBlock{m->C(w.intra.hh4), m->C(w.intra.bias), m->C(w.fci_frag), m->C(w.fci_b), m->C(w.lni_g), m->C(w.lni_b),
+                                       m->C(w.inter.wfrag), m->C(w.inter.bias), state + soff + (long)bi * Fp * 64,
+                                       m->C(w.fce_frag), m->C(w.fce_b), m->C(w.lne_g), m->C(w.lne_b),
+                                       next ? m->C(blocks[bi + 1].intra.ih_frag) : nullptr, next ? m->C(blocks[bi + 1].intra.ih_bias) : nullptr};
+        }
+        ha.nb = nbk; ha.S = S_; ha.Fp = Fp; ha.h_hi = S;
+        ha.x0 = x; ha.gi0 = gibuf.p; ha.gi = L.hs_gi[br]; ha.hcat = L.hs_hcat[br]; ha.y_out = xa == x ? xb : xa;
+        ha.gi_flags = L.hs_flags[br]; ha.epoch0 = L.hs_epoch[br]; L.hs_epoch[br] += (unsigned)nbk;
+        ha.err = m->d_err; ha.done = nullptr;
+        if (!df && L.join_want) {
+            if (!L.join_ctr) {
+                if (hipMalloc((void**)&L.join_ctr, sizeof(unsigned)) != hipSuccess) return false;
+                if (hipMemset(L.join_ctr, 0, sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+                L.join_total = 0;
+            }
+            ha.done = L.join_ctr; L.join_total += (unsigned)S_; L.join_armed = true;
+        }
+        const unsigned grid = (unsigned)(2 * ((S_ + 3) / 4) + S_);
+        hipLaunchKernelGGL(dprnn_hop_stack_kernel, dim3(grid), dim3(512), 0, m->cur, ha);
+        x = ha.y_out; intra_gi_ready = false;
+        return true;
+    }
     void block(size_t bi) {
         const DprnnW& w = blocks[bi];
         bool inter_gi_ready = false;
@@ -1504,6 +1584,16 @@ int run_stage1(dpdf_model* m, const ChunkArgs& c) {
     }
     x.c1d = x.c1.p; x.e3d = x.e3.p;
     if (d.nb > 0) {
+        // a streaming hop whose stacks fit the chip: one persistent launch per stack (both must take this form: they share the CUs)
+        bool stacked = false;
+        if (wdf.stack_ok() && werb.stack_ok()) {
+            m->cur = sA; const bool a_ = wdf.stack();
+            m->cur = sC; const bool b_ = a_ && werb.stack();
+            stacked = a_ && b_;
+            if (a_ && !b_) return set_err(DPDF_E_RUNTIME, "dprnn_hop_stack: allocation failed");
+        }
+        if (stacked) {
+        } else
         if (m->interleave) {
             for (size_t bi = 0; bi < wdf.size(); ++bi) {
                 m->cur = sA; wdf.block(bi);
@@ -1638,6 +1728,25 @@ void run_mask_df(dpdf_model* m, const ChunkArgs& c, XSet& x, hipStream_t st) {
         return;
     }
     hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mk);
+#ifdef DPDF_HAZARD_PROBE
+    da.dump = m->probe_dump_on ? m->probe_dump : nullptr; da.dump_T = m->probe_dump_T;
+    if (m->probe_taps >= 0) {
+        const dim3 g((unsigned)((total + 255) / 256));
+#define DPDF_PROBE_CASE(T, W, LT) case (LT) * 1000 + (T) * 20 + (W): hipLaunchKernelGGL(HIP_KERNEL_NAME(df_apply_probe_kernel<T, W, LT>), g, dim3(256), 0, st, da); break;
+        switch (m->probe_late * 1000 + m->probe_taps * 20 + m->probe_wait) {
+        DPDF_PROBE_CASE(0, 0, 0) DPDF_PROBE_CASE(1, 0, 0) DPDF_PROBE_CASE(2, 0, 0) DPDF_PROBE_CASE(3, 0, 0) DPDF_PROBE_CASE(4, 0, 0) DPDF_PROBE_CASE(5, 0, 0) DPDF_PROBE_CASE(6, 0, 0)
+        DPDF_PROBE_CASE(1, 1, 0) DPDF_PROBE_CASE(2, 1, 0) DPDF_PROBE_CASE(4, 1, 0) DPDF_PROBE_CASE(2, 2, 0) DPDF_PROBE_CASE(4, 2, 0)
+        DPDF_PROBE_CASE(2, 10, 0) DPDF_PROBE_CASE(2, 11, 0)
+        DPDF_PROBE_CASE(2, 6, 0) DPDF_PROBE_CASE(2, 7, 0) DPDF_PROBE_CASE(2, 8, 0) DPDF_PROBE_CASE(2, 9, 0) DPDF_PROBE_CASE(2, 6, 1) DPDF_PROBE_CASE(2, 8, 1)
+        DPDF_PROBE_CASE(2, 4, 0) DPDF_PROBE_CASE(4, 4, 0) DPDF_PROBE_CASE(2, 5, 0) DPDF_PROBE_CASE(4, 5, 0) DPDF_PROBE_CASE(3, 4, 0) DPDF_PROBE_CASE(0, 4, 0)
+        DPDF_PROBE_CASE(2, 3, 0) DPDF_PROBE_CASE(4, 3, 0) DPDF_PROBE_CASE(1, 3, 0) DPDF_PROBE_CASE(0, 3, 0)
+        DPDF_PROBE_CASE(0, 0, 1) DPDF_PROBE_CASE(2, 0, 1) DPDF_PROBE_CASE(4, 0, 1) DPDF_PROBE_CASE(2, 1, 1) DPDF_PROBE_CASE(4, 1, 1)
+        default: fprintf(stderr, "probe: no kernel for taps %d wait %d late %d\n", m->probe_taps, m->probe_wait, m->probe_late); abort();
+        }
+#undef DPDF_PROBE_CASE
+        return;
+    }
+#endif
     hipLaunchKernelGGL(df_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, da);
 }
 
@@ -1921,6 +2030,7 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
 
     dpdf_model* m = new dpdf_model();
     m->cfg = *cfg; m->d = d; m->device = device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) m->n_cus = cus; }
     dpdf_get_state_layout(&d, &m->L);
     Blob B; B.base = weights;
     dpdf_manifest(cfg, blob_cb, &B);
@@ -2254,6 +2364,7 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "gru256_step") m->gru256_step = value != 0;
     else if (n == "hop_glue") m->hop_glue = value != 0;
     else if (n == "hop_fused") m->hop_fused = value != 0;
+    else if (n == "hop_stack") m->hop_stack = value != 0;
     else if (n == "hop_spin_join") m->hop_spin_join = value != 0;
     else if (n == "hop_feat") m->hop_feat = value != 0;
     else if (n == "glue8") m->glue8 = value != 0;
@@ -2284,6 +2395,16 @@ extern "C" int dpdf_set_option(dpdf_model* m, const char* name, int value) {
     else if (n == "gru256_c8_tiles") m->gru256_c8_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_c16_tiles") m->gru256_c16_tiles = value < 0 ? 0 : value;
     else if (n == "gru256_cluster") m->use_gru256_cluster = value != 0;
+#ifdef DPDF_HAZARD_PROBE
+    else if (n == "probe_taps") m->probe_taps = value;                      // -1: the shipped df_apply_kernel
+    else if (n == "probe_wait") m->probe_wait = value;
+    else if (n == "probe_late") m->probe_late = value;
+    else if (n == "probe_dump") m->probe_dump_on = value != 0;
+    else if (n == "probe_coefs_uncached") {
+        m->lanes[0].ws.release();                                           // re-allocated by the next call
+        m->lanes[0].ws.coefs.uncached = value != 0;
+    }
+#endif
     else return set_err(DPDF_E_INVALID, "unknown option '%s'", name);
     return DPDF_OK;
 }
@@ -3201,15 +3322,19 @@ static int pool_join(dpdf_streams* s, StreamPoolC* P, int n, const int* idx, con
     for (int j = 0; j < n; ++j)
         if (P->slot_round[slots[idx[j]]] >= 0) return set_err(DPDF_E_STATE, "slot %d already has a request in flight", slots[idx[j]]);
     StreamPoolC::Round* R;
+    bool blocked = false;
     for (;;) {
         R = &P->rd[P->open_id & 1];
         // the buffer of the open round is free once the readers of the round that used it before are through; and a round takes
         // one hop count only
         if (R->state == StreamPoolC::Round::OPEN && R->id == P->open_id && (R->n_queued == 0 || R->k == k)) break;
-        P->n_blocked += n; P->arrivals.fetch_add(1, std::memory_order_release); P->cv.notify_all();     // (the open round's leader counts us as "cannot come")
+        if (!blocked) {        // said ONCE: the open round's leader counts us as "cannot come" (several blocked submitters that re-announced themselves on every wake-up kept waking each other until the round fired)
+            blocked = true;
+            P->n_blocked += n; P->arrivals.fetch_add(1, std::memory_order_release); P->cv.notify_all();
+        }
         ++P->n_cv_waiters; P->cv.wait(lk); --P->n_cv_waiters;
-        P->n_blocked -= n;
     }
+    if (blocked) P->n_blocked -= n;
     if (R->n_queued == 0) {
         R->k = k;
         const size_t need = (size_t)s->S * row;
@@ -3278,7 +3403,6 @@ static void pool_lead(dpdf_streams* s, StreamPoolC* P, long id, bool no_window) 
     // rounds execute in order: the previous round's leader holds exec_mu until its device call is through; this round stays open
     // (and keeps filling) while we wait for it
     std::lock_guard<std::mutex> ex(P->exec_mu);
-    std::vector<unsigned char> active;
     int k;
     {
         std::unique_lock<std::mutex> lk(P->mu, std::defer_lock); pool_lock(lk);
@@ -3286,12 +3410,17 @@ static void pool_lead(dpdf_streams* s, StreamPoolC* P, long id, bool no_window) 
         ++P->open_id;                                  // later submitters fill the other buffer
         P->cv.notify_all();
         while (R->copies_pending > 0) { ++P->n_cv_waiters; P->cv.wait(lk); --P->n_cv_waiters; }
-        active = R->active; k = R->k;
-        P->prev_active = active; P->n_prev_in_use = 0;
-        for (int i = 0; i < s->S; ++i) { if (!P->in_use[i]) P->prev_active[i] = 0; P->n_prev_in_use += P->prev_active[i]; }
+        k = R->k;
+        P->n_prev_in_use = 0;                          // (element-wise into vectors sized at creation: nothing here allocates)
+        for (int i = 0; i < s->S; ++i) { P->prev_active[i] = R->active[i] && P->in_use[i]; P->n_prev_in_use += P->prev_active[i]; }
     }
     const auto t_call0 = std::chrono::steady_clock::now();
-    const int rc = streams_call(s, nullptr, k, nullptr, active.data(), DPDF_HOST_PTRS, R->pin_in, R->pin_out);
+    // Whatever happens in the device call, the round reaches DONE with a return code: its followers block in pool_collect without
+    // a time-out, and no C++ exception may cross the extern "C" boundary above us.  (R->active is not written while the round fires.)
+    int rc; std::string call_err;
+    try { rc = streams_call(s, nullptr, k, nullptr, R->active.data(), DPDF_HOST_PTRS, R->pin_in, R->pin_out); if (rc) call_err = dpdf_last_error(); }
+    catch (const std::exception& e) { rc = DPDF_E_RUNTIME; try { call_err = std::string("exception in the pool's device call: ") + e.what(); } catch (...) {} }
+    catch (...) { rc = DPDF_E_RUNTIME; }
     {
         std::lock_guard<std::mutex> lk(P->mu);
         const auto t_call1 = std::chrono::steady_clock::now();
@@ -3299,7 +3428,7 @@ static void pool_lead(dpdf_streams* s, StreamPoolC* P, long id, bool no_window) 
         P->t_call += std::chrono::duration<double>(t_call1 - t_call0).count();
         if (P->last_done != std::chrono::steady_clock::time_point{}) P->t_gap += std::chrono::duration<double>(t_call0 - P->last_done).count();
         P->last_done = t_call1;
-        R->rc = rc; R->err = rc ? dpdf_last_error() : "";
+        R->rc = rc; R->err.swap(call_err);
         R->state = StreamPoolC::Round::DONE;
         R->readers_left = R->n_queued;
         ++P->device_calls; ++P->rounds;
@@ -3478,4 +3607,28 @@ extern "C" long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, l
 
 #ifdef DPDF_PHASE_TRACE
 extern "C" int dpdf_debug_trace(unsigned long long* out32) { return hipMemcpyFromSymbol(out32, HIP_SYMBOL(dpdf_trace_buf), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; }
+#endif
+
+#ifdef DPDF_HAZARD_PROBE
+// Probe build only (tools/hazard_probe.py): the side buffer df_apply_probe_kernel dumps the taps it consumed into.
+extern "C" int dpdf_probe_dump_alloc(dpdf_model* m, int B, int T) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t n = (size_t)B * T * m->d.F * 36;
+    if (n > m->probe_dump_n) {
+        if (m->probe_dump) (void)hipFree(m->probe_dump);
+        HIP_TRY(hipMalloc((void**)&m->probe_dump, n * sizeof(unsigned)));
+        m->probe_dump_n = n;
+    }
+    m->probe_dump_T = T;
+    HIP_TRY(hipMemset(m->probe_dump, 0xff, n * sizeof(unsigned)));
+    return DPDF_OK;
+}
+extern "C" int dpdf_probe_dump_fetch(dpdf_model* m, unsigned* host, size_t n) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, m->probe_dump, std::min(n, m->probe_dump_n) * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return DPDF_OK;
+}
 #endif

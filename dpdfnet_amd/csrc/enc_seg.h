@@ -98,7 +98,7 @@ __device__ __forceinline__ void enc_seg_layer(const float (*src)[68], const floa
         for (int i = 0; i < 4; ++i) {
             const int row = rt * 16 + 4 * q + i, g = lo_out + row;
             const bool valid = row < NROW && g >= 0 && g < Fout;
-            const float v = valid ? fmaxf(acc[i] + bv, 0.f) : 0.f;
+            const float v = valid ? relu_f(acc[i] + bv) : 0.f;
             if (dst && row < NROW) dst[row][16 * w + cl] = v;
             if (valid && g >= own_lo && g < own_hi) out[(size_t)g * 64 + 16 * w + cl] = v;
         }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void erb_enc_seg_kernel(ErbEncArgs a) {
                         acc.x = __builtin_fmaf(w0[0][kt * 3 + kf], x, acc.x); acc.y = __builtin_fmaf(w0[1][kt * 3 + kf], x, acc.y);
                         acc.z = __builtin_fmaf(w0[2][kt * 3 + kf], x, acc.z); acc.w = __builtin_fmaf(w0[3][kt * 3 + kf], x, acc.w);
                     }
-                acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+                acc.x = relu_f(acc.x); acc.y = relu_f(acc.y); acc.z = relu_f(acc.z); acc.w = relu_f(acc.w);
                 if (f >= own_lo && f < own_hi) *(float4*)(e0 + (size_t)f * 64 + c4) = acc;
             }
             *(float4*)&E0[r][c4] = acc;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void df_enc_seg_kernel(DfEncArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int r = rt * 16 + 4 * q + i, f = lo0 + r;
                 const bool valid = r < N0 && f >= 0 && f < a.D;
-                const float v = valid ? fmaxf(acc[i] + bv, 0.f) : 0.f;
+                const float v = valid ? relu_f(acc[i] + bv) : 0.f;
                 if (r < N0) C0[r][16 * w + cl] = v;
                 if (valid && f >= 2 * a1) c0[(size_t)f * 64 + 16 * w + cl] = v;
             }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void df_enc_seg_kernel(DfEncArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int band = 2 * a1 + mt * 16 + q * 4 + i;
-                if (band < a.D) a.p[((size_t)bt * a.D + band) * 10 + cl] = fmaxf(acc[i] + Pz[mt][i][lane] + cpb, 0.f);
+                if (band < a.D) a.p[((size_t)bt * a.D + band) * 10 + cl] = relu_f(acc[i] + Pz[mt][i][lane] + cpb);
             }
         }
     }

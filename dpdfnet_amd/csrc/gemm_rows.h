@@ -212,10 +212,10 @@ struct SubpixA {
                 for (int j = 0; j < 3; ++j) {
                     int fi = f + j - 1;
                     if (fi >= 0 && fi < e.Fp) {
-                        float ux = fmaxf(s4.x * R.ev[i][j].x + b4.x, 0.f) + R.pv[i][j].x;
-                        float uy = fmaxf(s4.y * R.ev[i][j].y + b4.y, 0.f) + R.pv[i][j].y;
-                        float uz = fmaxf(s4.z * R.ev[i][j].z + b4.z, 0.f) + R.pv[i][j].z;
-                        float uw = fmaxf(s4.w * R.ev[i][j].w + b4.w, 0.f) + R.pv[i][j].w;
+                        float ux = relu_f(s4.x * R.ev[i][j].x + b4.x) + R.pv[i][j].x;
+                        float uy = relu_f(s4.y * R.ev[i][j].y + b4.y) + R.pv[i][j].y;
+                        float uz = relu_f(s4.z * R.ev[i][j].z + b4.z) + R.pv[i][j].z;
+                        float uw = relu_f(s4.w * R.ev[i][j].w + b4.w) + R.pv[i][j].w;
                         v.x += w[(c4 + 0) * 3 + j] * ux; v.y += w[(c4 + 1) * 3 + j] * uy;
                         v.z += w[(c4 + 2) * 3 + j] * uz; v.w += w[(c4 + 3) * 3 + j] * uw;
                     }
@@ -377,7 +377,7 @@ struct BiasReluToView {
             int b, t, f; rm.split(row, b, t, f);
             float* dst = o.at(b, t, f);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) dst[nt * 16 + cl] = fmaxf(acc[nt][i] + bv[nt], 0.f);
+            for (int nt = 0; nt < 4; ++nt) dst[nt * 16 + cl] = relu_f(acc[nt][i] + bv[nt]);
         }
     }
 };
@@ -418,7 +418,7 @@ struct MaskSumEpi {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const float u = fmaxf(acc[nt][i] + bv[nt], 0.f) + fmaxf(__builtin_fmaf(sc[nt], P.r[nt][i], sh[nt]), 0.f);
+                const float u = relu_f(acc[nt][i] + bv[nt]) + relu_f(__builtin_fmaf(sc[nt], P.r[nt][i], sh[nt]));
                 s0 = __builtin_fmaf(w0[nt], u, s0); s1 = __builtin_fmaf(w1[nt], u, s1); s2 = __builtin_fmaf(w2[nt], u, s2);
             }
             s0 = row16_allreduce_sum(s0); s1 = row16_allreduce_sum(s1); s2 = row16_allreduce_sum(s2);
@@ -499,7 +499,7 @@ struct ConvpEpi {
             int row = row0 + rq + i;
             if (row >= M) continue;
             int b, t, f; rm.split(row, b, t, f);
-            float v = fmaxf(acc[0][i] + bv, 0.f) + P.d[i];
+            float v = relu_f(acc[0][i] + bv) + P.d[i];
             coefs[((((size_t)b * Tt + 2 + t) * rm.Fp) + f) * 10 + cl] = v;
         }
     }

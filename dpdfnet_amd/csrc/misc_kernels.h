@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void conv0_erb_kernel(Conv0ErbArgs a) {
                 acc.z += w[2][kt * 3 + kf] * x; acc.w += w[3][kt * 3 + kf] * x;
             }
         }
-        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        acc.x = relu_f(acc.x); acc.y = relu_f(acc.y); acc.z = relu_f(acc.z); acc.w = relu_f(acc.w);
         *(float4*)(a.e0 + row * 64 + c4) = acc;
     }
 }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void mask_out_kernel(MaskOutArgs a) {
         int fi = f + k - 1;
         if (fi >= 0 && fi < a.Ec) {
             size_t o = (bt * a.Ec + fi) * 64 + lane;
-            float u = fmaxf(ps * a.e0[o] + pb, 0.f) + a.d1[o];
+            float u = relu_f(ps * a.e0[o] + pb) + a.d1[o];
             acc += a.w[lane * 3 + k] * u;
         }
     }
@@ -322,7 +322,13 @@ struct DfApplyArgs {
     const float* raw;      // attn-limit noisy reference (same geometry as out) or null
     float alpha, beta;
     int B, Tc, F, D; float inv_wnorm;
+#ifdef DPDF_HAZARD_PROBE
+    unsigned* dump; int dump_T;   // [B][dump_T][F][24]: what this thread consumed and produced (bit patterns), XCC id, s_memtime low word
+#endif
 };
+#ifdef DPDF_HAZARD_PROBE
+#include "hazard_probe.h"     // df_apply_probe_kernel<...>: tools/hazard_probe.py, DESIGN.md section 6
+#endif
 __global__ void df_apply_kernel(DfApplyArgs a) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)a.B * a.Tc * a.F;
@@ -339,7 +345,7 @@ __global__ void df_apply_kernel(DfApplyArgs a) {
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
             float2 s = *(const float2*)(xb + n * fs);
-            const float cr = ld_agent(c + 2 * n), ci = ld_agent(c + 2 * n + 1);
+            const float cr = c[2 * n], ci = c[2 * n + 1];
             rr += s.x * cr; ii += s.y * ci; ri += s.x * ci; ir += s.y * cr;
         }
         re = rr - ii; im = ri + ir;
@@ -409,7 +415,7 @@ __global__ void mask_df_kernel(MaskDfArgs a) {
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
             const float2 s = tap(n);
-            const float cr = ld_agent(c + 2 * n), ci = ld_agent(c + 2 * n + 1);
+            const float cr = c[2 * n], ci = c[2 * n + 1];
             rr += s.x * cr; ii += s.y * ci; ri += s.x * ci; ir += s.y * cr;
         }
         re = rr - ii; im = ri + ir;
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(256) void state_io_kernel(StateIoArgs a) {
             for (long i = tid; i < fsz; i += 256) {
                 int n = (int)(i / (2 * a.D)); int rem = (int)(i - (long)n * 2 * a.D);
                 int f = rem >> 1, p = rem & 1;                               // state index = (n*D + f)*2 + p
-                if (a.do_export) sp[i] = ld_agent(tp + (long)f * 10 + 2 * n + p); else tp[(long)f * 10 + 2 * n + p] = sp[i];
+                if (a.do_export) sp[i] = tp[(long)f * 10 + 2 * n + p]; else tp[(long)f * 10 + 2 * n + p] = sp[i];
             }
         }
     }

@@ -104,7 +104,7 @@ __device__ __forceinline__ void emb_in_first(const GlFrag& g, const float* xrow,
             f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
             gl_mma<1, NCH>(a4[u], wv[u], acc);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Es[4 * q + i][16 * (jj + u) + cl] = fmaxf(acc[0][i] + b1[jj + u], 0.f);
+            for (int i = 0; i < 4; ++i) Es[4 * q + i][16 * (jj + u) + cl] = relu_f(acc[0][i] + b1[jj + u]);
         }
     }
 }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void emb_in_mfma_kernel(EmbInMArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + 4 * q + i;
-        if (r < a.M) a.out[(size_t)r * 256 + g2 * 16 + cl] = fmaxf(acc[0][i] + b2, 0.f);
+        if (r < a.M) a.out[(size_t)r * 256 + g2 * 16 + cl] = relu_f(acc[0][i] + b2);
     }
 }
 
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void emb_out_mfma_kernel(EmbOutMArgs a) {
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v = fmaxf(acc[nt][i] + b1[j][nt], 0.f);
+                const float v = relu_f(acc[nt][i] + b1[j][nt]);
                 Es[w][4 * q + i][32 * j + 16 * nt + cl] = v;
                 const int r = row0 + 4 * q + i;
                 if (r < a.M) a.emb[(size_t)r * 512 + g1 * 32 + nt * 16 + cl] = v;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void emb_out_mfma_kernel(EmbOutMArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int r = row0 + 4 * q + i;
             if (r < a.M) {
-                a.ed_x[(size_t)r * 256 + g1 * 16 + cl] = fmaxf(ae[0][i] + be[j], 0.f);
+                a.ed_x[(size_t)r * 256 + g1 * 16 + cl] = relu_f(ae[0][i] + be[j]);
                 a.skip_out[(size_t)r * 256 + g1 * 16 + cl] = as[0][i] + bs[j];
             }
         }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void emb_out_mfma_kernel(EmbOutMArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = row0 + 4 * q + i;
-            if (r < a.M) a.df_x[(size_t)r * 256 + g * 32 + nt * 16 + cl] = fmaxf(ad[nt][i] + bd[nt], 0.f);
+            if (r < a.M) a.df_x[(size_t)r * 256 + g * 32 + nt * 16 + cl] = relu_f(ad[nt][i] + bd[nt]);
         }
     }
 }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void dec_in_mfma_kernel(DecInMArgs a) {
             const float bv = b1[nt];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v = fmaxf(acc[nt][i] + bv, 0.f);
+                const float v = relu_f(acc[nt][i] + bv);
                 Es[w][4 * q + i][16 * nt + cl] = v;
                 const int r = row0 + 4 * q + i;
                 if (!a.erb_fc.frag && r < a.M) a.demb[(size_t)r * 512 + g * 32 + nt * 16 + cl] = v;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void dec_in_mfma_kernel(DecInMArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = row0 + 4 * q + i;
-                if (r < a.M) a.demb2[(size_t)r * a.n2 + g2 * 80 + nt * 16 + cl] = fmaxf(acc[nt][i] + bv, 0.f);
+                if (r < a.M) a.demb2[(size_t)r * a.n2 + g2 * 80 + nt * 16 + cl] = relu_f(acc[nt][i] + bv);
             }
         }
     }

@@ -16,6 +16,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* torch.relu / F.relu propagate NaN (relu(NaN) = NaN: the reference's frame function keeps a NaN that has entered a clip in every state
+   of that clip); `v > 0 ? v : 0` would turn it into 0.  tests/golden/nonfinite_*.npz pins this. */
+static inline float relu_f(float v) { return v < 0.f ? 0.f : v; }
+
 #define MAXC 64
 
 typedef struct { const float *w, *b, *mean, *var; } bn_t;
@@ -373,7 +377,7 @@ static void grouped_linear(const gl_t* g, const float* x, float* y, int act) {
             float acc = 0.f;
             for (int i = 0; i < g->Ig; ++i) acc += w[i] * xi[i];
             acc += g->b[gi * g->Og + o];
-            if (act == ACT_RELU) acc = acc > 0.f ? acc : 0.f;
+            if (act == ACT_RELU) acc = relu_f(acc);
             else if (act == ACT_TANH) acc = tanhf(acc);
             y[gi * g->Og + o] = acc;
         }
@@ -407,7 +411,7 @@ static void pw_bn_relu(const float* pw_t, const bn_t* bn, const float* x, float*
         matvec_t(out, pw_t, NULL, col, 64, 64);
         for (int oc = 0; oc < 64; ++oc) {
             float v = bn_apply(bn, oc, out[oc]);
-            y[oc * F + f] = v > 0.f ? v : 0.f;
+            y[oc * F + f] = relu_f(v);
         }
     }
 }
@@ -435,7 +439,7 @@ static void pathconv_add(const pathconv_t* p, const float* e, const float* add, 
     for (int c = 0; c < 64; ++c)
         for (int f = 0; f < F; ++f) {
             float v = bn_apply(&p->bn, c, p->scale[c] * e[c * F + f]);
-            v = v > 0.f ? v : 0.f;
+            v = relu_f(v);
             y[c * F + f] = v + add[c * F + f];
         }
 }
@@ -542,7 +546,7 @@ void dpdf_oracle_frame(dpdf_oracle* o, const float* spec_in, const float* state_
                         if (fi >= 0 && fi < Ec) acc += o->erb_conv0_w[oc * 9 + kt * 3 + kf] * buf[kt * E + fi];
                     }
                 float v = bn_apply(&o->erb_conv0_bn, oc, acc);
-                e0[oc * Ec + f] = v > 0.f ? v : 0.f;
+                e0[oc * Ec + f] = relu_f(v);
             }
     }
     sepconv(&o->erb_conv1, e0, e1, Ec, d->s1);
@@ -669,7 +673,7 @@ void dpdf_oracle_frame(dpdf_oracle* o, const float* spec_in, const float* state_
                 float acc = 0.f;
                 for (int ci = 0; ci < 10; ++ci) acc += o->df_convp_pw[oc * 10 + ci] * g10[ci * D + f];
                 float v = bn_apply(&o->df_convp_bn, oc, acc);
-                v = v > 0.f ? v : 0.f;
+                v = relu_f(v);
                 coefs[f * 10 + oc] = outv[f * 10 + oc] + v; /* view(b,t,F,O*2) + c0 (dpdfnet.py:515) */
             }
     }

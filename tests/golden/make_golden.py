@@ -586,6 +586,79 @@ def make_sparse_fixtures():
     make_sparse_stream_fixture(m8, "48k_nb8_sparse", SEED + 318)
 
 
+NONFINITE_CLASSES = ("nan_sample", "pos_inf_sample", "neg_inf_sample", "denormal_noise", "nan_first_sample")
+
+
+def nonfinite_clip(cls: str, n: int, sr: int, seed: int) -> np.ndarray:
+    """A clean synthetic clip with ONE non-finite sample (or denormal-only content): what the reference's frame function does with it
+    is the contract -- a NaN / Inf reaches the EMA norm states and every recurrent state of that clip and never leaves them."""
+    wav = synth_clip(n, sr, seed)
+    k = int(0.35 * n)
+    if cls == "nan_sample":
+        wav[k] = np.nan
+    elif cls == "pos_inf_sample":
+        wav[k] = np.inf
+    elif cls == "neg_inf_sample":
+        wav[k] = -np.inf
+    elif cls == "nan_first_sample":
+        wav[0] = np.nan
+    elif cls == "denormal_noise":
+        rng = np.random.default_rng(seed + 5)
+        wav = (1e-40 * rng.standard_normal(n)).astype(np.float32)
+    else:
+        raise ValueError(cls)
+    return wav
+
+
+def make_nonfinite_fixture(tag: str, sr: int, nb: int, seconds: float, seed: int):
+    """Round 6: NaN / +-Inf / denormal inputs through the reference's frame function (onnx_model/dpdfnet.py:748-852, 48 kHz twin
+    dpdfnet_48khz_hr.py:820-924) with torch's own analysis and synthesis, as make_model_fixture does for clean clips.  Stored per class:
+    the input, the enhanced waveform (NaNs included), the index of the first non-finite output sample and the non-finite mask of the
+    final state vector."""
+    import torch
+    from oracle import oracle as orc
+    from dpdfnet_amd.weights import parse_manifest_text, synth_blob
+
+    entries = parse_manifest_text(orc.manifest_text(sr, nb))
+    blob = synth_blob(entries, seed)
+    model = build_reference_model(sr, nb, blob, entries)
+    n = int(seconds * sr)
+    win = model.stft.win_len
+    fix = {}
+    for i, cls in enumerate(NONFINITE_CLASSES):
+        wav = nonfinite_clip(cls, n, sr, seed + 30 + i)
+        with torch.no_grad():
+            audio_pad = torch.nn.functional.pad(torch.from_numpy(wav)[None], (0, win))
+            spec_c = model.stft(audio_pad).transpose(1, 2)[0]
+        spec = torch.view_as_real(spec_c).numpy().astype(np.float32)
+        g = run_reference_frames(model, spec, probe_frames=())
+        with torch.no_grad():
+            c = torch.view_as_complex(torch.from_numpy(np.ascontiguousarray(g["spec_e"])))[None]
+            audio = model.istft(c.transpose(1, 2))
+            audio = torch.nn.functional.pad(audio[:, win * 2:], (0, win * 2))
+        a = audio[0].numpy()
+        out = np.zeros(n, dtype=np.float32)
+        m = min(n, a.shape[0])
+        out[:m] = a[:m]
+        bad = np.nonzero(~np.isfinite(out))[0]
+        fix[f"{cls}_wav"] = wav
+        fix[f"{cls}_enhanced"] = out
+        fix[f"{cls}_first_bad"] = np.int64(bad[0] if len(bad) else -1)
+        fix[f"{cls}_state_bad"] = ~np.isfinite(g["state_out"])
+        fr = np.nonzero(~np.isfinite(g["spec_e"]).all(axis=(1, 2)))[0]
+        print(f"[golden] nonfinite_{tag} {cls}: first bad output sample {fix[f'{cls}_first_bad']} of {n}, "
+              f"{int((~np.isfinite(out)).sum())} bad samples, first bad enhanced frame {fr[0] if len(fr) else -1} of {spec.shape[0]}, "
+              f"{int(fix[f'{cls}_state_bad'].sum())} of {g['state_out'].size} state entries non-finite")
+    meta = dict(tag=tag, sample_rate=sr, nb=nb, seed=seed, n=n, classes=list(NONFINITE_CLASSES))
+    fix["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT / f"nonfinite_{tag}.npz", **fix)
+
+
+def make_nonfinite_fixtures():
+    make_nonfinite_fixture("16k_nb2", 16000, 2, 0.5, SEED + 402)
+    make_nonfinite_fixture("48k_nb8", 48000, 8, 0.3, SEED + 408)
+
+
 def main():
     assert REF.is_dir(), "reference checkout not mounted; goldens can only be regenerated in the build container"
     _stub_modules()
@@ -600,6 +673,9 @@ def main():
         return
     if "--sparse-only" in sys.argv:          # the round-5 additions alone
         make_sparse_fixtures()
+        return
+    if "--nonfinite-only" in sys.argv:       # the round-6 additions alone
+        make_nonfinite_fixtures()
         return
 
     make_constants_fixture()
@@ -620,6 +696,7 @@ def main():
     make_stress_fixtures()
     make_einsum_fixture()
     make_sparse_fixtures()
+    make_nonfinite_fixtures()
 
 
 if __name__ == "__main__":

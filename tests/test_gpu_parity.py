@@ -472,7 +472,7 @@ def test_small_launch_kernel_forms_equal_the_plain_forms(be, sr, nb):
         assert np.abs(a_ - b_).max() < 2e-5 * max(1.0, float(np.abs(b_).max())), k
 
 
-@pytest.mark.parametrize("sr,nb,S", [(16000, 2, 1), (16000, 4, 8), (48000, 1, 5), (48000, 2, 64)])
+@pytest.mark.parametrize("sr,nb,S", [(16000, 2, 1), (16000, 4, 8), (48000, 1, 5), (48000, 2, 64), (48000, 8, 64), (16000, 8, 3)])
 def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
     """Everything a single streaming hop does differently from a general call -- stage 2 on the main stream, staging + FIFO import
     + state copy as one prologue launch, one combined FIFO export behind the overlap-add (the host waits for the output event
@@ -483,7 +483,7 @@ def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
     blob = synth_blob(be.manifest(sr, nb), 4711)
     rng = np.random.default_rng(5)
     runs = {}
-    for tag, opts in (("hop", {}), ("two_launch", {"hop_fused": 0}), ("event_join", {"hop_spin_join": 0}),
+    for tag, opts in (("hop", {}), ("block_launches", {"hop_stack": 0}), ("two_launch", {"hop_fused": 0}), ("event_join", {"hop_spin_join": 0}),
                       ("plain", {"single_chunk_inline": 0, "hop_prologue": 0, "late_export": 0, "dual_step": 0, "hop_pconv": 0,
                                  "fuse_enc": 0, "fuse_dec": 0, "snapshot": 0, "hop_fused": 0})):
         m = be.HipModel(sr, nb, blob, 0)
@@ -501,6 +501,11 @@ def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
     for a_, b_ in zip(runs["hop"][0], runs["plain"][0]):
         assert a_.shape == b_.shape and rms(a_ - b_) < 1e-6
     assert np.abs(runs["hop"][1] - runs["plain"][1]).max() < 5e-5
+    # a whole DPRNN stack as ONE persistent launch (dprnn_hop_stack.h: the default while its workgroups fit the chip) against one launch per
+    # block: the same per-row arithmetic whatever rows share a tile, bit for bit
+    for a_, b_ in zip(runs["hop"][0], runs["block_launches"][0]):
+        np.testing.assert_array_equal(a_, b_)
+    np.testing.assert_array_equal(runs["hop"][1], runs["block_launches"][1])
     # scan + glue of a DPRNN block as one launch (dprnn_hop_block.h) against the two launches: the same arithmetic, bit for bit
     for a_, b_ in zip(runs["hop"][0], runs["two_launch"][0]):
         np.testing.assert_array_equal(a_, b_)
@@ -730,3 +735,64 @@ def test_sparse_spectra_streaming_hops_match_the_reference_stream_enhancer(S, be
             y = np.concatenate([se.process(wav[i:i + chunk]) for i in range(0, len(wav), chunk)] + [se.flush()])
             ref = G[f"f64_{cls}_chunk{chunk}"]
             assert y.shape == ref.shape and rms(y - ref) < 1e-5, (cls, chunk, rms(y - ref))
+
+
+# ----- non-finite inputs (round 6) --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["16k_nb2", "48k_nb8"])
+def test_nonfinite_inputs_match_the_reference_and_stay_in_their_slot(be, tag):
+    """A NaN / +Inf / -Inf sample (and a denormal-only clip) in SOME slots of a batch (reference goldens tests/golden/nonfinite_*.npz,
+    generated by make_golden.py:make_nonfinite_fixture from onnx_model/dpdfnet.py:748-852 / dpdfnet_48khz_hr.py:820-924): the
+    enhanced waveform of such a slot is non-finite in EXACTLY the reference's samples (torch.relu keeps a NaN: it stays in the clip's
+    states to the end) and equal elsewhere; every other slot of the batch is BIT-IDENTICAL to a batch without the poisoned clips; the
+    streaming path does the same hop by hop."""
+    import json
+    g = np.load(GOLDEN / f"nonfinite_{tag}.npz")
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    sr, nb, n = meta["sample_rate"], meta["nb"], meta["n"]
+    blob = golden_blob(meta)
+    m = be.HipModel(sr, nb, blob, 0)
+    classes = meta["classes"]
+    clean = [synth_clip(n, sr, 900 + i) for i in range(len(classes) + 3)]
+    base = m.enhance_batch(np.stack(clean), None)
+    assert np.isfinite(base).all()
+    # poisoned clips in the odd slots, clean clips around them
+    batch = [c.copy() for c in clean]
+    slots = {}
+    for i, cls in enumerate(classes):
+        slot = 1 + i if i < len(clean) - 1 else i
+        batch[slot] = g[f"{cls}_wav"]; slots[cls] = slot
+    out = m.enhance_batch(np.stack(batch), None)
+    for b in range(len(clean)):
+        if b not in slots.values():
+            np.testing.assert_array_equal(out[b], base[b], err_msg=f"clean slot {b} changed beside poisoned clips")
+    for cls, slot in slots.items():
+        ref = g[f"{cls}_enhanced"]
+        bad_o, bad_r = ~np.isfinite(out[slot]), ~np.isfinite(ref)
+        assert np.array_equal(bad_o, bad_r), (tag, cls, int(bad_o.sum()), int(bad_r.sum()), int(np.argmax(bad_o)), int(np.argmax(bad_r)))
+        fin = ~bad_r
+        if fin.any():
+            assert float(np.abs(out[slot][fin] - ref[fin]).max()) < 1e-5, (tag, cls)
+    # chunked in time (stage 2 of a chunk under stage 1 of the next) and as a one-clip call: the same samples go bad
+    m.set_chunk_frames(7)
+    out7 = m.enhance_batch(np.stack(batch), None)
+    m.set_chunk_frames(0)
+    assert np.array_equal(np.isfinite(out7), np.isfinite(out))
+    fin = np.isfinite(out)
+    assert float(np.abs(out7[fin] - out[fin]).max()) < 2e-6
+    # streaming: one poisoned stream between two clean ones, hop by hop; the clean streams stay bit-identical to a run of their own
+    hop = m.hop
+    k = (n // hop) * hop
+    S = be.HipStreams(m, 3)
+    trio = np.stack([clean[0][:k], g["nan_sample_wav"][:k], clean[2][:k]])
+    S.prime(trio[:, :hop].copy())
+    got = [S.process(trio[:, j:j + hop].copy()) for j in range(hop, k, hop)]
+    got = np.concatenate(got, axis=1)
+    S2 = be.HipStreams(m, 3)
+    solo = np.stack([clean[0][:k], clean[1][:k], clean[2][:k]])
+    S2.prime(solo[:, :hop].copy())
+    want = np.concatenate([S2.process(solo[:, j:j + hop].copy()) for j in range(hop, k, hop)], axis=1)
+    np.testing.assert_array_equal(got[0], want[0]); np.testing.assert_array_equal(got[2], want[2])
+    assert not np.isfinite(got[1]).all() and not np.isfinite(got[1][-hop:]).any(), "the poisoned stream must stay poisoned to the end"
+    st = S.get_state(1)
+    assert not np.isfinite(st).all()
+    S.close(); S2.close(); m.close()

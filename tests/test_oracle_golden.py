@@ -156,3 +156,46 @@ def test_sparse_spectra_streaming_oracle_matches_the_reference_stream_enhancer()
             ref = G[key]
             assert y.shape == ref.shape, (key, y.shape, ref.shape)
             assert rms(y - ref) < 2e-6, (key, rms(y - ref))
+
+
+# ----- non-finite inputs (round 6): what the reference's frame function does with a NaN / Inf sample is the contract ---------------
+NONFINITE_TAGS = ["16k_nb2", "48k_nb8"]
+
+
+def load_nonfinite(tag):
+    g = np.load(GOLDEN / f"nonfinite_{tag}.npz")
+    return g, json.loads(bytes(g["meta_json"]).decode())
+
+
+@pytest.mark.parametrize("tag", NONFINITE_TAGS)
+def test_nonfinite_inputs_propagate_as_in_the_reference(tag):
+    """NaN / +Inf / -Inf samples and denormal-only clips through the reference's frame function (tests/golden/make_golden.py:
+    make_nonfinite_fixture; onnx_model/dpdfnet.py:748-852, dpdfnet_48khz_hr.py:820-924).  torch.relu keeps a NaN, so a non-finite
+    value that has entered a clip stays in every recurrent and EMA state of that clip: the enhanced waveform is non-finite from
+    the first frame that saw it to the end of the audio.  The oracle must show the SAME non-finite samples and state entries and agree
+    on everything finite."""
+    from oracle import oracle as orc
+    g, meta = load_nonfinite(tag)
+    blob = golden_blob(meta)
+    for cls in meta["classes"]:
+        wav, ref = g[f"{cls}_wav"], g[f"{cls}_enhanced"]
+        o = orc.Oracle(meta["sample_rate"], meta["nb"], blob)
+        out = o.enhance(wav)
+        bad_o, bad_r = ~np.isfinite(out), ~np.isfinite(ref)
+        assert np.array_equal(bad_o, bad_r), (tag, cls, int(bad_o.sum()), int(bad_r.sum()))
+        first = int(np.nonzero(bad_r)[0][0]) if bad_r.any() else -1
+        assert first == int(g[f"{cls}_first_bad"])
+        fin = ~bad_r
+        if fin.any():
+            assert float(np.abs(out[fin] - ref[fin]).max()) < 5e-6, (tag, cls)
+        # the state after the last frame: non-finite in exactly the reference's entries
+        spec = o.stft(wav)
+        _, st = orc.Oracle(meta["sample_rate"], meta["nb"], blob).run_frames(spec)
+        bad_st, ref_st = ~np.isfinite(st), g[f"{cls}_state_bad"]
+        if "inf" in cls:
+            # +-Inf samples: whether a bin of the analysis transform comes out Inf or NaN (Inf - Inf inside an FFT butterfly) is a property
+            # of the transform's arithmetic, and an EMA norm state that went to Inf instead of NaN turns later features into finite zeros
+            # -- the poisoned state is required, its exact entries are not
+            assert bad_st.sum() > 0.5 * ref_st.sum() and bad_st[-2 * 5 * 2:].any() == ref_st[-2 * 5 * 2:].any(), (tag, cls, int(bad_st.sum()), int(ref_st.sum()))
+        else:
+            assert np.array_equal(bad_st, ref_st), (tag, cls)
