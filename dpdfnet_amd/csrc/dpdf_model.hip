@@ -402,7 +402,7 @@ struct dpdf_model {
     bool counted = false;              // this handle is in g_live_models
     int hop_spin_join = 1;             // ... and stage 2's emb_in waits for the ERB stack's last block by a counter instead of a cross-stream event (~10 us)
     int n_cus = 256;                   // compute units of the device (co-residency checks of the persistent launches)
-    int hop_stack = 1;                 // a whole DPRNN stack of a hop as ONE persistent launch (dprnn_hop_stack.h) while its workgroups fit the chip
+    int hop_stack = 0;                 // OPT-IN: a whole DPRNN stack of a hop as ONE persistent launch (dprnn_hop_stack.h; measured equal to the per-block launches)
     int hop_fused = 1;                 // ... and that glue in the SAME launch as the scan in front of it (dprnn_hop_block.h): one launch per block
     int hop_glue = 1;                  // single-hop streaming: one glue launch per DPRNN block between the intra-band scans (fcln_gi.h)
     int fcln_gi = 1;                   // small batches: fc + LayerNorm GEMMs of the DPRNN also produce the next recurrence's input projection (fcln_gi.h)
@@ -3606,6 +3606,7 @@ extern "C" long dpdf_debug_fetch(dpdf_model* m, const char* name, float* host, l
 }
 
 #ifdef DPDF_PHASE_TRACE
+extern "C" int dpdf_debug_stack_trace(unsigned long long* out512) { return hipMemcpyFromSymbol(out512, HIP_SYMBOL(dpdf_stack_trace), 512 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; }
 extern "C" int dpdf_debug_trace(unsigned long long* out32) { return hipMemcpyFromSymbol(out32, HIP_SYMBOL(dpdf_trace_buf), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1; }
 #endif
 

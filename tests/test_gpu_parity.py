@@ -483,7 +483,7 @@ def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
     blob = synth_blob(be.manifest(sr, nb), 4711)
     rng = np.random.default_rng(5)
     runs = {}
-    for tag, opts in (("hop", {}), ("block_launches", {"hop_stack": 0}), ("two_launch", {"hop_fused": 0}), ("event_join", {"hop_spin_join": 0}),
+    for tag, opts in (("hop", {}), ("stack_launch", {"hop_stack": 1}), ("two_launch", {"hop_fused": 0}), ("event_join", {"hop_spin_join": 0}),
                       ("plain", {"single_chunk_inline": 0, "hop_prologue": 0, "late_export": 0, "dual_step": 0, "hop_pconv": 0,
                                  "fuse_enc": 0, "fuse_dec": 0, "snapshot": 0, "hop_fused": 0})):
         m = be.HipModel(sr, nb, blob, 0)
@@ -501,11 +501,11 @@ def test_streaming_hop_forms_equal_the_plain_chain(be, sr, nb, S):
     for a_, b_ in zip(runs["hop"][0], runs["plain"][0]):
         assert a_.shape == b_.shape and rms(a_ - b_) < 1e-6
     assert np.abs(runs["hop"][1] - runs["plain"][1]).max() < 5e-5
-    # a whole DPRNN stack as ONE persistent launch (dprnn_hop_stack.h: the default while its workgroups fit the chip) against one launch per
-    # block: the same per-row arithmetic whatever rows share a tile, bit for bit
-    for a_, b_ in zip(runs["hop"][0], runs["block_launches"][0]):
+    # a whole DPRNN stack as ONE persistent launch (dprnn_hop_stack.h, opt-in) against one launch per block: the same per-row arithmetic
+    # whatever rows share a tile, bit for bit
+    for a_, b_ in zip(runs["hop"][0], runs["stack_launch"][0]):
         np.testing.assert_array_equal(a_, b_)
-    np.testing.assert_array_equal(runs["hop"][1], runs["block_launches"][1])
+    np.testing.assert_array_equal(runs["hop"][1], runs["stack_launch"][1])
     # scan + glue of a DPRNN block as one launch (dprnn_hop_block.h) against the two launches: the same arithmetic, bit for bit
     for a_, b_ in zip(runs["hop"][0], runs["two_launch"][0]):
         np.testing.assert_array_equal(a_, b_)
