@@ -23,6 +23,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
@@ -770,6 +771,26 @@ class CollectiveWatchdog:
         reexec_with_gloo_fallback(f"no answer within {seconds:g} s at stage `{self._stage}`")
 
 
+def float64_recurrence_error() -> dict:
+    """Both GRU-64 kernel families against a float64 recurrence on the same weights and inputs (tools/gru64_limb_bench: the carried state of
+    the inter-band scan after 192 steps): the claim "the limb kernels are not narrower than fp32" as a number on the line."""
+    exe = ROOT / "tools" / "gru64_limb_bench"
+    if not exe.exists():
+        return {"available": False, "why": "tools/gru64_limb_bench not built (__graft_entry__.build_tools)"}
+    try:
+        r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=180)
+        import re
+        m = re.search(r"float64 recurrence \((\d+) rows x (\d+) steps, state RMS ([0-9.e+-]+)\): fp32-MFMA kernel RMS ([0-9.e+-]+) max ([0-9.e+-]+) \| limb kernel RMS ([0-9.e+-]+) max ([0-9.e+-]+)", r.stdout)
+        if not m:
+            return {"available": False, "why": "no result line: " + (r.stdout + r.stderr)[-200:]}
+        return {"available": True, "rows": int(m.group(1)), "steps": int(m.group(2)), "state_rms": float(m.group(3)),
+                "fp32_mfma_kernels": {"rms": float(m.group(4)), "max": float(m.group(5))},
+                "limb_kernels": {"rms": float(m.group(6)), "max": float(m.group(7))},
+                "speed_isolated": [l.strip() for l in r.stdout.splitlines() if " x" in l and ("intra" in l or "inter (" in l)][:3]}
+    except Exception as exc:
+        return {"available": False, "why": f"{type(exc).__name__}: {exc}"[:200]}
+
+
 def multi_gpu_summary(per_rank: list) -> dict:
     """What a first hardware scaling curve needs to be read without a re-run: the spread of the ranks' own step times and what the
     gather to rank 0 costs (device-side duration of the grouped receive on rank 0 -- it overlaps the next step's compute -- and as a
@@ -943,8 +964,9 @@ def main() -> None:
         model.set_chunk_frames(args.chunk)
     if args.overlap >= 0:
         model.set_overlap(args.overlap)
-    if args.limbs:
-        model.set_option("gru64_limbs", 3)
+    # the headline is the fp32-MFMA engine whatever the process environment says (DPDF_GRU64_LIMBS starts every handle in the opt-in mode:
+    # that is how the GPU suite is run under it); --limbs is the explicit A/B
+    model.set_option("gru64_limbs", 3 if args.limbs else 0)
     if args.no_fuse:
         model.set_fuse_dprnn(False)
     for kv in args.opt:
@@ -1107,7 +1129,7 @@ def main() -> None:
         step(); sync()
         limb_iso = model.profile_report()
         model.profile(False); model.set_overlap(args.overlap if args.overlap >= 0 else 27)
-        model.set_option("gru64_limbs", 0)
+        model.set_option("gru64_limbs", 3 if args.limbs else 0)
         limb = {"ms_per_step": ms_l, "value": B * T / (ms_l * 1e-3), "out": limb_out, "prof": limb_prof, "iso": limb_iso}
 
     mark("per_kernel_event_passes")
@@ -1297,7 +1319,9 @@ def main() -> None:
                             "fp32-exact products (closer to a float64 recurrence than the fp32-MFMA kernels: tools/gru64_limb_bench.hip), but another instruction mix than "
                             "the reference's fp32 -- the headline `value`, `dtype` and `roofline` above are the fp32-MFMA kernels'",
                     "value": limb["value"], "ms_per_step": limb["ms_per_step"], "speedup_over_headline": (dt / args.steps) / (limb["ms_per_step"] * 1e-3),
+                    "dtype": "f32 (bf16x3 limbs, fp32 accumulate)",
                     "parity": lpar,
+                    "float64_recurrence_error": float64_recurrence_error(),
                     "roofline": None if ld not in lk else {
                         "bound": "mfma", "kernel": ld, "achieved": lk[ld]["issued_tflops"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": lk[ld]["issued_tflops"] / BF16_MFMA_PEAK_TFLOPS,

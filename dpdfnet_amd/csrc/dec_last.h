@@ -304,162 +304,5 @@ struct DecSegArgs {
     const float* ps0; const float* pb0; const float* w0;   // LAST: conv0p folded, conv0_out [64][3]
     int BT, FO;
 };
-template <int S, int R, bool LAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dec_seg_kernel(DecSegArgs a) {
-    constexpr int RI = R / S, NRT = R / 16;
-    constexpr int NP = ((RI + 2) * 16 + 255) / 256;                      // float4 pieces per thread of e / prev (incl. the halo bands)
-    constexpr int NE = (R * 16 + 255) / 256;                             // ... of e0 (LAST)
-    static_assert(R % 16 == 0 && R % S == 0, "tile = whole MFMA row tiles and whole input bands");
-    __shared__ __attribute__((aligned(16))) float U1[RI + 2][68];
-    __shared__ __attribute__((aligned(16))) float As[R][68];
-    __shared__ __attribute__((aligned(16))) float E0[LAST ? R : 1][68];  // relu(ps0 e0 + pb0)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cl = lane & 15, q = lane >> 4;
-    const int c4 = (tid & 15) * 4, r16 = tid >> 4;
-    float breg[64];
-#pragma unroll
-    for (int i = 0; i < 64; ++i) breg[i] = a.pwfrag[(size_t)i * 64 + lane];
-    const float4 s1 = *(const float4*)(a.ps + c4), b1 = *(const float4*)(a.pb + c4);
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = s0;
-    if (LAST) { s0 = *(const float4*)(a.ps0 + c4); b0 = *(const float4*)(a.pb0 + c4); }
-    float dwv[S][4][3];
-#pragma unroll
-    for (int k = 0; k < S; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) dwv[k][j][t] = a.dw[((size_t)k * 64 + c4 + j) * 3 + t];
-    float bv[4], w0v[4][3];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int c = nt * 16 + cl;
-        bv[nt] = a.bias[c];
-        if (LAST) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t) w0v[nt][t] = a.w0[c * 3 + t];
-        }
-    }
-    const int FI = a.FO / S, nseg = a.FO / R;
-    const long ntiles = (long)a.BT * nseg;
-    // the input run of a tile: bands fi0 - 1 .. fi0 + RI of frame bt (bands outside the frame read as zero), in 16-byte pieces
-    auto load_tile = [&](long tile, float4 (&ve)[NP], float4 (&vp)[NP], float4 (&ve0)[NE]) __attribute__((always_inline)) {
-        const long bt = tile / nseg;
-        const int seg = (int)(tile - bt * nseg), fi0 = seg * RI;
-        const float* ep = a.e + ((size_t)bt * FI + fi0) * 64;
-        const float* pp = a.prev + ((size_t)bt * FI + fi0) * 64;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int row = r16 + 16 * i, fi = fi0 - 1 + row;
-            const bool ok = row < RI + 2 && fi >= 0 && fi < FI;
-            ve[i] = ok ? *(const float4*)(ep + (long)(row - 1) * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vp[i] = ok ? *(const float4*)(pp + (long)(row - 1) * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (LAST) {
-            const float* e0p = a.e0 + ((size_t)bt * a.FO + (size_t)seg * R) * 64;
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int row = r16 + 16 * i;
-                ve0[i] = row < R ? *(const float4*)(e0p + (long)row * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    long tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    float4 ve[NP], vp[NP], ve0[NE];
-    load_tile(tile, ve, vp, ve0);
-    for (; tile < ntiles; tile += gridDim.x) {
-        const long bt = tile / nseg;
-        const int seg = (int)(tile - bt * nseg), fi0 = seg * RI;
-        // ---- u for input bands fi0 - 1 .. fi0 + RI (halo bands outside the frame stay zero: the pathway term too)
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int row = r16 + 16 * i, fi = fi0 - 1 + row;
-            if (row < RI + 2) {
-                float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (fi >= 0 && fi < FI) {
-                    u.x = relu_f(__builtin_fmaf(s1.x, ve[i].x, b1.x)) + vp[i].x; u.y = relu_f(__builtin_fmaf(s1.y, ve[i].y, b1.y)) + vp[i].y;
-                    u.z = relu_f(__builtin_fmaf(s1.z, ve[i].z, b1.z)) + vp[i].z; u.w = relu_f(__builtin_fmaf(s1.w, ve[i].w, b1.w)) + vp[i].w;
-                }
-                *(float4*)&U1[row][c4] = u;
-            }
-        }
-        if (LAST) {
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int row = r16 + 16 * i;
-                if (row < R) {
-                    float4 u;
-                    u.x = relu_f(__builtin_fmaf(s0.x, ve0[i].x, b0.x)); u.y = relu_f(__builtin_fmaf(s0.y, ve0[i].y, b0.y));
-                    u.z = relu_f(__builtin_fmaf(s0.z, ve0[i].z, b0.z)); u.w = relu_f(__builtin_fmaf(s0.w, ve0[i].w, b0.w));
-                    *(float4*)&E0[row][c4] = u;
-                }
-            }
-        }
-        const long next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next, ve, vp, ve0);                 // in flight under the rest of this tile
-        __syncthreads();
-        // ---- sub-pixel depthwise: output band fo = S f + k <- u bands f - 1 .. f + 1 with conv k
-        for (int r = r16; r < R; r += 16) {
-            const int f = r / S, k = r - f * S;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const float4 x = *(const float4*)&U1[f + t][c4];
-                float d0 = dwv[0][0][t], d1 = dwv[0][1][t], d2 = dwv[0][2][t], d3 = dwv[0][3][t];
-#pragma unroll
-                for (int kk = 1; kk < S; ++kk)
-                    if (k == kk) { d0 = dwv[kk][0][t]; d1 = dwv[kk][1][t]; d2 = dwv[kk][2][t]; d3 = dwv[kk][3][t]; }
-                v.x += d0 * x.x; v.y += d1 * x.y; v.z += d2 * x.z; v.w += d3 * x.w;
-            }
-            *(float4*)&As[r][c4] = v;
-        }
-        __syncthreads();
-        // ---- pointwise 64 x 64: wave w takes row tiles w, w + 4, ...
-        const size_t orow0 = ((size_t)bt * a.FO + (size_t)seg * R);
-        for (int rt = w; rt < NRT; rt += 4) {
-            f32x4 acc[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float* arow = &As[16 * rt + cl][4 * q];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 a4 = *(const float4*)(arow + 16 * c);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int bi = (c * 4 + nt) * 4;
-                    acc[nt] = mfma16(a4.x, breg[bi + 0], acc[nt]);
-                    acc[nt] = mfma16(a4.y, breg[bi + 1], acc[nt]);
-                    acc[nt] = mfma16(a4.z, breg[bi + 2], acc[nt]);
-                    acc[nt] = mfma16(a4.w, breg[bi + 3], acc[nt]);
-                }
-            }
-            if (!LAST) {
-                // the wave overwrites only the rows it has just read
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) As[16 * rt + 4 * q + i][nt * 16 + cl] = relu_f(acc[nt][i] + bv[nt]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int lr = 16 * rt + 4 * q + i;
-                    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const float u = relu_f(acc[nt][i] + bv[nt]) + E0[lr][nt * 16 + cl];
-                        t0 = __builtin_fmaf(w0v[nt][0], u, t0); t1 = __builtin_fmaf(w0v[nt][1], u, t1); t2 = __builtin_fmaf(w0v[nt][2], u, t2);
-                    }
-                    t0 = row16_allreduce_sum(t0); t1 = row16_allreduce_sum(t1); t2 = row16_allreduce_sum(t2);
-                    if (cl == 0) *(float4*)(a.ssum + (orow0 + lr) * 4) = make_float4(t0, t1, t2, 0.f);
-                }
-            }
-        }
-        __syncthreads();
-        if (!LAST) {
-            for (int r = r16; r < R; r += 16) *(float4*)(a.out + (orow0 + r) * 64 + c4) = *(const float4*)&As[r][c4];
-        }
-        // U1 / E0 are rewritten at the top of the next tile: their last readers are behind the barrier above; As is rewritten
-        // after the next tile's first barrier, i.e. after every thread has finished the read-out above
-    }
-}
+// (dec_seg_kernel itself -- one tile through four barrier-separated phases, two 256-thread workgroups per CU -- was superseded by the
+// tile-pipelined dec_seg2.h in round 5 and removed in round 6; its argument block and tile plan above are dec_seg2's.)

@@ -42,108 +42,7 @@ struct Dft2Args {
     RowSeg seg; int M;                 // frames of this launch
 };
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// forward stage 1: FR frames per workgroup; windowed samples (centre / reflect padding, per-clip lengths: as StftA) staged in
-// LDS, 15 row tiles of (frame, n2) over the four waves.
-template <int N2>
-__global__ __launch_bounds__(256) void dft2_fwd1_kernel(Dft2Args g) {
-    using C = Dft2Cfg<N2>;
-    __shared__ float xs[C::FR][C::N];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
-    const int fr0 = blockIdx.x * C::FR;
-    for (int idx = tid; idx < C::FR * C::N; idx += 256) {
-        const int f = idx / C::N, n = idx - f * C::N, fr = fr0 + f;
-        float v = 0.f;
-        if (fr < g.M) {
-            const int b = fr / g.seg.Tc, t = g.seg.t0 + (fr - b * g.seg.Tc);
-            const int nb_ = g.lens ? g.lens[b] : g.N, np_ = nb_ + C::N;
-            int j = t * g.hop + n - C::N / 2;
-            if (j < 0) j = -j;
-            if (j >= np_) j = 2 * (np_ - 1) - j;
-            const bool live = !g.lens || t < 1 + np_ / g.hop;
-            if (live && j >= 0 && j < nb_) v = g.wav[(size_t)b * g.N + j] * g.window[n];
-        }
-        xs[f][n] = v;
-    }
-    float bf[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) bf[i] = g.frag_a[(size_t)i * 64 + lane];
-    __syncthreads();
-    for (int rt = w; rt < 15; rt += 4) {
-        const int row = rt * 16 + cl, f = row / N2, n2 = row - f * N2;
-        f32x4 acc[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const float a = xs[f][N2 * (16 * c + 4 * q + kb) + n2];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma16(a, bf[(c * 4 + nt) * 4 + kb], acc[nt]);
-            }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rt * 16 + 4 * q + i;
-            if (fr0 + r / N2 < g.M) {
-                float* o = g.mid + ((size_t)fr0 * N2 + r) * 64 + cl;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) o[nt * 16] = acc[nt][i];
-            }
-        }
-    }
-}
-
-// forward stage 2: workgroup = (16 frames, k1 half); wave w takes k1 = 16 h + 4 w + j, j = 0..3.  A rows come straight from the
-// intermediate (two 8-byte pieces per lane and K chunk; a 256-byte line (frame, n2) serves the 16 k1 of a half); results are
-// gathered in an LDS tile [frame][k2][k1][re,im] and leave as contiguous 128-byte runs of spectrum bins.
-template <int N2>
-__global__ __launch_bounds__(256) void dft2_fwd2_kernel(Dft2Args g) {
-    using C = Dft2Cfg<N2>;
-    __shared__ __attribute__((aligned(16))) float zs[16][C::NT2 * 8][32];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 15, q = lane >> 4;
-    const int fr0 = blockIdx.x * 16, h = blockIdx.y;
-    const int fra = min(fr0 + cl, g.M - 1);                   // A row of this lane (clamped; rows >= M are not stored)
-    const float* yrow = g.mid + (size_t)fra * N2 * 64;
-    for (int j = 0; j < 4; ++j) {
-        const int k1 = 16 * h + 4 * w + j;
-        const float* bp = g.frag_b + (size_t)k1 * C::F2 + lane;
-        float bfr[C::KC * C::NT2 * 4];
-#pragma unroll
-        for (int i = 0; i < C::KC * C::NT2 * 4; ++i) bfr[i] = bp[(size_t)i * 64];
-        f32x4 acc[C::NT2];
-#pragma unroll
-        for (int nt = 0; nt < C::NT2; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < C::KC; ++c) {
-            const int n2a = 8 * c + 2 * q;                    // K index kk = 16 c + 4 q + kb = (n2 = n2a + kb / 2, re / im = kb & 1)
-            float2 p0 = make_float2(0.f, 0.f), p1 = p0;
-            if (n2a < N2) p0 = *(const float2*)(yrow + (size_t)n2a * 64 + 2 * k1);
-            if (n2a + 1 < N2) p1 = *(const float2*)(yrow + (size_t)(n2a + 1) * 64 + 2 * k1);
-            const float av[4] = {p0.x, p0.y, p1.x, p1.y};
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int nt = 0; nt < C::NT2; ++nt) acc[nt] = mfma16(av[kb], bfr[(c * C::NT2 + nt) * 4 + kb], acc[nt]);
-        }
-#pragma unroll
-        for (int nt = 0; nt < C::NT2; ++nt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = nt * 16 + cl;                 // (k2 = col >> 1, re / im = col & 1)
-                zs[4 * q + i][col >> 1][(4 * w + j) * 2 + (col & 1)] = acc[nt][i];
-            }
-    }
-    __syncthreads();
-    // [16 frames][k2][16 k1] bins, 8 bytes each: a (frame, k2) is 16 consecutive bins k = 16 h + 32 k2 .. + 15
-    for (int idx = tid; idx < 16 * C::NK2 * 16; idx += 256) {
-        const int k1l = idx & 15, rest = idx >> 4, k2 = rest % C::NK2, fl = rest / C::NK2;
-        const int fr = fr0 + fl, k = 16 * h + k1l + 32 * k2;
-        if (fr < g.M && k < C::F)
-            *(float2*)(g.spec + g.seg.map(fr) * C::SPEC + 2 * k) = *(const float2*)&zs[fl][k2][2 * k1l];
-    }
-}
-
+// (the analysis stages dft2_fwd1 / dft2_fwd2 of rounds 3-5 are gone: the analysis DFT is float64, dft64.h)
 // ---------------------------------------------------------------------------------------------------------------------------
 // inverse stage A: workgroup = (16 frames, k1 half): per k1 the N2 bins k1 + 32 k2 of a frame (bins above N / 2 read their mirror;
 // the conjugation sits in the operand) -> N2 complex U[n2]; gathered in LDS [frame][n2][k1][re,im], written as 128-byte runs.
@@ -233,21 +132,11 @@ __global__ __launch_bounds__(256) void dft2_invB_kernel(Dft2Args g) {
 }
 
 template <int N2>
-static inline void launch_dft2_forward(hipStream_t st, const Dft2Args& a) {
-    if (a.M <= 0) return;
-    constexpr int FR = Dft2Cfg<N2>::FR;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(dft2_fwd1_kernel<N2>), dim3((a.M + FR - 1) / FR), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(dft2_fwd2_kernel<N2>), dim3((a.M + 15) / 16, 2), dim3(256), 0, st, a);
-}
-template <int N2>
 static inline void launch_dft2_inverse(hipStream_t st, const Dft2Args& a) {
     if (a.M <= 0) return;
     constexpr int FR = Dft2Cfg<N2>::FR;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(dft2_invA_kernel<N2>), dim3((a.M + 15) / 16, 2), dim3(256), 0, st, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(dft2_invB_kernel<N2>), dim3((a.M + FR - 1) / FR), dim3(256), 0, st, a);
-}
-static inline void launch_dft2_forward(hipStream_t st, const Dft2Args& a, int win) {
-    if (win == 960) launch_dft2_forward<30>(st, a); else launch_dft2_forward<10>(st, a);
 }
 static inline void launch_dft2_inverse(hipStream_t st, const Dft2Args& a, int win) {
     if (win == 960) launch_dft2_inverse<30>(st, a); else launch_dft2_inverse<10>(st, a);

@@ -138,167 +138,8 @@ struct HopGlueArgs {
     int M;
 };
 
-template <bool NEXT>
-__global__ __launch_bounds__(256) void dprnn_hop_glue_kernel(HopGlueArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[16][132];
-    __shared__ __attribute__((aligned(16))) float Fs[16][68];
-    __shared__ __attribute__((aligned(16))) float Ys[16][68];      // y1, later y2
-    __shared__ __attribute__((aligned(16))) float Hs[16][68];      // h, later h'
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int cl = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * 16;
-    for (int f = tid; f < 16 * 32; f += 256) {
-        const int r = f >> 5, c4 = f & 31;
-        int row = row0 + r; if (row >= g.M) row = g.M - 1;
-        *(float4*)&As[r][4 * c4] = *(const float4*)(g.hcat + (size_t)row * 128 + 4 * c4);
-    }
-    const int rr = tid >> 4, rc4 = 4 * (tid & 15);
-    const bool rok = row0 + rr < g.M;
-    const int grow = rok ? row0 + rr : g.M - 1;
-    const float4 xres = *(const float4*)(g.x + (size_t)grow * 64 + rc4);
-    {   // carried hidden state of the 16 rows (row-contiguous pieces)
-        const float* hp = g.hstate + (long)(grow / g.rdiv) * g.h_hi + (long)(grow % g.rdiv) * g.h_lo + rc4;
-        *(float4*)&Hs[rr][rc4] = *(const float4*)hp;
-    }
-    // inter-band GRU fragments of this wave (units [16 w, 16 w + 16)), issued early
-    float wih[3][16], whh[3][16];
-    {
-        const float* wp = g.wfrag + ((size_t)w * 2) * 3 * 16 * 64 + lane;
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { wih[gt][j] = wp[(size_t)((0 * 3 + gt) * 16 + j) * 64]; whh[gt][j] = wp[(size_t)((1 * 3 + gt) * 16 + j) * 64]; }
-    }
-    const float b_r = g.bias[16 * w + cl], b_z = g.bias[64 + 16 * w + cl], b_in = g.bias[128 + 16 * w + cl], b_hn = g.bias[192 + 16 * w + cl];
-    // every other operand of the launch too: the kernel is a chain of short dependent phases, a load issued inside one
-    // would cost its full L2 latency there
-    float ffi[32], ffe[16], fih[NEXT ? 96 : 1];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) ffi[k] = g.fci_frag[(size_t)((((k >> 2) * 4 + w) * 4 + (k & 3)) * 64) + lane];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) ffe[k] = g.fce_frag[(size_t)((((k >> 2) * 4 + w) * 4 + (k & 3)) * 64) + lane];
-    if (NEXT) {
-#pragma unroll
-        for (int gp = 0; gp < 6; ++gp)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) fih[gp * 16 + k] = g.ih_frag[(size_t)gp * 4096 + (size_t)((((k >> 2) * 4 + w) * 4 + (k & 3)) * 64) + lane];
-    }
-    const float bfi = g.fci_b[16 * w + cl], bfe = g.fce_b[16 * w + cl];
-    __syncthreads();
-    auto layer_norm_res = [&](const float4 v, const float4 res, const float* gam, const float* bet) {
-        const float mean = row16_allreduce_sum(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
-        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-        const float s2 = row16_allreduce_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-        const float inv = rsqrtf(s2 * (1.0f / 64.0f) + 1e-5f);
-        const float4 gg = *(const float4*)(gam + rc4), bb = *(const float4*)(bet + rc4);
-        float4 o;
-        o.x = res.x + d0 * inv * gg.x + bb.x; o.y = res.y + d1 * inv * gg.y + bb.y;
-        o.z = res.z + d2 * inv * gg.z + bb.z; o.w = res.w + d3 * inv * gg.w + bb.w;
-        return o;
-    };
-    // ---- fc_intra (K = 128), wave w -> columns [16 w, 16 w + 16)
-    {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-        for (int c = 0; c < 8; c += 2) {
-            const float4 a4 = *(const float4*)&As[cl][16 * c + 4 * q], b4 = *(const float4*)&As[cl][16 * c + 16 + 4 * q];
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv4[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                acc0 = mfma16(av[kb], ffi[c * 4 + kb], acc0);
-                acc1 = mfma16(bv4[kb], ffi[(c + 1) * 4 + kb], acc1);
-            }
-        }
-        const float bv = bfi;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Fs[4 * q + i][16 * w + cl] = acc0[i] + acc1[i] + bv;
-    }
-    __syncthreads();
-    const float4 y1 = layer_norm_res(*(const float4*)&Fs[rr][rc4], xres, g.lni_g, g.lni_b);
-    *(float4*)&Ys[rr][rc4] = y1;
-    __syncthreads();
-    // ---- inter-band GRUCell step
-    {
-        f32x4 ar = {b_r, b_r, b_r, b_r}, az = {b_z, b_z, b_z, b_z}, axn = {b_in, b_in, b_in, b_in}, ahn = {b_hn, b_hn, b_hn, b_hn};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 x4 = *(const float4*)&Ys[cl][16 * c + 4 * q], h4 = *(const float4*)&Hs[cl][16 * c + 4 * q];
-            const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                ar = mfma16(xv[kb], wih[0][c * 4 + kb], ar);
-                az = mfma16(xv[kb], wih[1][c * 4 + kb], az);
-                axn = mfma16(xv[kb], wih[2][c * 4 + kb], axn);
-            }
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                ar = mfma16(hv[kb], whh[0][c * 4 + kb], ar);
-                az = mfma16(hv[kb], whh[1][c * 4 + kb], az);
-                ahn = mfma16(hv[kb], whh[2][c * 4 + kb], ahn);
-            }
-        }
-        float hn[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hn[i] = gru64_cell(ar[i], az[i], axn[i], ahn[i], Hs[4 * q + i][16 * w + cl]);
-        __syncthreads();                      // every wave has read h
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Hs[4 * q + i][16 * w + cl] = hn[i];
-    }
-    __syncthreads();
-    if (rok) {      // h' back into the carried state (row-contiguous pieces)
-        float* hp = g.hstate + (long)(grow / g.rdiv) * g.h_hi + (long)(grow % g.rdiv) * g.h_lo + rc4;
-        *(float4*)hp = *(const float4*)&Hs[rr][rc4];
-    }
-    // ---- fc_inter (K = 64) on h'
-    {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-        for (int c = 0; c < 4; c += 2) {
-            const float4 a4 = *(const float4*)&Hs[cl][16 * c + 4 * q], b4 = *(const float4*)&Hs[cl][16 * c + 16 + 4 * q];
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv4[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                acc0 = mfma16(av[kb], ffe[c * 4 + kb], acc0);
-                acc1 = mfma16(bv4[kb], ffe[(c + 1) * 4 + kb], acc1);
-            }
-        }
-        const float bv = bfe;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Fs[4 * q + i][16 * w + cl] = acc0[i] + acc1[i] + bv;
-    }
-    __syncthreads();
-    const float4 y2 = layer_norm_res(*(const float4*)&Fs[rr][rc4], y1, g.lne_g, g.lne_b);
-    if (rok) *(float4*)(g.y2 + (size_t)(row0 + rr) * 64 + rc4) = y2;
-    if (NEXT) {
-        __syncthreads();                      // every wave is done with y1 in Ys
-        *(float4*)&Ys[rr][rc4] = y2;
-        __syncthreads();
-        float4 y4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) y4[c] = *(const float4*)&Ys[cl][16 * c + 4 * q];
-        f32x4 acc[6];
-#pragma unroll
-        for (int gp = 0; gp < 6; ++gp) acc[gp] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float yv[4] = {y4[c].x, y4[c].y, y4[c].z, y4[c].w};
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int gp = 0; gp < 6; ++gp) acc[gp] = mfma16(yv[kb], fih[NEXT ? gp * 16 + c * 4 + kb : 0], acc[gp]);
-        }
-#pragma unroll
-        for (int gp = 0; gp < 6; ++gp) {
-            const int col = gp * 64 + w * 16 + cl;
-            const float bv = g.ih_bias[col];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = row0 + 4 * q + i;
-                if (row < g.M) g.gi[(size_t)row * 384 + col] = acc[gp][i] + bv;
-            }
-        }
-    }
-}
+// (the four-wave form dprnn_hop_glue_kernel -- 240 MFMAs and 240 weight registers per wave -- was replaced by the eight-wave form below in
+// round 3 and removed in round 6.)
 
 // ---------------------------------------------------------------------------------------------
 // dprnn_hop_glue8_kernel<NEXT>: the same launch on EIGHT waves per 16-row tile.  A hop's glue launch is a chain of short

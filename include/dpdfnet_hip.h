@@ -183,43 +183,17 @@ int dpdf_set_chunk_frames(dpdf_model* m, int frames);
 /* Execution-shape mask (default 27 = 1|2|8|16): bit 0 stage 2 of chunk i (GRU-256 scans, decoders) on its own HIP stream
  * underneath stage 1 of chunk i+1; bit 1 the ERB encoder branch on its own stream; bit 3 the DF decoder beside the ERB decoder
  * inside stage 2; bit 4 eight / sixteen (not four) workgroups per tile in the GRU-256 cluster scans of small launches.
- * 0: everything serial on one stream (A/B timing).  Bits 2 and 5 (two lanes; five-stream sub-stage pipeline) selected forms that
- * were measured slower and have been removed; they are accepted and ignored. */
+ * 0: everything serial on one stream (A/B timing).  Other bits are ignored. */
 int dpdf_set_overlap(dpdf_model* m, int mask);
 /* Where fc + LayerNorm + residual of every DPRNN block run: 2 always inside the GRU-64 scan kernels;
  * 0 always as separate GEMM kernels; 1 (default) picks per chunk -- fused once streams x frames fills the
  * chip (>= 3072 frame rows), separate below that (single-hop streaming, small batches). */
 int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
-/* Further A/B switches by name (measurement only; results equal to rounding): "fuse_mask" (1: the mask head's 64->1
- * contraction runs in the last decoder stage's epilogue, 0: stand-alone kernel), "dec_seg" (the 48 kHz decoder stages: 2 =
- * band-segment tiles pipelined inside one workgroup, dec_seg2_kernel, on "dec_seg_grid" workgroups; 3 = the same in one launch
- * (slower in the pipeline); 1 = band-segment tiles, dec_seg_kernel; 0 = gemm_rows producers), "df_ring" (df_conv0 + df_conv1 + DF pathway conv as one
- * time-walking pass for big batches; 0: time-parallel GEMM launches), "hoist_gi" (small-batch GRU-64 input GEMM hoisting),
- * "scan4_max_wgs" (default 512: hoisted-input GRU-64 scans run on 4-row tiles, gru64_scan4_gi_kernel, while the launch has at
- * most this many workgroups; 0 never), "gru256_cluster" (0: single-workgroup GRU-256 scan, the form without cross-workgroup
- * waits), "gru256_c8_tiles" / "gru256_c16_tiles" (launches of at most this many 16-row tiles run the GRU-256 scans on 8 / 16
- * workgroups per tile; defaults 4 / 2), "gru256_stack" (1: launches of at most gru256_c16_tiles tiles run the two cells of each
- * decoder stack as one wavefront launch, gru_stack.h), "tail_frames" (default 32: >= 96 streams, automatic chunking: a last
- * chunk of >= 96 frames gives up a tail chunk of this many frames; 0 off), "fcln_gi" / "hop_glue" / "gru256_step" (small-batch
- * and single-hop launch fusions, fcln_gi.h, gru_stack.h; default 1), "stft_ksplit" (bit 0: STFT of a few 48 kHz frames split
- * over K, bit 1: streaming iSTFT split over K; default 3).  Small-launch forms (<= 512 frame rows; default 1, 0 = the plain
- * per-layer launches): "fuse_small" (mask + deep filter in one launch, grouped linears chained per tile), "fuse_gl", "fuse_enc"
- * (enc_seg.h: each encoder front end as one LDS-pyramid launch, bit-identical to the plain kernels), "fuse_dec" (dec_pyr.h: the
- * ERB decoder's three stages + mask tap sums), "enc_seg_rows" / "dec_pyr_rows" (their row thresholds, default 512),
- * "interleave" (the two encoder branches' DPRNN blocks enqueued alternately).  One-chunk calls (a streaming hop, a clip of <=
- * 256 frames; default 1): "single_chunk_inline" (stage 2 on the main stream: no cross-stream handoff on the chain),
- * "hop_prologue" (> 4 streams: staging + FIFO import + state copy as one launch in front of the STFT), "late_export" (the hop's
- * FIFO export behind the overlap-add, the host waits for the output event), "dual_step" (the two decoders' GRU-256 steps
- * pairwise in one launch), "hop_pconv" (the DF pathway conv inside the front-end launch), "dfout_in_decin" (df_out as extra
- * workgroups of the ERB decoder's input-linear launch), "hop_dec_fork" (default 0; 1: the DF decoder on its own stream also in
- * one-chunk calls), "snapshot" (default 1; 0 disables the streaming calls' pre-call state copy and with it the automatic
- * recovery -- timing only).  Round 4: "dft2" (1: the analysis / synthesis DFT of big launches as two small matrix stages,
- * dft2stage.h; 0: one [win x 2F] GEMM), "hop_fused" (a streaming hop's DPRNN scan and glue as one launch), "hop_spin_join" (stage 2 of a hop waits for the ERB stack by counter instead of a cross-stream event; only while this is the process's one engine handle), "gru256_fused_x" / "gru256_fused_x_tiles" (1 / 6: from six 16-row tiles on the GRU-256
- * input projection runs inside the four-workgroup cluster scan, gru_clusterx.h; 0: hoisted GEMM + scan), "host_pipe" (1:
- * host-pointer batch calls pipelined over time slices), "host_copy_threads" (4), "host_prefault" (1: a helper thread populates
- * the caller's output rows while the first chunk computes), "chunk_io" (default 0; 1: per-chunk STFT / iSTFT also for
- * device-pointer calls -- measured, no gain).  Unknown name -> DPDF_E_INVALID.  (Removed after measurement, see
- * docs/HISTORY.md section 7 and tools/experimental/: "gru64_bf16x3", "gru256_pair", "gru256_chain", "pipe_chunk".) */
+/* Engine switches by name: every name, its default, what it selects and the test that exercises it are ONE table, docs/OPTIONS.md
+ * (tests/test_options_table.py keeps the table, the library and the tests in step).  Two kinds: MODES a caller may want --
+ * "gru64_limbs" (0 default; 3: the GRU-64 throughput kernels on bf16 limbs, gru_limb.h: fp32-exact products on the bf16 matrix pipe,
+ * opt-in), "host_pipe", "host_copy_threads", "snapshot", "tail_frames" -- and A/B switches between kernel forms that give results
+ * equal to rounding (measurement and recovery only).  Unknown name -> DPDF_E_INVALID. */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);
 
 /* Rational polyphase resampler on the device, for `ensure_sample_rate` when the caller's rate differs from the

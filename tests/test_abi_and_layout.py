@@ -145,15 +145,16 @@ def test_banked_profiles_are_of_this_build():
 
 def test_limb_kernel_microbenchmark_builds_for_gfx950(tmp_path):
     """tools/gru64_limb_bench.hip (the limb GRU-64 kernels against the fp32-MFMA kernels and a float64 recurrence) and the bf16 MFMA /
-    VALU overlap probe stay buildable: DESIGN.md section 3a quotes their output; so does tools/dec_seg_bench.hip (the 48 kHz decoder stage
-    kernels alone, dec_seg_kernel against dec_seg2_kernel)."""
+    VALU overlap probe stay buildable: DESIGN.md section 3a quotes their output; so does tools/pk_fma_coissue_probe.hip (the stand-alone
+    reproducer of the packed-FP32 hazard)."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(hipcc).exists():
         pytest.skip("no hipcc")
-    for src in ("tools/gru64_limb_bench.hip", "tools/mfma_bf16_valu_overlap.hip", "tools/dec_seg_bench.hip"):
+    for src in ("tools/gru64_limb_bench.hip", "tools/mfma_bf16_valu_overlap.hip", "tools/pk_fma_coissue_probe.hip"):
         out = tmp_path / (Path(src).stem + ".o")
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", str(ROOT / src), "-o", str(out)], capture_output=True, text=True)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + str(ROOT / "dpdfnet_amd" / "csrc"), "-I" + str(ROOT / "include"), "-c", str(ROOT / src), "-o", str(out)],
+                           capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         assert out.stat().st_size > 10000

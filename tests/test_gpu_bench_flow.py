@@ -54,7 +54,10 @@ def test_single_gpu_line_has_the_contract_fields():
     # the public Python API (list of numpy clips in, list out) rides on the same line
     assert d["pcie"]["max_abs_diff_vs_hbm_resident_output"] == 0.0 and d["pcie"]["ms_per_step_unpipelined"] > 0
     assert d["value_public_api"] > 0 and d["public_api"]["finite_output"] is True
-    assert d["public_api"]["max_abs_diff_vs_hbm_resident_output"] == 0.0
+    # (with DPDF_GRU64_LIMBS in the environment the public API's own handle runs the opt-in limb kernels while the headline stays fp32 MFMA:
+    # equal to rounding then, bit-identical otherwise)
+    import os
+    assert d["public_api"]["max_abs_diff_vs_hbm_resident_output"] <= (5e-6 if os.environ.get("DPDF_GRU64_LIMBS", "0") not in ("", "0") else 0.0)
     # RCCL has executed on this box: one-rank process group (backend nccl) in a child process, the collectives of the N > 1 path
     st = d["rccl_selftest"]
     # the child streams stage stamps and runs under a 60 s cap: a run that did not finish must SAY where it stopped (round-4 review:

@@ -180,6 +180,43 @@ int main() {
         (void)hipDeviceSynchronize();
         cmp("inter block output y", y1, y2, (size_t)16 * Tc * Fp * 64);
         cmp("inter carried state ", hs1, hs2, (size_t)nr * 64);
+        // ---- both kernel families against a FLOAT64 recurrence: the carried state after Tc steps of the first 64 rows (same pre-scaled weights:
+        // r, z = 1 / (1 + 2^a), n = 2 / (1 + 2^(xn + r hn)) - 1, h' = n + z (h - n): common.h gru64_cell)
+        {
+            const int R = 64 < nr ? 64 : nr;
+            std::vector<double> hd((size_t)R * 64);
+            for (int r = 0; r < R; ++r) for (int u = 0; u < 64; ++u) hd[(size_t)r * 64 + u] = h0[(size_t)r * 64 + u];
+            std::vector<double> g(6 * 64);
+            for (int r = 0; r < R; ++r) {
+                const int hi = r / Fp, lo = r % Fp;
+                for (int t = 0; t < Tc; ++t) {
+                    const float* xr = h.data() + (size_t)hi * a.x_hi + (size_t)lo * a.x_lo + (size_t)t * a.x_step;
+                    double* hr = &hd[(size_t)r * 64];
+                    for (int gt = 0; gt < 3; ++gt) for (int u = 0; u < 64; ++u) {
+                        double sx = 0, sh = 0;
+                        for (int k = 0; k < 64; ++k) { sx += (double)Wc(0, 0, gt, u, k) * xr[k]; sh += (double)Wc(0, 1, gt, u, k) * hr[k]; }
+                        g[gt * 64 + u] = sx; g[(3 + gt) * 64 + u] = sh;
+                    }
+                    double hn_[64];
+                    for (int u = 0; u < 64; ++u) {
+                        const double ar = g[u] + g[192 + u] + B[u], az = g[64 + u] + g[256 + u] + B[64 + u];
+                        const double rr_ = 1.0 / (1.0 + exp2(ar)), zz = 1.0 / (1.0 + exp2(az));
+                        const double nn = 2.0 / (1.0 + exp2((g[128 + u] + B[128 + u]) + rr_ * (g[320 + u] + B[192 + u]))) - 1.0;
+                        hn_[u] = nn + zz * (hr[u] - nn);
+                    }
+                    for (int u = 0; u < 64; ++u) hr[u] = hn_[u];
+                }
+            }
+            std::vector<float> s1((size_t)R * 64), s2((size_t)R * 64);
+            (void)hipMemcpy(s1.data(), hs1, s1.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(s2.data(), hs2, s2.size() * 4, hipMemcpyDeviceToHost);
+            double d1 = 0, d2 = 0, m1 = 0, m2 = 0, sg = 0;
+            for (size_t i = 0; i < hd.size(); ++i) {
+                const double e1 = s1[i] - hd[i], e2 = s2[i] - hd[i];
+                d1 += e1 * e1; d2 += e2 * e2; sg += hd[i] * hd[i]; if (fabs(e1) > m1) m1 = fabs(e1); if (fabs(e2) > m2) m2 = fabs(e2);
+            }
+            printf("float64 recurrence (%d rows x %d steps, state RMS %.3f): fp32-MFMA kernel RMS %.3e max %.3e | limb kernel RMS %.3e max %.3e\n",
+                   R, Tc, sqrt(sg / hd.size()), sqrt(d1 / hd.size()), m1, sqrt(d2 / hd.size()), m2);
+        }
     }
     return 0;
 }

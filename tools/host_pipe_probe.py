@@ -41,10 +41,8 @@ def call_fresh():
     backend._check(m._L.dpdf_enhance_batch(m._h, wav.ctypes.data, B, N, float("nan"), o.ctypes.data, 0))
     return o
 for pf in (1, 0):
-    m.set_option("host_prefault", pf)
     ms, _ = t(call_fresh)
     print(f"host block, fresh np.empty out, prefault {pf} {ms:8.2f} ms", flush=True)
-m.set_option("host_prefault", 1)
 ms, _ = t(lambda: m.enhance_batch(wav))
 print(f"host block, HipModel.enhance_batch (leased out block) {ms:8.2f} ms", flush=True)
 clips = [c.copy() for c in wav]

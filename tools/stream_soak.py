@@ -8,7 +8,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[1]; sys.path.insert(0, str(ROOT))
 from dpdfnet_amd import backend as be
 from dpdfnet_amd.weights import synth_blob
-PLAIN = {"single_chunk_inline": 0, "hop_prologue": 0, "late_export": 0, "dual_step": 0, "hop_pconv": 0, "dfout_in_decin": 0,
+PLAIN = {"single_chunk_inline": 0, "hop_prologue": 0, "late_export": 0, "dual_step": 0, "hop_pconv": 0,
          "fuse_enc": 0, "fuse_dec": 0, "fuse_small": 0}
 
 def rms(x): return float(np.sqrt(np.mean(np.square(x.astype(np.float64)))))

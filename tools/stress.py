@@ -18,7 +18,7 @@ def run(budget: float = 60.0, seed: int = 1, min_cases: int = 0) -> dict:
         if (sr, nb) not in models:
             models[(sr, nb)] = be.HipModel(sr, nb, synth_blob(be.manifest(sr, nb), 20260417), 0)
             import os
-            for kv in filter(None, os.environ.get("DPDF_STRESS_OPTS", "").split(",")):      # bisecting: DPDF_STRESS_OPTS=glue8=0,fuse_small=0
+            for kv in filter(None, os.environ.get("DPDF_STRESS_OPTS", "").split(",")):      # bisecting: DPDF_STRESS_OPTS=hop_fused=0,fuse_small=0
                 models[(sr, nb)].set_option(kv.split("=")[0], int(kv.split("=")[1]))
         return models[(sr, nb)]
 
