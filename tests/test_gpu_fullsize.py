@@ -184,9 +184,10 @@ def test_config5_64_streams_48khz_dpdfnet8(be):
 def test_limb_and_fp32_gru64_kernels_agree_on_every_clip_of_a_pipelined_batch(be):
     """The opt-in GRU-64 throughput kernels on bf16 limbs (gru_limb.h, gru64_limbs = 3) against the default fp32-MFMA kernels of gru_scan.h, 256 clips through
     the multi-chunk pipeline (stage 2 of a chunk under stage 1 of the next), several times over: every clip within fp32 rounding of the
-    other path, and each path bit-identical to itself run to run.  (Round 5: with the faster stage 1 the deep-filter kernel read taps
-    whose 128-byte lines two XCDs had written piecewise -- single wrong low-band frames in a few clips per run; the taps are read with
-    agent-scope loads since: common.h ld_agent.)"""
+    other path, each path bit-identical to itself run to run AND to its own serial schedule (one stream, nothing side by side).  This is the
+    dynamic guard of DESIGN.md section 6: in round 5 the deep-filter kernel's packed FP32 products (v_pk_fma_f32) lost half of a result
+    beside the limb kernels' bf16 MFMAs -- single wrong low-band frames in 23-36 clips per run, never the same twice; the library is built
+    without packed FP32 instructions since round 6 (tests/test_no_packed_fp32.py is the static guard)."""
     m, blob = _model(be, 16000, 4)
     rng = np.random.default_rng(3)
     B, n = 256, 160 * 64 * 8
@@ -194,17 +195,18 @@ def test_limb_and_fp32_gru64_kernels_agree_on_every_clip_of_a_pipelined_batch(be
     m.set_chunk_frames(64)
     m.set_option("gru64_limbs", 0)
     y0 = m.enhance_batch(wav, None)
-    assert np.array_equal(y0, m.enhance_batch(wav, None))
+    for rep in range(3):
+        assert np.array_equal(y0, m.enhance_batch(wav, None)), rep
+    m.set_overlap(0)
+    assert np.array_equal(y0, m.enhance_batch(wav, None)), "default kernels: pipelined schedule differs from the serial one"
     m.set_option("gru64_limbs", 3)
-    first = None
+    y1_serial = m.enhance_batch(wav, None)
+    m.set_overlap(27)
     for rep in range(6):
         y1 = m.enhance_batch(wav, None)
         d = np.sqrt(np.mean((y1.astype(np.float64) - y0) ** 2, axis=1))
         assert d.max() < 5e-7, (rep, int(d.argmax()), float(d.max()))
-        if first is None:
-            first = y1
-        else:
-            assert np.array_equal(y1, first), rep
+        assert np.array_equal(y1, y1_serial), (rep, "limb kernels: pipelined schedule differs from the serial one")
     m.set_chunk_frames(0)
     y2 = m.enhance_batch(wav, None)                     # the automatic schedule
     assert np.sqrt(np.mean((y2.astype(np.float64) - y0) ** 2, axis=1)).max() < 5e-7

@@ -646,3 +646,56 @@ def test_output_blocks_are_leased_and_recycled(monkeypatch):
     del d
     gc.collect()
     assert pool.idle_blocks() == 2
+
+
+def test_multi_gpu_summary_reads_a_scaling_line_without_a_rerun():
+    """bench.py's N > 1 line: per-rank step times as min / max / spread and the gather to rank 0 as a share of the slowest rank's step
+    (what the first hardware scaling curve needs)."""
+    import importlib.util
+    from tests.util import ROOT
+    spec = importlib.util.spec_from_file_location("dpdf_bench_for_test", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    per_rank = [{"rank": 1, "ms_per_step": 110.0, "gather_host_ms_per_step": 0.2, "gather_device_ms_per_step": None},
+                {"rank": 0, "ms_per_step": 100.0, "gather_host_ms_per_step": 0.3, "gather_device_ms_per_step": 5.5}]
+    s = bench.multi_gpu_summary(per_rank)
+    assert s["per_rank_ms_min"] == 100.0 and s["per_rank_ms_max"] == 110.0 and abs(s["per_rank_ms_spread"] - 10.0 / 110.0) < 1e-12
+    assert s["gather_ms_per_step_root_device"] == 5.5 and abs(s["gather_frac_of_step"] - 0.05) < 1e-12
+    assert s["gather_host_ms_per_step_max"] == 0.3
+    assert bench.multi_gpu_summary([]) == {}
+    # the opt-in block's float64 figures: absent tool -> said so, never invented
+    r = bench.float64_recurrence_error()
+    assert "available" in r and (r["available"] is False or r["limb_kernels"]["rms"] > 0)
+
+
+def test_pool_submit_calls_validate_what_they_hand_to_the_library():
+    """HipStreams.submit_wait / submit_block / submit_many hand raw pointers to the C ABI: a short, non-contiguous or float64 array must be
+    converted or refused in Python, never read out of bounds in native code (round-5 advisor finding)."""
+    import types
+    from dpdfnet_amd import backend
+    calls = []
+
+    class L:
+        def dpdf_streams_submit_wait(self, h, slot, inp, k, outp, flags): calls.append(("wait", slot, k)); return 0
+        def dpdf_streams_submit_block(self, h, n, slots, inp, k, outp, flags): calls.append(("block", n, k)); return 0
+        def dpdf_streams_submit_many(self, h, n, sl, ip, kk, op, flags): calls.append(("many", n)); return 0
+
+    st = backend.HipStreams.__new__(backend.HipStreams)
+    st.model = types.SimpleNamespace(hop=160, _L=L())
+    st._h = None
+    st.n = 4
+    out = st.submit_wait(1, np.zeros(320, np.float64), 2)             # converted to float32
+    assert out.shape == (320,) and out.dtype == np.float32
+    with pytest.raises(ValueError):
+        st.submit_wait(1, np.zeros(319, np.float32), 2)
+    with pytest.raises(ValueError):
+        st.submit_wait(1, np.zeros(160, np.float32), 0)
+    blk = st.submit_block([0, 2], np.zeros((2, 160), np.float32)[:, ::1], 1)
+    assert blk.shape == (2, 160)
+    with pytest.raises(ValueError):
+        st.submit_block(np.array([0, 2]), np.zeros((2, 150), np.float32), 1)
+    with pytest.raises(ValueError):
+        st.submit_many([0, 1], [np.zeros(160, np.float32)], [1, 1])
+    with pytest.raises(ValueError):
+        st.submit_many([0, 1], [np.zeros(160, np.float32), np.zeros(100, np.float32)], [1, 1])
+    assert [c[0] for c in calls] == ["wait", "block"]

@@ -21,3 +21,6 @@ cp $X/hop_16k_nb2_1stream_timeline.txt profiles/${T}_stream_hop_16k_1stream_time
 for c in 16k_nb2 16k_nb8 48k_nb2 48k_nb8; do cp $X/offline_${c}_256x10s_kernel_stats.csv profiles/${T}_offline_${c}_256x10s_kernel_stats.csv; done
 cp gpurun_out/${T}_latency.txt profiles/${T}_latency_bench.txt; cp gpurun_out/${T}_hop_ab.txt profiles/${T}_hop_same_process.txt
 grep "wall us/hop\|ms/step" $X/*.log
+[ -f gpurun_out/${T}_pk_fma_coissue_probe.txt ] && grep -v "^    thread" gpurun_out/${T}_pk_fma_coissue_probe.txt > profiles/${T}_pk_fma_coissue_probe_final_build.txt
+tail -4 gpurun_out/${T}_gpu_tests.log > profiles/${T}_gpu_tests_tail.txt
+cp gpurun_out/${T}_soak.txt profiles/${T}_soak.txt 2>/dev/null || true
