@@ -431,6 +431,21 @@ def other_configs(only=None) -> dict:
         for _ in range(calls):
             st.process(pcm)
         dt = (time.perf_counter() - t0) / calls
+        # the same hops from a native loop (tools/pool_native_feeders.cpp: native_hop_loop calls dpdf_streams_process `calls` times): the C-ABI
+        # figure without the interpreter between the hops
+        native_us = None
+        try:
+            import ctypes
+            helper = ctypes.CDLL(str(Path(__file__).resolve().parent / "tools" / "libpool_native_feeders.so"))
+            helper.native_hop_loop.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+            us = ctypes.c_double(0.0)
+            outb = np.empty_like(pcm)
+            fn = ctypes.cast(m._L.dpdf_streams_process, ctypes.c_void_p)
+            if helper.native_hop_loop(st._h, fn, calls, 20, pcm.ctypes.data, outb.ctypes.data, backend.DPDF_HOST_PTRS, ctypes.byref(us)) == 0:
+                native_us = round(us.value, 1)
+        except (OSError, AttributeError):
+            pass
         sparse = sparse_stream_parity(m, st, sr_, nb_, S) if sr_ == 48000 else None
         rec = m.recovery_count
         st.close(); m.close()
@@ -446,7 +461,7 @@ def other_configs(only=None) -> dict:
         steps = nb_ * d.Fd
         chain = nb_ + 19
         bound_us = steps * 0.41 + chain * 1.5
-        return {"us_per_call": round(1e6 * dt, 1), "frames_per_s": round(S / dt), "rtf": round(dt / (hop / sr_), 4),
+        return {"us_per_call": round(1e6 * dt, 1), "us_per_call_native_loop": native_us, "frames_per_s": round(S / dt), "rtf": round(dt / (hop / sr_), 4),
                 "mfma_frac": mfma(S / dt, sr_, nb_),
                 "latency_model": {"dependent_gru64_steps": steps, "dependent_launches_on_critical_path": chain,
                                   "bound_us": round(bound_us, 1), "achieved_over_bound": round(1e6 * dt / bound_us, 2)},

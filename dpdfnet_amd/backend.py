@@ -517,7 +517,7 @@ class HipModel:
         _check(self._L.dpdf_set_fuse_dprnn(self._h, code))
 
     def set_option(self, name: str, value: int) -> None:
-        """Named A/B switch (`dpdf_set_option`): "fuse_mask", "hoist_gi", "gru256_cluster"."""
+        """Named engine switch (`dpdf_set_option`): every name, default and owner test is in docs/OPTIONS.md."""
         _check(self._L.dpdf_set_option(self._h, name.encode(), int(value)))
 
     def debug_fetch(self, name: str) -> np.ndarray:

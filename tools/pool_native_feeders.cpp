@@ -37,3 +37,15 @@ extern "C" int pool_native_feeders(void* streams, void* submit_block, int S, int
     *us_per_round = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / rounds;
     return failed.load();
 }
+
+// The lock-step hop from a NATIVE loop: `calls` consecutive dpdf_streams_process(streams, pcm, 1, out, flags) of ONE host thread, timed here
+// -- what a C / C++ host pays per hop (bench.py's `us_per_call` drives the same entry point from a Python loop: + the interpreter's ~20 us).
+typedef int (*process_fn)(void* s, const float* pcm_in, int n_hops, float* pcm_out, int flags);
+extern "C" int native_hop_loop(void* streams, void* process, int calls, int warm, const float* pcm, float* out, int flags, double* us_per_call) {
+    process_fn f = (process_fn)process;
+    for (int i = 0; i < warm; ++i) if (f(streams, pcm, 1, out, flags)) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < calls; ++i) if (f(streams, pcm, 1, out, flags)) return 1;
+    *us_per_call = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / calls;
+    return 0;
+}
