@@ -833,7 +833,8 @@ def main() -> None:
                     help="time-chunk length in frames (0 = engine default)")
     ap.add_argument("--overlap", type=int, default=-1, help="overlap bit mask (1 stage-2 stream, 2 ERB stream, 8 decoder fork, 16 8-/16-WG GRU-256 clusters; 0 serial; -1 engine default)")
     ap.add_argument("--no-fuse", action="store_true", help="run fc+LN of the DPRNN blocks as separate kernels")
-    ap.add_argument("--limbs", action="store_true", help="A/B and traces only: time the OPT-IN limb kernels (gru64_limbs = 3) as this run's mode; the line says so")
+    ap.add_argument("--fp32-mfma", action="store_true", help="A/B and traces only: time the fp32-MFMA GRU-64 kernels (gru64_limbs = 0, the default of rounds 1-5) as this run's mode; the line says so")
+    ap.add_argument("--limbs", action="store_true", help="the default since round 6 (gru64_limbs = 3: the GRU-64 throughput kernels on bf16 limbs); kept so that older command lines still parse")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 control flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -979,9 +980,11 @@ def main() -> None:
         model.set_chunk_frames(args.chunk)
     if args.overlap >= 0:
         model.set_overlap(args.overlap)
-    # the headline is the fp32-MFMA engine whatever the process environment says (DPDF_GRU64_LIMBS starts every handle in the opt-in mode:
-    # that is how the GPU suite is run under it); --limbs is the explicit A/B
-    model.set_option("gru64_limbs", 3 if args.limbs else 0)
+    # the headline is the library's DEFAULT engine (GRU-64 throughput kernels on bf16 limbs since round 6), whatever the process environment says
+    # (DPDF_GRU64_LIMBS changes the default of every handle: that is how the GPU suite is run under the other family); --fp32-mfma is the explicit A/B
+    MODE = 0 if args.fp32_mfma else 3
+    OTHER = 3 - MODE
+    model.set_option("gru64_limbs", MODE)
     if args.no_fuse:
         model.set_fuse_dprnn(False)
     for kv in args.opt:
@@ -1124,11 +1127,12 @@ def main() -> None:
         iso_prof = model.profile_report()
         model.profile(False)
         model.set_overlap(args.overlap if args.overlap >= 0 else 27)
-    # OPT-IN mode beside the headline (never `value`): the same pipelined steps with the GRU-64 throughput kernels on bf16 limbs
-    # (gru_limb.h, dpdf_set_option gru64_limbs = 3) -- its own timing, its own per-kernel pass, its own parity block
+    # The OTHER GRU-64 kernel family beside the headline (never `value`): the same pipelined steps with dpdf_set_option gru64_limbs = OTHER
+    # (0: the fp32-MFMA kernels of gru_scan.h, the default of rounds 1-5; 3: the bf16-limb kernels of gru_limb.h) -- its own timing, its own
+    # per-kernel pass, its own parity block
     limb = None
-    if rank == 0 and not args.no_isolated and not args.no_fuse and not args.limbs:
-        model.set_option("gru64_limbs", 3)
+    if rank == 0 and not args.no_isolated and not args.no_fuse:
+        model.set_option("gru64_limbs", OTHER)
         step(); sync()
         nl = max(1, min(args.steps, 3))
         t1 = time.perf_counter()
@@ -1144,7 +1148,7 @@ def main() -> None:
         step(); sync()
         limb_iso = model.profile_report()
         model.profile(False); model.set_overlap(args.overlap if args.overlap >= 0 else 27)
-        model.set_option("gru64_limbs", 3 if args.limbs else 0)
+        model.set_option("gru64_limbs", MODE)
         limb = {"ms_per_step": ms_l, "value": B * T / (ms_l * 1e-3), "out": limb_out, "prof": limb_prof, "iso": limb_iso}
 
     mark("per_kernel_event_passes")
@@ -1190,7 +1194,7 @@ def main() -> None:
         #   gru64_epi_kernel<1>    inter-band + fc_inter + LN              49 152 + 2*64*64 FLOP
         # rows*steps per step of the bench: NB blocks x B*T frames x (48 DF + 8 ERB) band positions.
         rs = NB * (B * T) * (48 + 8)
-        # Round 5, OPT-IN (limb_kernels_opt_in below): the same three launches on bf16 LIMBS (gru_limb.h, option gru64_limbs): every fp32 product is formed from
+        # Round 5 (opt-in then, the default since round 6): the same three launches on bf16 LIMBS (gru_limb.h, option gru64_limbs): every fp32 product is formed from
         # 3 x 3 bf16 limbs, six v_mfma_f32_16x16x32_bf16 per term, fp32 accumulation -- same algorithmic (fp32) FLOPs, six times as
         # many matrix FLOPs issued, on a pipe with 16 x the fp32 rate.  `flop` below is the ALGORITHMIC fp32 count per (row, step);
         # `issued` = flop x 6 is what the bf16 pipe executes and what the roofline prices against the bf16 peak.
@@ -1236,9 +1240,13 @@ def main() -> None:
         # words the metric with the H2D / D2H of the PCM inside: that figure is `value_incl_pcie` (measured below in the
         # same run); `value_hbm_resident` repeats `value` under an explicit name.
         line["value_hbm_resident"] = value
-        if args.limbs:
-            line["opt_in_mode"] = "--limbs: THIS RUN times the opt-in limb kernels (dpdf_set_option gru64_limbs = 3), not the default engine"
-            line["dtype"] = "f32 values; GRU-64 products as 3 x 3 bf16 limbs on the bf16 MFMA pipe, fp32 accumulate (opt-in mode)"
+        if MODE == 3:
+            # every value, state and accumulator of the path is fp32 (the analysis DFT float64); the PRODUCTS of the GRU-64 throughput kernels are formed
+            # from three bf16 limbs per operand -- exact where the fp32 MFMA rounds (float64_recurrence_error below: not narrower than fp32)
+            line["dtype"] = "f32 (GRU-64 products as bf16x3 limbs, fp32 accumulate)"
+            line["float64_recurrence_error"] = float64_recurrence_error()
+        else:
+            line["ab_mode"] = "--fp32-mfma: THIS RUN times the fp32-MFMA GRU-64 kernels (dpdf_set_option gru64_limbs = 0), not the default engine"
         if not args.no_parity and timed_out_host:
             line["parity"] = parity_vs_oracle(blob, wav_host, timed_out_host, parity_slots, WEIGHT_SEED + lo)
             mark("parity_vs_oracle")
@@ -1291,9 +1299,9 @@ def main() -> None:
                 "timing": f"HIP events on the launching stream around every launch of {psteps} steps run right after the timed "
                           "region in the same execution shape (the timed region itself runs with these events off: "
                           f"{1e3 * dt / args.steps:.2f} ms/step timed vs {prof_ms:.2f} ms/step with events)",
-                "reproduce": (banked_trace(("limbs_" if args.limbs else "") + "serial") if serial_mode else banked_trace(("limbs_" if args.limbs else "") + "pipelined"))
+                "reproduce": (banked_trace(("fp32mfma_" if MODE == 0 else "") + "serial") if serial_mode else banked_trace(("fp32mfma_" if MODE == 0 else "") + "pipelined"))
                              + ": rocprofv3 --kernel-trace --stats of `python bench.py --no-isolated --no-other-configs --no-cpu-baseline "
-                               "--no-pcie" + (" --overlap 0`" if serial_mode else "`") + " -- every launch of that run has this execution "
+                               "--no-pcie" + (" --fp32-mfma" if MODE == 0 else "") + (" --overlap 0`" if serial_mode else "`") + " -- every launch of that run has this execution "
                                "shape, so the CSV's AverageNs for the kernel is this avg_launch_ms (profiles/README.md)",
                 "gru64_family": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "launches": v["launches"],
                                      "useful_fp32_tflops": round(v["tflops"], 1), "issued_tflops": round(v["issued_tflops"], 1),
@@ -1326,29 +1334,34 @@ def main() -> None:
             line["roofline"] = roofline
             if limb is not None:
                 lk, li = kernel_stats(limb["prof"], 1), kernel_stats(limb["iso"], 1)
-                ld = "gru64_l3_kernel<2>"
+                ld = "gru64_l3_kernel<2>" if OTHER == 3 else "gru64_epi_kernel<2>"
+                lpeak = BF16_MFMA_PEAK_TFLOPS if OTHER == 3 else FP32_MFMA_PEAK_TFLOPS
                 lpar = parity_vs_oracle(blob, wav_host, limb["out"], sorted(limb["out"]), WEIGHT_SEED + lo) if (not args.no_parity and timed_out_host) else None
-                line["limb_kernels_opt_in"] = {
-                    "what": "NOT the headline: the same step with dpdf_set_option(gru64_limbs, 3) -- the three GRU-64 throughput launches of a DPRNN block form every "
-                            "fp32 product from three bf16 limbs per operand (v = hi + mid + lo exactly; six v_mfma_f32_16x16x32_bf16 per term, fp32 accumulate): gru_limb.h. "
-                            "fp32-exact products (closer to a float64 recurrence than the fp32-MFMA kernels: tools/gru64_limb_bench.hip), but another instruction mix than "
-                            "the reference's fp32 -- the headline `value`, `dtype` and `roofline` above are the fp32-MFMA kernels'",
-                    "value": limb["value"], "ms_per_step": limb["ms_per_step"], "speedup_over_headline": (dt / args.steps) / (limb["ms_per_step"] * 1e-3),
-                    "dtype": "f32 (bf16x3 limbs, fp32 accumulate)",
+                what3 = ("the three GRU-64 throughput launches of a DPRNN block form every fp32 product from three bf16 limbs per operand (v = hi + mid + lo exactly; six "
+                         "v_mfma_f32_16x16x32_bf16 per term, fp32 accumulate): gru_limb.h -- fp32-exact products, closer to a float64 recurrence than the fp32-MFMA kernels "
+                         "(float64_recurrence_error)")
+                what0 = ("the GRU-64 throughput launches as v_mfma_f32_16x16x4_f32 kernels (gru_scan.h): the default engine of rounds 1-5, kept as a mode "
+                         "(dpdf_set_option gru64_limbs 0 / DPDF_GRU64_LIMBS=0) and measured here so that both families are on one line")
+                line["limb_kernels" if OTHER == 3 else "fp32_mfma_kernels"] = {
+                    "what": f"NOT the headline: the same step with dpdf_set_option(gru64_limbs, {OTHER}) -- " + (what3 if OTHER == 3 else what0),
+                    "value": limb["value"], "ms_per_step": limb["ms_per_step"],
+                    "headline_over_this": (limb["ms_per_step"] * 1e-3) / (dt / args.steps),
+                    "dtype": "f32 (bf16x3 limbs, fp32 accumulate)" if OTHER == 3 else "f32",
                     "parity": lpar,
-                    "float64_recurrence_error": float64_recurrence_error(),
+                    "float64_recurrence_error": line.get("float64_recurrence_error") or float64_recurrence_error(),
                     "roofline": None if ld not in lk else {
-                        "bound": "mfma", "kernel": ld, "achieved": lk[ld]["issued_tflops"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": lk[ld]["issued_tflops"] / BF16_MFMA_PEAK_TFLOPS,
-                        "frac_isolated": (li[ld]["issued_tflops"] / BF16_MFMA_PEAK_TFLOPS) if ld in li else None,
+                        "bound": "mfma", "kernel": ld, "achieved": lk[ld]["issued_tflops"], "peak": lpeak, "unit": "TFLOP/s",
+                        "frac": lk[ld]["issued_tflops"] / lpeak,
+                        "frac_isolated": (li[ld]["issued_tflops"] / lpeak) if ld in li else None,
                         "useful_fp32_tflops": lk[ld]["tflops"], "useful_fp32_tflops_isolated": li[ld]["tflops"] if ld in li else None,
                         "avg_launch_ms": lk[ld]["avg_launch_ms"], "launches": lk[ld]["launches"],
-                        "accounting": f"achieved = {LIMB_TERMS} x the algorithmic fp32 FLOPs per launch (the bf16 MFMAs issued) / launch duration, against the dense bf16 peak",
+                        "accounting": (f"achieved = {LIMB_TERMS} x the algorithmic fp32 FLOPs per launch (the bf16 MFMAs issued) / launch duration, against the dense bf16 peak"
+                                       if OTHER == 3 else "algorithmic fp32 FLOPs per launch / launch duration, against the fp32 MFMA peak"),
                         "family": {k: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "avg_launch_ms_isolated": round(li[k]["avg_launch_ms"], 4) if k in li else None,
                                        "useful_fp32_tflops": round(v["tflops"], 1), "issued_tflops": round(v["issued_tflops"], 1)} for k, v in lk.items()}},
                 }
                 if lpar is not None and not lpar["ok"]:
-                    print(f"[bench.py] PARITY FAILURE of the opt-in limb kernels: {lpar}", file=sys.stderr, flush=True)
+                    print(f"[bench.py] PARITY FAILURE of the gru64_limbs = {OTHER} kernels: {lpar}", file=sys.stderr, flush=True)
         else:
             line["roofline"] = None
             print("[bench.py] no GRU-64 kernel launches were profiled (--profile-steps 0?): the roofline block is empty", file=sys.stderr)

@@ -24,7 +24,7 @@
 // the host asks for it only while they fit, every wait has the time-out of the GRU-256 clusters behind it (device error flag -> snapshot
 // recovery on the plain launches), and the engine counts recoveries (dpdf_recovery_count).
 // Arithmetic: the per-row operations and their order are those of dprnn_hop_glue8_body / gru64_scan4_body -- a row's result does not
-// depend on which rows share its tile -- so the outputs are bit-identical to the per-block launches (tests/test_gpu_api.py hop forms).
+// depend on which rows share its tile -- so the outputs are bit-identical to the per-block launches (tests/test_gpu_parity.py::test_streaming_hop_forms_equal_the_plain_chain).
 // Reference: onnx_model/layers.py:159-196 (block), :278-302 (streaming inter-band GRUCell).
 #pragma once
 #include <type_traits>

@@ -1,5 +1,5 @@
-// gru_limb.h -- OPT-IN (dpdf_set_option "gru64_limbs" = 3; the default engine and every headline figure use the fp32-MFMA kernels of
-// gru_scan.h): the GRU(64) scans with every fp32 product formed from THREE bf16 limbs per operand on the bf16 matrix pipe.
+// gru_limb.h -- the DEFAULT GRU-64 throughput kernels (dpdf_set_option "gru64_limbs" = 3; 0 selects the fp32-MFMA kernels of gru_scan.h, which the
+// bench line times beside them): the GRU(64) scans with every fp32 product formed from THREE bf16 limbs per operand on the bf16 matrix pipe.
 //
 // The fp32 matrix rate of CDNA4 is 256 FLOP/cycle/CU (v_mfma_f32_16x16x4_f32: 32 cycles per SIMD), the bf16 rate 4096
 // (v_mfma_f32_16x16x32_bf16: 16 cycles for eight times the MACs).  The GRU-64 kernels of gru_scan.h sit at 77-81 % matrix-pipe busy

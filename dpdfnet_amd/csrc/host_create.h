@@ -18,8 +18,8 @@ extern "C" int dpdf_create(const dpdf_cfg* cfg, const float* weights, size_t n_f
     dpdf_model* m = new dpdf_model();
     m->cfg = *cfg; m->d = d; m->device = device;
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) m->n_cus = cus; }
-    // DPDF_GRU64_LIMBS=3: every engine handle of the process starts in the opt-in bf16-limb mode (how the whole GPU suite is run under it:
-    // profiles/r6_gpu_suite_limbs.txt); dpdf_set_option("gru64_limbs", ...) still overrides per handle
+    // DPDF_GRU64_LIMBS=0 (or 1, 2, 3): every engine handle of the process starts with that GRU-64 kernel family -- 3, the bf16-limb kernels, is the
+    // default; 0 the fp32-MFMA kernels (the whole GPU suite is run under both: profiles/r6_gpu_suite_*.txt); dpdf_set_option("gru64_limbs", ...) overrides per handle
     if (const char* e = getenv("DPDF_GRU64_LIMBS")) { const int v = atoi(e); if (v >= 0 && v <= 3) m->gru64_limbs = v; }
     dpdf_get_state_layout(&d, &m->L);
     Blob B; B.base = weights;

@@ -305,8 +305,9 @@ struct dpdf_model {
     long dbg_nspec = 0, dbg_nframes = 0;
     int dft2 = 1;                      // big launches at 48 kHz: the synthesis DFT as two small matrix stages (0: one [2F x win] GEMM; A/B)
     size_t dft64_tw1 = 0, dft64_twm = 0, dft64_tw2 = 0;   // operands of the float64 analysis DFT (dft64.h; doubles stored in the float arena)
-    int gru64_limbs = 0;               // OPT-IN (default off: the headline arithmetic is fp32 MFMA, reviews of rounds 1 and 2); bit 0: intra-band pair, bit 1: inter-band scan: the GRU-64 throughput kernels on bf16 limbs (gru_limb.h: every fp32 product from three bf16 limbs per operand, six
-                                       // bf16 MFMAs per term, fp32 accumulation -- fp32-exact products at 2.67 x the fp32 matrix rate); 0 = the fp32-MFMA kernels of gru_scan.h
+    int gru64_limbs = 3;               // DEFAULT since the end of round 6 (the corruption seen beside these kernels in round 5 was packed FP32 arithmetic; the library has none now): bit 0 intra-band pair, bit 1 inter-band scan -- the GRU-64 throughput kernels
+                                       // on bf16 limbs (gru_limb.h: every fp32 product from three bf16 limbs per operand, six bf16 MFMAs per term, fp32 accumulation -- fp32-exact products at 2.67 x the fp32 matrix rate, closer to a float64 recurrence than the fp32 MFMA);
+                                       // 0 = the fp32-MFMA kernels of gru_scan.h (dpdf_set_option, or DPDF_GRU64_LIMBS=0 for every handle of the process)
     HostPipe hp;                       // pinned staging ring + copy streams of the host-pointer batch calls
     int host_pipe = 1;                 // host-pointer batch calls pipelined over time slices (0: one upload, compute, one download; A/B)
     int gru256_fused_x_tiles = 6;      // ... from this many 16-row tiles on

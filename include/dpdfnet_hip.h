@@ -191,8 +191,8 @@ int dpdf_set_overlap(dpdf_model* m, int mask);
 int dpdf_set_fuse_dprnn(dpdf_model* m, int mode);
 /* Engine switches by name: every name, its default, what it selects and the test that exercises it are ONE table, docs/OPTIONS.md
  * (tests/test_options_table.py keeps the table, the library and the tests in step).  Two kinds: MODES a caller may want --
- * "gru64_limbs" (0 default; 3: the GRU-64 throughput kernels on bf16 limbs, gru_limb.h: fp32-exact products on the bf16 matrix pipe,
- * opt-in), "host_pipe", "host_copy_threads", "snapshot", "tail_frames" -- and A/B switches between kernel forms that give results
+ * "gru64_limbs" (3 default: the GRU-64 throughput kernels on bf16 limbs, gru_limb.h: fp32-exact products on the bf16 matrix pipe; 0: the
+ * fp32-MFMA kernels), "host_pipe", "host_copy_threads", "snapshot", "tail_frames" -- and A/B switches between kernel forms that give results
  * equal to rounding (measurement and recovery only).  Unknown name -> DPDF_E_INVALID. */
 int dpdf_set_option(dpdf_model* m, const char* name, int value);
 

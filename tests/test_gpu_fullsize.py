@@ -190,7 +190,7 @@ def test_config5_64_streams_48khz_dpdfnet8(be):
 
 
 def test_limb_and_fp32_gru64_kernels_agree_on_every_clip_of_a_pipelined_batch(be):
-    """The opt-in GRU-64 throughput kernels on bf16 limbs (gru_limb.h, gru64_limbs = 3) against the default fp32-MFMA kernels of gru_scan.h, 256 clips through
+    """The default GRU-64 throughput kernels on bf16 limbs (gru_limb.h, gru64_limbs = 3) against the fp32-MFMA kernels of gru_scan.h (gru64_limbs = 0), 256 clips through
     the multi-chunk pipeline (stage 2 of a chunk under stage 1 of the next), several times over: every clip within fp32 rounding of the
     other path, each path bit-identical to itself run to run AND to its own serial schedule (one stream, nothing side by side).  This is the
     dynamic guard of DESIGN.md section 6: in round 5 the deep-filter kernel's packed FP32 products (v_pk_fma_f32) lost half of a result
@@ -206,7 +206,7 @@ def test_limb_and_fp32_gru64_kernels_agree_on_every_clip_of_a_pipelined_batch(be
     for rep in range(3):
         assert np.array_equal(y0, m.enhance_batch(wav, None)), rep
     m.set_overlap(0)
-    assert np.array_equal(y0, m.enhance_batch(wav, None)), "default kernels: pipelined schedule differs from the serial one"
+    assert np.array_equal(y0, m.enhance_batch(wav, None)), "fp32-MFMA kernels: pipelined schedule differs from the serial one"
     m.set_option("gru64_limbs", 3)
     y1_serial = m.enhance_batch(wav, None)
     m.set_overlap(27)
@@ -218,7 +218,7 @@ def test_limb_and_fp32_gru64_kernels_agree_on_every_clip_of_a_pipelined_batch(be
     m.set_chunk_frames(0)
     y2 = m.enhance_batch(wav, None)                     # the automatic schedule
     assert np.sqrt(np.mean((y2.astype(np.float64) - y0) ** 2, axis=1)).max() < 5e-7
-    # and against the oracle, at the default path's tolerance
+    # and against the oracle, at the one tolerance both families are held to
     from oracle import oracle as orc
     for b in (0, 131, 255):
         assert rms(y2[b] - orc.Oracle(16000, 4, blob).enhance(wav[b])) < WAVE_TOL, b

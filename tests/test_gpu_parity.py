@@ -129,7 +129,7 @@ def test_fused_and_unfused_dprnn_paths_agree(case):
     spec = o.stft(g["wav"])[:30]
     ref, st_ref = o.run_frames(spec)
     outs = []
-    # fused on bf16 limbs (gru_limb.h, opt-in), fused on the fp32-MFMA kernels (gru_scan.h, the default), unfused -- every golden tag, incl. the
+    # fused on bf16 limbs (gru_limb.h, the default), fused on the fp32-MFMA kernels (gru_scan.h), unfused -- every golden tag, incl. the
     # hot / stiff weights: each against the oracle, and against each other
     for fuse, limbs in ((True, 3), (True, 0), (False, 3)):
         m.set_fuse_dprnn(fuse)
@@ -139,7 +139,7 @@ def test_fused_and_unfused_dprnn_paths_agree(case):
         assert np.abs(st - st_ref).max() < 2e-4 * K(meta), (fuse, limbs)
         outs.append(out)
     m.set_fuse_dprnn("auto")
-    m.set_option("gru64_limbs", 0)
+    m.set_option("gru64_limbs", 3)
     assert np.abs(outs[0] - outs[2]).max() < 2e-5 * K(meta) * float(np.abs(ref).max())
     assert np.abs(outs[0] - outs[1]).max() < 2e-5 * K(meta) * float(np.abs(ref).max())
 

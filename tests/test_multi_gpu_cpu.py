@@ -93,14 +93,14 @@ def test_bench_plain_invocation_becomes_its_own_launcher(monkeypatch):
 
 def test_bench_names_the_banked_trace_of_its_own_mode():
     """bench.banked_trace(kind) is the file the roofline block tells a reader to compare with: the newest profiles/r<N>_<kind>_kernel_stats.csv,
-    by EXACT name -- the opt-in mode's `r5_limbs_pipelined_kernel_stats.csv` is not the default engine's pipelined trace."""
+    by EXACT name -- the A/B mode's `r6_fp32mfma_pipelined_kernel_stats.csv` is not the default engine's pipelined trace."""
     import re
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     sys.path.insert(0, str(root))
     import bench
-    for kind in ("pipelined", "serial", "limbs_pipelined", "limbs_serial"):
+    for kind in ("pipelined", "serial", "fp32mfma_pipelined", "fp32mfma_serial"):
         name = bench.banked_trace(kind)
         assert re.fullmatch(rf"profiles/r\d+_{kind}_kernel_stats\.csv", name), (kind, name)
         assert (root / name).is_file()

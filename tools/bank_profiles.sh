@@ -8,8 +8,8 @@ cp $P/trace_serial/bench_kernel_stats.csv profiles/${T}_serial_kernel_stats.csv
 cp $P/bench_line_under_trace_pipelined.json profiles/${T}_bench_line_under_trace_pipelined.json
 cp $P/bench_line_under_trace_serial.json profiles/${T}_bench_line_under_trace_serial.json
 for m in pipelined serial; do
-    [ -f $P/trace_limbs_$m/bench_kernel_stats.csv ] && cp $P/trace_limbs_$m/bench_kernel_stats.csv profiles/${T}_limbs_${m}_kernel_stats.csv
-    [ -f $P/bench_line_under_trace_limbs_$m.json ] && cp $P/bench_line_under_trace_limbs_$m.json profiles/${T}_bench_line_under_trace_limbs_$m.json
+    [ -f $P/trace_fp32mfma_$m/bench_kernel_stats.csv ] && cp $P/trace_fp32mfma_$m/bench_kernel_stats.csv profiles/${T}_fp32mfma_${m}_kernel_stats.csv
+    [ -f $P/bench_line_under_trace_fp32mfma_$m.json ] && cp $P/bench_line_under_trace_fp32mfma_$m.json profiles/${T}_bench_line_under_trace_fp32mfma_$m.json
 done
 cp $P/pmc_summary.json profiles/${T}_pmc_summary.json; cp $P/pmc_summary.json profiles/pmc_summary.json
 cp $P/build_manifest.json profiles/build_manifest.json

@@ -1,4 +1,4 @@
-"""Opt-in limb kernels (gru64_limbs = 3) against the default fp32-MFMA kernels, 256 clips through the multi-chunk pipeline (eight 64-frame
+"""The limb kernels (gru64_limbs = 3, the default) against the fp32-MFMA kernels (gru64_limbs = 0), 256 clips through the multi-chunk pipeline (eight 64-frame
 chunks: stage 2 of a chunk under stage 1 of the next), run after run: any clip further than 1e-5 (max abs) from the fp32 path is a
 "bad clip" (single wrong low-band frames before the taps were read with agent-scope loads).
 usage: python tools/limb_check4.py [runs=10] [also_automatic_schedule=0]"""

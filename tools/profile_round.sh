@@ -18,11 +18,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pipelined -o 
 grep '^{"metric"' $OUT/bench_trace_pipelined.log > $OUT/bench_line_under_trace_pipelined.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -o bench -- $CMD --overlap 0 > $OUT/bench_trace_serial.log 2>&1
 grep '^{"metric"' $OUT/bench_trace_serial.log > $OUT/bench_line_under_trace_serial.json
-# the opt-in limb kernels (bench.py --limbs), the same two execution shapes
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_limbs_pipelined -o bench -- $CMD --limbs > $OUT/bench_trace_limbs_pipelined.log 2>&1
-grep '^{"metric"' $OUT/bench_trace_limbs_pipelined.log > $OUT/bench_line_under_trace_limbs_pipelined.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_limbs_serial -o bench -- $CMD --limbs --overlap 0 > $OUT/bench_trace_limbs_serial.log 2>&1
-grep '^{"metric"' $OUT/bench_trace_limbs_serial.log > $OUT/bench_line_under_trace_limbs_serial.json
+# the fp32-MFMA GRU-64 kernels (bench.py --fp32-mfma: the default of rounds 1-5, an A/B mode since), the same two execution shapes
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fp32mfma_pipelined -o bench -- $CMD --fp32-mfma > $OUT/bench_trace_fp32mfma_pipelined.log 2>&1
+grep '^{"metric"' $OUT/bench_trace_fp32mfma_pipelined.log > $OUT/bench_line_under_trace_fp32mfma_pipelined.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_fp32mfma_serial -o bench -- $CMD --fp32-mfma --overlap 0 > $OUT/bench_trace_fp32mfma_serial.log 2>&1
+grep '^{"metric"' $OUT/bench_trace_fp32mfma_serial.log > $OUT/bench_line_under_trace_fp32mfma_serial.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $OUT/pmc_mfma -o pmc -- $CMD > $OUT/pmc_mfma.log 2>&1

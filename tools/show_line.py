@@ -2,9 +2,9 @@ import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][0])
 r = d["roofline"]
 print("headline", round(d["value"]), round(d["ms_per_step"], 2), d["dtype"], "parity", d["parity"]["rms_max"], "|", r["kernel"], "frac", round(r["frac"], 3), "iso", r.get("frac_isolated"), "traffic", r["traffic"])
-l = d.get("limb_kernels_opt_in")
+l = d.get("fp32_mfma_kernels") or d.get("limb_kernels")
 if l:
-    print("limbs", round(l["value"]), round(l["ms_per_step"], 2), "x", round(l["speedup_over_headline"], 3), "parity", l["parity"] and l["parity"]["rms_max"], l["parity"] and l["parity"]["ok"])
+    print("other family", round(l["value"]), round(l["ms_per_step"], 2), "headline x", round(l["headline_over_this"], 3), "parity", l["parity"] and l["parity"]["rms_max"], l["parity"] and l["parity"]["ok"])
     print(json.dumps(l["roofline"])[:700])
 oc = d.get("other_configs")
 if oc:
