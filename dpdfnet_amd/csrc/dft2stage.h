@@ -138,6 +138,4 @@ static inline void launch_dft2_inverse(hipStream_t st, const Dft2Args& a) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(dft2_invA_kernel<N2>), dim3((a.M + 15) / 16, 2), dim3(256), 0, st, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(dft2_invB_kernel<N2>), dim3((a.M + FR - 1) / FR), dim3(256), 0, st, a);
 }
-static inline void launch_dft2_inverse(hipStream_t st, const Dft2Args& a, int win) {
-    if (win == 960) launch_dft2_inverse<30>(st, a); else launch_dft2_inverse<10>(st, a);
-}
+static inline void launch_dft2_inverse(hipStream_t st, const Dft2Args& a, int) { launch_dft2_inverse<30>(st, a); }   // 48 kHz only (win 960 = 30 x 32; the callers check): at 16 kHz the one-GEMM form is the faster one

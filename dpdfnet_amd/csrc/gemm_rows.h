@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(AProd ap, const float* _
     // gridDim.x tiles is cut into 8 contiguous slabs, one per XCD, instead of being interleaved across all of them.
     // K split (gridDim.z > 1: few-row launches whose K loop is a chain of load latencies, e.g. the STFT of one streaming hop):
     // block z accumulates panels [z, z + 1) * npanels / gridDim.z and hands its partial sums to the epilogue under the virtual
-    // group index grp + z * gridDim.y; a follow-up kernel adds the partials in a fixed order (ksplit_sum_kernel).
+    // group index grp + z * gridDim.y; the consumer adds the partials in a fixed order (stream_ola_ksplit_kernel).
     const int pper = npanels / (int)gridDim.z, p0 = (int)blockIdx.z * pper, p1 = p0 + pper;
     const int vgrp = grp + (int)blockIdx.z * (int)gridDim.y;
     int tile = blockIdx.x, panel = p0, cur = 0;
@@ -851,14 +851,3 @@ static inline void launch_gemm_rows(hipStream_t st, const AProd& ap, const float
     hipLaunchKernelGGL((gemm_rows_kernel<NT, KP, PERSIST_B, AProd, Epi>), grid, dim3(256), 0, st, ap, wfrag, ep, M, K);
 }
 
-// out[r][c] = (sum over z (in order) of part[r][z][c]) [* colscale[c]], c < ncol: the second half of a K-split launch
-__global__ __launch_bounds__(256) void ksplit_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int M, int ks, int W, int ncol,
-                                                         const float* __restrict__ colscale) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)M * ncol) return;
-    const int r = (int)(i / ncol), c = (int)(i % ncol);
-    const float* p = part + (size_t)r * ks * W + c;
-    float s = p[0];
-    for (int z = 1; z < ks; ++z) s += p[(size_t)z * W];
-    out[i] = colscale ? s * colscale[c] : s;
-}

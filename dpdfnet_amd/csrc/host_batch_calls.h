@@ -281,8 +281,7 @@ static int enhance_impl(dpdf_model* m, const float* wav, int B, int N, const int
             } else {
             PlainSegA<48> ap{m->enh_spec.p, (size_t)2 * d.F, 2 * d.F, seg};
             WindowSegStore<5> ep{m->frames.p, d.win, m->C(m->window), seg};
-            if (m->istft_groups % 4 == 0) launch_gemm_rows_wn<5, 48>(hp.s_down, ap, m->C(m->istft_frag), ep, B * Tc, m->istft_K, m->istft_groups / 4);
-            else launch_gemm_rows<5, 48, false>(hp.s_down, ap, m->C(m->istft_frag), ep, B * Tc, m->istft_K, m->istft_groups);
+            launch_gemm_rows_wn<5, 48>(hp.s_down, ap, m->C(m->istft_frag), ep, B * Tc, m->istft_K, m->istft_groups / 4);      // win / 80 = 4 or 12 column groups: always a multiple of 4
             }
             if (w > 0) {
                 OlaArgs oa{m->frames.p, m->C(m->window), d_out, B, T, N, d.win, d.hop, d_lens, q.v0, w};

@@ -1104,10 +1104,9 @@ void run_dec_convs(dpdf_model* m, XSet& x, float* dembp, int B, int Tc, hipStrea
                        m->C(m->c0out_w), m->c0out_bias, BT};
         const int ntiles = (BT + 1) / 2;
         hipLaunchKernelGGL(dec_last_kernel, dim3(std::min(ntiles, 256 * 3 * 4)), dim3(256), 0, st, da);
-    } else if (m->fuse_mask) {
-        // w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
-        if (d.s1 == 2) run_subpix_mask<2>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
-        else run_subpix_mask<3>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
+    } else if (m->fuse_mask && d.s1 == 3) {
+        // 48 kHz geometry (stride 3; the 16 kHz one is dec_last_kernel above): w.d1 holds the three tap sums per row ([rows][4]) instead of the 64-channel d1 rows
+        run_subpix_mask<3>(m, m->convt1, m->conv1p, e1v, d2v, x.e0.p, w.d1.p, d.Ec, B, Tc);
         // small launches at 48 kHz: the tap sums are finished inside mask_df_kernel (one launch fewer on the hop's chain)
         m->ln->mask_from_sums = m->fuse_small && d.is48 && BT <= SMALL_M_ROWS;
         if (!m->ln->mask_from_sums) {

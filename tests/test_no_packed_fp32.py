@@ -43,3 +43,37 @@ def test_shipped_library_has_no_packed_fp32_instructions():
             hits.setdefault(kernel, []).append(line.split("//")[0].strip())
     assert sum(1 for l in text.splitlines() if re.match(r"^[0-9a-f]+ <_Z", l)) > 50, "disassembly looks empty"
     assert not hits, "packed-FP32 instructions in: " + "; ".join(f"{k} ({len(v)}x, e.g. {v[0]})" for k, v in list(hits.items())[:8])
+
+
+@pytest.mark.skipif(not OBJDUMP.exists(), reason="llvm-objdump of the ROCm toolchain not present")
+def test_every_kernel_of_the_library_is_launched_by_the_gpu_suite():
+    """No dead kernels: profiles/r*_suite_kernel_census.csv is `rocprofv3 --kernel-trace --stats` over `pytest -m gpu` (tools/suite_kernel_census.sh,
+    part of the round's collection) reduced to name + calls; every kernel of the shipped code object must be in it.  (Round 6 found five that
+    were not -- two 16 kHz instantiations of the two-stage synthesis DFT, a K-split sum, two gemm_rows instantiations behind conditions that
+    are never true -- and removed them.)  Skips while the tree runs ahead of the banked evidence, like the manifest test."""
+    import csv
+    import json
+    import sys
+    import __graft_entry__ as ge
+    banked = sorted((ROOT / "profiles").glob("r*_suite_kernel_census.csv"), key=lambda p: int(re.match(r"r(\d+)_", p.name).group(1)))
+    assert banked, "no kernel census banked under profiles/"
+    seen = {r["Name"].replace("void ", "") for r in csv.DictReader(open(banked[-1]))}
+    lib = ge.build_hip()
+    with tempfile.TemporaryDirectory() as td:
+        local = Path(td) / lib.name
+        shutil.copy(lib, local)
+        subprocess.run([str(OBJDUMP), "--offloading", str(local)], check=True, capture_output=True, cwd=td)
+        co = next(p for p in Path(td).iterdir() if "amdgcn-amd-amdhsa--gfx950" in p.name)
+        sym = subprocess.run([str(OBJDUMP.with_name("llvm-readelf")), "-s", "--wide", str(co)], check=True, capture_output=True, text=True).stdout
+    mangled = [l.split()[7] for l in sym.splitlines() if " FUNC " in l and len(l.split()) > 7]
+    names = subprocess.run(["c++filt"], input="\n".join(mangled), check=True, capture_output=True, text=True).stdout.splitlines()
+    kernels = sorted({n.replace("void ", "") for n in names})
+    assert len(kernels) > 50, kernels
+    dead = [k for k in kernels if k not in seen]
+    if dead:
+        sys.path.insert(0, str(ROOT / "tools"))
+        import build_manifest
+        stale = json.loads((ROOT / "profiles" / "build_manifest.json").read_text())["files"] != build_manifest.manifest()
+        if stale:
+            pytest.skip(f"profiles/ is of an earlier build; kernels not in its census: {dead}")
+    assert not dead, f"kernels the GPU suite never launches (remove them, or add the test that does, then re-run tools/collect_round.sh): {dead}"

@@ -24,3 +24,4 @@ grep "wall us/hop\|ms/step" $X/*.log
 [ -f gpurun_out/${T}_pk_fma_coissue_probe.txt ] && grep -v "^    thread" gpurun_out/${T}_pk_fma_coissue_probe.txt > profiles/${T}_pk_fma_coissue_probe_final_build.txt
 tail -4 gpurun_out/${T}_gpu_tests.log > profiles/${T}_gpu_tests_tail.txt
 cp gpurun_out/${T}_soak.txt profiles/${T}_soak.txt 2>/dev/null || true
+[ -f gpurun_out/suite_kernel_census.csv ] && cp gpurun_out/suite_kernel_census.csv profiles/${T}_suite_kernel_census.csv

@@ -12,3 +12,4 @@ python tools/hop_ab2.py - > gpurun_out/${T}_hop_ab.txt 2>&1
 (python tools/stress.py 120 7; python tools/stream_soak.py 120 11; python tools/host_pipe_soak.py 120 13) > gpurun_out/${T}_soak.txt 2>&1
 tail -3 gpurun_out/${T}_soak.txt
 timeout 120 tools/pk_fma_coissue_probe 3 > gpurun_out/${T}_pk_fma_coissue_probe.txt 2>&1; head -8 gpurun_out/${T}_pk_fma_coissue_probe.txt | grep -v "^    thread"
+bash tools/suite_kernel_census.sh > gpurun_out/${T}_suite_kernel_census.log 2>&1; tail -2 gpurun_out/${T}_suite_kernel_census.log
