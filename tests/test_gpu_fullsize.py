@@ -223,3 +223,44 @@ def test_limb_and_fp32_gru64_kernels_agree_on_every_clip_of_a_pipelined_batch(be
     for b in (0, 131, 255):
         assert rms(y2[b] - orc.Oracle(16000, 4, blob).enhance(wav[b])) < WAVE_TOL, b
     m.close()
+
+
+@pytest.mark.parametrize("tag,limbs", [("16k_nb2", 3), ("16k_nb2", 0), ("48k_nb8", 3)])
+def test_nonfinite_clips_in_a_throughput_batch_match_the_reference_and_stay_in_their_slot(be, tag, limbs):
+    """The reference's NaN / +-Inf / denormal goldens (tests/golden/nonfinite_*.npz, make_golden.py:make_nonfinite_fixture from
+    onnx_model/dpdfnet.py:748-852 / dpdfnet_48khz_hr.py:820-924) inside a 256-clip batch: this is the execution shape of the headline -- the
+    FUSED GRU-64 throughput kernels, on bf16 limbs (the default) and as fp32 MFMAs -- where tests/test_gpu_parity.py's non-finite test runs the
+    small-batch forms.  A poisoned clip shares its 16-row tiles with its neighbours' rows; a NaN must not cross a row of a tile (the limb split
+    of a NaN or an Inf is NaN in every limb: it stays in its own row of the matrix product), so: the poisoned slots are non-finite in EXACTLY
+    the reference's samples and equal elsewhere; every other slot is BIT-IDENTICAL to the batch without poisoned clips."""
+    import json
+    from tests.util import GOLDEN, golden_blob
+    g = np.load(GOLDEN / f"nonfinite_{tag}.npz")
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    sr, nb, n = meta["sample_rate"], meta["nb"], meta["n"]
+    m = be.HipModel(sr, nb, golden_blob(meta), 0)
+    m.set_option("gru64_limbs", limbs)
+    B = 256
+    clean = np.stack([synth_clip(n, sr, 4000 + i) for i in range(B)])
+    m.profile(True)
+    base = m.enhance_batch(clean, None)
+    rep = m.profile_report(); m.profile(False)
+    want = "gru64_l3_kernel" if limbs else "gru64_epi_kernel"
+    assert any(k.startswith(want) for k in rep), sorted(rep)           # the fused throughput kernels of that family did run
+    assert np.isfinite(base).all()
+    batch = clean.copy()
+    slots = {cls: s for cls, s in zip(meta["classes"], (1, 16, 127, 200, 255))}      # first / last rows of tiles, the last slot of the batch
+    for cls, s in slots.items():
+        batch[s] = g[f"{cls}_wav"]
+    out = m.enhance_batch(batch, None)
+    for b in range(B):
+        if b not in slots.values():
+            assert np.array_equal(out[b], base[b]), f"clean slot {b} changed beside poisoned clips"
+    for cls, s in slots.items():
+        ref = g[f"{cls}_enhanced"]
+        bad_o, bad_r = ~np.isfinite(out[s]), ~np.isfinite(ref)
+        assert np.array_equal(bad_o, bad_r), (tag, limbs, cls, int(bad_o.sum()), int(bad_r.sum()))
+        fin = ~bad_r
+        if fin.any():
+            assert float(np.abs(out[s][fin] - ref[fin]).max()) < 1e-5, (tag, limbs, cls)
+    m.close()
